@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the `vilma fit` hot path from the REFERENCE itself.
+
+Runs ONLY in the build container (the reference lives at /root/reference and never
+travels).  The reference is imported by path with three inert stand-ins for packages
+that are not installed here (numba -> identity decorators, h5py/plinkio -> empty
+modules; see tests/golden/_shim).  The jitted bodies of vilma.numerics are ordinary
+Python, so the semantics are the reference's own up to summation order.
+
+    PYTHONPATH=tests/golden/_shim:/root/reference/src PYTHONDONTWRITEBYTECODE=1 \
+        python tests/golden/make_golden.py
+
+Outputs (committed, data only):
+    tests/golden/numerics_kat.npz          per-function known-answer vectors (numerics.py)
+    tests/golden/ldop_kat.npz              LowRankMatrix / BlockDiagonalMatrix vectors
+    tests/golden/traj_<name>.npz           class-API trajectories driven through
+                                           MultiPopVI._optimize_step (variational_inference.py:396)
+    tests/golden/mixgrid_kat.npz           vi_options._make_simple outputs (RNG order pin)
+"""
+import io
+import logging
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from vilma import numerics as rn                      # noqa: E402
+from vilma import matrix_structures as rms            # noqa: E402
+from vilma import variational_inference as rvi        # noqa: E402
+from vilma import vi_options as rvo                   # noqa: E402
+
+
+# --------------------------------------------------------------------------------------
+# synthetic inputs (recipe of SURVEY.md section 8d, scaled down)
+# --------------------------------------------------------------------------------------
+def ar1(n, rho):
+    idx = np.arange(n)
+    return rho ** np.abs(idx[:, None] - idx[None, :])
+
+
+def factor_ld(rng, n):
+    m = max(2, int(np.ceil(n / 4)))
+    f = rng.normal(size=(n, m))
+    cov = f @ f.T / m + 0.05 * np.eye(n)
+    d = 1.0 / np.sqrt(np.diag(cov))
+    return cov * np.outer(d, d)
+
+
+def make_problem(seed, P, sizes, M, ldthresh, kind, frac_missing, A, shuffle):
+    rng = np.random.default_rng(seed)
+    n_ld = int(np.sum(sizes))
+    n_missing = int(round(frac_missing * n_ld))
+    N = n_ld + n_missing
+    # which SNP (extract order) sits at each LD-order position
+    order = rng.permutation(N) if shuffle else np.arange(N)
+    ld_members = order[:n_ld]
+    if not shuffle:
+        ld_members = np.sort(rng.choice(N, size=n_ld, replace=False))
+    missing = np.setdiff1d(np.arange(N), ld_members)
+    blocks = []     # blocks[p][b] = dense symmetric matrix handed to LowRankMatrix(X, t)
+    for p in range(P):
+        this = []
+        for n in sizes:
+            if kind == 'ar1':
+                this.append(ar1(n, rng.uniform(0.5, 0.95)))
+            else:
+                this.append(factor_ld(rng, n))
+        blocks.append(this)
+    perm = np.concatenate([ld_members, missing]).astype(np.int64)
+
+    se = rng.uniform(0.005, 0.02, size=(P, N))
+    causal = rng.random(N) < 0.05
+    cov = 0.01 ** 2 * (0.2 * np.eye(P) + 0.8 * np.ones((P, P)))
+    beta = np.zeros((P, N))
+    beta[:, causal] = rng.multivariate_normal(np.zeros(P), cov, size=int(causal.sum())).T
+    betahat = np.zeros((P, N))
+    for p in range(P):
+        start = 0
+        z_true = (beta[p] / se[p])[perm]
+        out = np.zeros(N)
+        for X in blocks[p]:
+            n = X.shape[0]
+            w, v = np.linalg.eigh(X)
+            w = np.maximum(w, 0)
+            half = (v * np.sqrt(w)) @ v.T
+            out[start:start + n] = X @ z_true[start:start + n] + half @ rng.normal(size=n)
+            start += n
+        inv_perm = np.argsort(perm)
+        betahat[p] = se[p] * out[inv_perm]
+    betahat[:, missing] = 0.0        # the loader sets BETA=0, SE=1 for SNPs it cannot use
+    se[:, missing] = 1.0
+
+    var = np.geomspace(1e-8, 1e-2, M)
+    covs = []
+    for k in range(M):
+        if P == 1:
+            covs.append(np.array([[var[k]]]))
+        else:
+            r = (0.0, 0.5, 0.9)[k % 3]
+            covs.append(var[k] * ((1 - r) * np.eye(P) + r * np.ones((P, P))))
+    annotations = np.zeros((N, A))
+    annotations[np.arange(N), rng.integers(0, A, size=N)] = 1
+    return dict(P=P, N=N, M=M, A=A, sizes=np.asarray(sizes, dtype=np.int64), perm=perm,
+                missing=missing.astype(np.int64), blocks=blocks, ldthresh=ldthresh,
+                betahat=betahat, se=se, covs=np.array(covs), annotations=annotations)
+
+
+def build_reference_vi(prob, scaled, scale_se, num_its, gwas_N, init_hg):
+    ld_mats = []
+    for p in range(prob['P']):
+        mats = [rms.LowRankMatrix(X, prob['ldthresh']) for X in prob['blocks'][p]]
+        ld_mats.append(rms.BlockDiagonalMatrix(mats, perm=prob['perm'],
+                                               missing=prob['missing']))
+    vi = rvi.MultiPopVI(marginal_effects=prob['betahat'], std_errs=prob['se'],
+                        ld_mats=ld_mats, mixture_covs=list(prob['covs']),
+                        annotations=prob['annotations'], checkpoint=False,
+                        checkpoint_freq=-1, output='golden', scaled=scaled,
+                        scale_se=scale_se, gwas_N=np.asarray(gwas_N, dtype=float),
+                        init_hg=np.asarray(init_hg, dtype=float), num_its=num_its)
+    return vi, ld_mats
+
+
+class ObjectiveLog(logging.Handler):
+    """Collects the sequence of line-search trial objectives the reference logs."""
+    def __init__(self):
+        super().__init__(level=logging.INFO)
+        self.records = []
+
+    def emit(self, record):
+        self.records.append((record.msg, record.args))
+
+
+def trajectory(name, prob, n_sweeps, scaled=False, scale_se=False, seed=42,
+               gwas_N=None, init_hg=None, full_optimize_its=None):
+    P = prob['P']
+    gwas_N = [1e5] * P if gwas_N is None else gwas_N
+    init_hg = [0.1] * P if init_hg is None else init_hg
+    vi, ld_mats = build_reference_vi(prob, scaled, scale_se, n_sweeps, gwas_N, init_hg)
+
+    # instrument: count LD matvecs and record every objective the loop evaluates
+    counts = {'dot': 0}
+    for ld in ld_mats:
+        orig = ld.dot
+
+        def counted(vec, _orig=orig):
+            counts['dot'] += 1
+            return _orig(vec)
+        ld.dot = counted
+    objs = []
+    orig_elbo, orig_bobj = vi.elbo, vi._beta_objective
+
+    def elbo_logged(params):
+        v = orig_elbo(params)
+        objs.append((0.0, float(v)))
+        return v
+
+    def bobj_logged(params):
+        v = orig_bobj(params)
+        objs.append((1.0, float(v)))
+        return v
+    vi.elbo, vi._beta_objective = elbo_logged, bobj_logged
+
+    np.random.seed(seed)
+    params = vi._initialize()
+    out = {}
+    out['init_vi_mu'], out['init_vi_delta'], out['init_hyper_delta'] = [np.copy(x) for x in params]
+    out['init_nat_grad_vi_delta'] = np.copy(vi.nat_grad_vi_delta)
+    elbo = vi.elbo(params)
+    out['init_elbo'] = elbo
+    L = np.ones(5)
+    red = None
+    elbos, Ls, reds, taus, hypers, pmeans, dots, nobj = [], [], [], [], [], [], [], []
+    for it in range(n_sweeps):
+        d0, o0 = counts['dot'], len(objs)
+        params, L, elbo, red = vi._optimize_step(params, L=L, curr_elbo=elbo,
+                                                 line_search_rate=2.,
+                                                 running_elbo_delta=red)
+        params = tuple(params)
+        elbos.append(float(elbo)); Ls.append(np.copy(L)); reds.append(float(red))
+        taus.append(np.copy(vi.error_scaling)); hypers.append(np.copy(params[2]))
+        pmeans.append(vi.real_posterior_mean(*params))
+        dots.append(counts['dot'] - d0); nobj.append(len(objs) - o0)
+        print('  %s sweep %d elbo %.10f L0 %.4f dots %d' % (name, it, elbo, L[0], dots[-1]),
+              flush=True)
+    out.update(
+        P=P, N=prob['N'], M=prob['M'], A=prob['A'], sizes=prob['sizes'], perm=prob['perm'],
+        missing=prob['missing'], ldthresh=prob['ldthresh'], betahat=prob['betahat'],
+        se=prob['se'], covs=prob['covs'], annotations=prob['annotations'],
+        scaled=scaled, scale_se=scale_se, seed=seed, gwas_N=np.asarray(gwas_N, dtype=float),
+        init_hg=np.asarray(init_hg, dtype=float),
+        # derived constants (VIScheme.__init__, variational_inference.py:189-252)
+        ld_diags=vi.ld_diags, adj_marginal_effects=vi.adj_marginal_effects,
+        chi_stat=vi.chi_stat, ld_ranks=vi.ld_ranks, inverse_betas=vi.inverse_betas,
+        scalings=vi.scalings, mixture_prec=vi.mixture_prec, log_det=vi.log_det,
+        # trajectory
+        elbo=np.array(elbos), L=np.array(Ls), running_elbo_delta=np.array(reds),
+        error_scaling=np.array(taus), hyper_delta=np.array(hypers),
+        post_mean=np.array(pmeans), dots_per_sweep=np.array(dots),
+        objs_per_sweep=np.array(nobj), objective_log=np.array(objs),
+        final_vi_mu=params[0], final_vi_delta=params[1], final_hyper_delta=params[2],
+        final_post_var=vi.real_posterior_variance(*params), final_vi_sigma=vi.vi_sigma,
+    )
+    for p in range(P):
+        for b, X in enumerate(prob['blocks'][p]):
+            out['ld_%d_%d' % (p, b)] = X
+        for b, m in enumerate(ld_mats[p].matrices):
+            out['rank_%d_%d' % (p, b)] = m.s.shape[0]
+
+    if full_optimize_its is not None:
+        # a second, independent object driven through optimize() to pin the convergence
+        # rule and iteration count (variational_inference.py:340-394)
+        vi2, _ = build_reference_vi(prob, scaled, scale_se, full_optimize_its, gwas_N, init_hg)
+        handler = ObjectiveLog()
+        root = logging.getLogger()
+        old_level = root.level
+        root.addHandler(handler); root.setLevel(logging.INFO)
+        np.random.seed(seed)
+        fin = vi2.optimize()
+        root.removeHandler(handler); root.setLevel(old_level)
+        n_it = [a[0] for m, a in handler.records if m.startswith('Optimization ran for')]
+        out['opt_num_its'] = int(n_it[0])
+        out['opt_vi_mu'], out['opt_vi_delta'], out['opt_hyper_delta'] = fin
+        out['opt_error_scaling'] = vi2.error_scaling
+        out['opt_post_mean'] = vi2.real_posterior_mean(*fin)
+        print('  %s optimize(): %d iterations' % (name, out['opt_num_its']), flush=True)
+    np.savez_compressed(os.path.join(HERE, 'traj_%s.npz' % name), **out)
+
+
+# --------------------------------------------------------------------------------------
+# per-function KATs (numerics.py, one recipe per function as in tests/test.py:877-1217)
+# --------------------------------------------------------------------------------------
+def numerics_kat():
+    rng = np.random.default_rng(7)
+    out = {}
+    for P, M, N, A in ((1, 5, 37, 1), (2, 4, 50, 2), (3, 6, 21, 3)):
+        t = 'P%d_' % P
+        mu = rng.normal(size=(M, P, N))
+        mu2 = rng.normal(size=(M, P, N))
+        delta = rng.dirichlet(np.ones(M), size=N)
+        B = rng.normal(size=(M, P, P, N))
+        lam = np.einsum('kpqi,krqi->kpri', B, B) + 0.5 * np.eye(P)[None, :, :, None]
+        prec = lam[:, :, :, :1].copy()
+        ann = rng.integers(0, A, size=N).astype(np.int64)
+        hyper = rng.dirichlet(np.ones(M), size=A)
+        log_det = rng.normal(size=M)
+        x = rng.normal(size=(P, N)); y = rng.uniform(0.5, 2, size=(P, N))
+        w = rng.normal(size=(P, N)); z = rng.normal(size=(P, N))
+        chi = rng.uniform(1, 2, size=P); ranks = rng.integers(5, 10, size=P).astype(float)
+        tau = rng.uniform(0.5, 2, size=P)
+        const = rng.normal(size=(N, M)); natd = rng.normal(size=(N, M - 1))
+        out.update({
+            t + 'mu': mu, t + 'mu2': mu2, t + 'delta': delta, t + 'lam': lam, t + 'prec': prec,
+            t + 'ann': ann, t + 'hyper': hyper, t + 'log_det': log_det, t + 'x': x, t + 'y': y,
+            t + 'w': w, t + 'z': z, t + 'chi': chi, t + 'ranks': ranks, t + 'tau': tau,
+            t + 'const': const, t + 'natd': natd,
+            t + 'sum_betas': rn.sum_betas(mu, mu2, 0.3),
+            t + 'fast_divide': rn.fast_divide(x, y),
+            t + 'fast_linked_ests': rn.fast_linked_ests(w, y, x, z),
+            t + 'fast_likelihood': rn.fast_likelihood(x, y, w, z, mu[0], mu2[0], chi, ranks, tau),
+            t + 'fast_posterior_mean': rn.fast_posterior_mean(mu, delta),
+            t + 'fast_pmv': rn.fast_pmv(rn.fast_posterior_mean(mu, delta), mu, delta,
+                                        np.abs(mu2)),
+            t + 'fast_nat_inner_product_m2': rn.fast_nat_inner_product_m2(mu, lam),
+            t + 'fast_nat_inner_product': rn.fast_nat_inner_product(mu, lam),
+            t + 'fast_inner_product_comp': rn.fast_inner_product_comp(mu, prec, delta),
+            t + 'sum_annotations': rn.sum_annotations(delta, ann, A),
+            t + 'fast_delta_kl': rn.fast_delta_kl(delta, hyper, ann),
+            t + 'fast_beta_kl': rn.fast_beta_kl(const, delta),
+            t + 'fast_vi_delta_grad': rn.fast_vi_delta_grad(hyper, log_det, ann),
+            t + 'map_to_nat_cat_2D': rn.map_to_nat_cat_2D(delta),
+            t + 'invert_nat_cat_2D': rn.invert_nat_cat_2D(natd * 40),
+            t + 'fast_invert_nat_vi_delta': rn.fast_invert_nat_vi_delta(mu, mu2, const, natd),
+            t + 'vi_sigma_inv': rn.vi_sigma_inv(lam),
+            t + 'vi_sigma_log_det': rn.vi_sigma_log_det(lam),
+        })
+    np.savez_compressed(os.path.join(HERE, 'numerics_kat.npz'), **out)
+
+
+def ldop_kat():
+    """LowRankMatrix / BlockDiagonalMatrix vectors incl. a rank-deficient block, the
+    degenerate all-below-threshold block and perm/missing (matrix_structures.py)."""
+    rng = np.random.default_rng(11)
+    out = {}
+    sizes = [7, 12, 5]
+    mats = []
+    for b, n in enumerate(sizes):
+        X = factor_ld(rng, n)
+        if b == 1:                       # make it singular: duplicate a SNP
+            X[:, 3] = X[:, 2]; X[3, :] = X[2, :]; X[3, 3] = 1.0
+        mats.append(X)
+        out['X%d' % b] = X
+    N = sum(sizes) + 3
+    perm = rng.permutation(N).astype(np.int64)
+    missing = perm[-3:].copy()
+    out['perm'] = perm; out['missing'] = missing
+    vec = rng.normal(size=N); out['vec'] = vec
+    reg = rng.uniform(0.5, 2.0, size=N); out['reg'] = reg
+    for t in (1.0, 0.8, 0.3):
+        lrs = [rms.LowRankMatrix(X, t) for X in mats]
+        bd = rms.BlockDiagonalMatrix(lrs, perm=perm, missing=missing)
+        tag = 't%02d_' % int(t * 10)
+        out[tag + 'dot'] = bd.dot(vec)
+        out[tag + 'inv_dot'] = bd.inverse.dot(vec)
+        out[tag + 'ridge'] = bd.ridge_inverse_dot(vec, reg)
+        out[tag + 'ridge_scalar'] = bd.ridge_inverse_dot(vec, 0.7)
+        out[tag + 'diag'] = bd.diag()
+        out[tag + 'rank'] = bd.get_rank()
+        out[tag + 'ranks'] = np.array([m.get_rank() for m in lrs])
+        out[tag + 'starts'] = bd.starts
+        out[tag + 'inv_perm'] = bd.inv_perm
+        for b, m in enumerate(lrs):
+            out[tag + 's%d' % b] = m.s
+            out[tag + 'recon%d' % b] = (np.asarray(m.u) * m.s) @ np.asarray(m.v)
+    # degenerate block: every eigenvalue below the threshold -> rank-1 zero operator
+    Xs = 0.01 * np.eye(4)
+    lr = rms.LowRankMatrix(Xs, 0.5)
+    out['degenerate_X'] = Xs
+    out['degenerate_s'] = lr.s
+    out['degenerate_rank'] = lr.get_rank()
+    out['degenerate_dot'] = lr.dot(np.arange(4.0))
+    np.savez_compressed(os.path.join(HERE, 'ldop_kat.npz'), **out)
+
+
+def mixgrid_kat():
+    out = {}
+    for P, K in ((1, 5), (2, 3), (3, 2)):
+        np.random.seed(42)
+        mins = np.linspace(1e-6, 2e-6, P); maxes = np.linspace(1e-2, 3e-2, P)
+        covs = rvo._make_simple(P, K, mins, maxes)
+        out['P%d_K%d' % (P, K)] = np.array(covs)
+        out['P%d_K%d_mins' % (P, K)] = mins
+        out['P%d_K%d_maxes' % (P, K)] = maxes
+        out['P%d_K%d_next_uniform' % (P, K)] = np.random.uniform()
+    np.savez_compressed(os.path.join(HERE, 'mixgrid_kat.npz'), **out)
+
+
+def main():
+    which = set(sys.argv[1:])
+
+    def want(name):
+        return not which or name in which
+
+    if want('kat'):
+        numerics_kat(); ldop_kat(); mixgrid_kat()
+    if want('p1_dense'):
+        prob = make_problem(1, P=1, sizes=[90, 60, 120, 75, 100, 55], M=25, ldthresh=1.0,
+                            kind='ar1', frac_missing=0.0, A=1, shuffle=False)
+        trajectory('p1_dense', prob, n_sweeps=12, full_optimize_its=40)
+    if want('p2_lowrank'):
+        prob = make_problem(2, P=2, sizes=[80, 110, 60, 95, 70], M=40, ldthresh=0.8,
+                            kind='factor', frac_missing=0.05, A=1, shuffle=True)
+        trajectory('p2_lowrank', prob, n_sweeps=10)
+    if want('p2_scale_se'):
+        prob = make_problem(3, P=2, sizes=[70, 90, 50, 85], M=12, ldthresh=1.0,
+                            kind='ar1', frac_missing=0.05, A=2, shuffle=True)
+        trajectory('p2_scale_se', prob, n_sweeps=14, scale_se=True, gwas_N=[1e5, 5e4],
+                   init_hg=[0.1, 0.3], full_optimize_its=30)
+    if want('p4_general'):
+        prob = make_problem(4, P=4, sizes=[60, 45, 70], M=12, ldthresh=0.9,
+                            kind='factor', frac_missing=0.04, A=1, shuffle=False)
+        trajectory('p4_general', prob, n_sweeps=8)
+    if want('p1_scaled'):
+        prob = make_problem(5, P=1, sizes=[64, 80, 50], M=10, ldthresh=1.0,
+                            kind='ar1', frac_missing=0.03, A=3, shuffle=True)
+        trajectory('p1_scaled', prob, n_sweeps=10, scaled=True, scale_se=True)
+
+
+if __name__ == '__main__':
+    main()
