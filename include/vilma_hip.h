@@ -1,0 +1,173 @@
+/*
+ * vilma_hip.h -- C-ABI of libvilma_hip.so: the MI355X (gfx950) implementation of the
+ * `vilma fit` variational-inference hot path.
+ *
+ * The reference (jeffspence/vilma v0.0.16) is pure Python + numba and has NO FFI; the
+ * boundary it exposes is the Python class API MultiPopVI / BlockDiagonalMatrix.  This header
+ * is the device-side contract *below* that class API: each entry point names the reference
+ * function(s) it replaces (paths relative to /root/reference/src/vilma/).  The Python host
+ * (vilma_amd/) binds it with ctypes -- see INTEGRATION.md for the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, nonzero on failure; vilma_last_error() gives text.
+ *   - all floating point is IEEE double; index arrays are int32/int64 as declared.
+ *   - "host or device" pointers may be either (copies use hipMemcpyDefault).
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  Calls that take a
+ *     stream are asynchronous on it; calls without one synchronise internally.
+ *   - one context drives ONE GPU (the device current at vilma_create).  Multi-GPU = one
+ *     process and one context per GPU, each holding a shard of the SNPs; the host all-reduces
+ *     the small `totals` vectors (RCCL via torch.distributed).
+ *   - SNP-indexed arrays are in the caller's SNP order ("extract order"); LD blocks are given
+ *     in LD order together with perm (LD position -> SNP index), exactly the reference's
+ *     BlockDiagonalMatrix.perm (matrix_structures.py:246-257).
+ */
+#ifndef VILMA_HIP_H
+#define VILMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vilma_ctx vilma_ctx;
+
+/* number of doubles in a `totals` vector for P cohorts:
+ *   [0,P)    lin_p  = sum_i m_pi * adj_pi
+ *   [P,2P)   var_p  = sum_i (ld_diag_pi / se_pi^2) * v_pi
+ *   [2P,3P)  quad_p = sum_i (R_p z_p)_i * z_pi,  z = m / se
+ *   3P       delta_kl  (numerics.py:132-141)
+ *   3P+1     ip_comp   (numerics.py:98-115)
+ *   3P+2     beta_kl   (numerics.py:144-146)
+ * These are the per-shard sums from which fast_likelihood (numerics.py:31-46) and _beta_KL
+ * (variational_inference.py:873-885) are assembled on the host after the all-reduce. */
+#define VILMA_NTOTALS(P) (3 * (P) + 3)
+
+/* number of doubles written by vilma_mean_diff */
+#define VILMA_NDIFF 6
+
+const char *vilma_version(void);
+
+/* Error text of the last failing call on `ctx` (or of vilma_create when ctx == NULL). */
+const char *vilma_last_error(const vilma_ctx *ctx);
+
+/* Create a context for a shard with P cohorts, N SNPs, M mixture components, A annotations
+ * on the current HIP device.  Replaces the array allocations of VIScheme.__init__ /
+ * MultiPopVI.__init__ (variational_inference.py:96-259, 599-630). */
+int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out);
+void vilma_destroy(vilma_ctx *ctx);
+
+/* ---- static per-SNP data -------------------------------------------------------------- */
+
+/* adj [P*N]   adj_marginal_effects           (variational_inference.py:226-243)
+ * se  [P*N]   std_errs (ones when --scaled)  (variational_inference.py:205-214)
+ * sld [P*N]   scaled_ld_diags = ld_diags / se^2   (variational_inference.py:215)
+ * scalings [P*N]  (variational_inference.py:211-214)
+ * annot [N]   annotation index per SNP       (variational_inference.py:217) */
+int vilma_set_snp_data(vilma_ctx *ctx, const double *adj, const double *se, const double *sld,
+                       const double *scalings, const int32_t *annot);
+
+/* prec [M*P*P] mixture_prec, log_det [M]     (variational_inference.py:621-626) */
+int vilma_set_mixture(vilma_ctx *ctx, const double *prec, const double *log_det);
+
+/* error_scaling tau [P]; on device vi_sigma, nat_sigma, vi_sigma_log_det, vi_sigma_matches and
+ * sigma_summary are functions of (prec, sld, tau) recomputed inside the kernels, so this call
+ * is the whole of _set_vi_sigma (variational_inference.py:712-733). */
+int vilma_set_tau(vilma_ctx *ctx, const double *tau);
+
+/* hyper_delta [A*M]; defines nat_grad_vi_delta = fast_vi_delta_grad(hyper, log_det, annot)
+ * (numerics.py:149-164, variational_inference.py:844-848) as an [A,M] table on device. */
+int vilma_set_hyper(vilma_ctx *ctx, const double *hyper);
+
+/* ---- LD operator: BlockDiagonalMatrix (matrix_structures.py:237-447) -------------------- */
+
+/* Start cohort `cohort`.  perm [N] int64: perm[t] = SNP index at LD position t; the first
+ * n_ld positions are covered by blocks (in the order they are added), the remaining N-n_ld are
+ * the `missing` SNPs (zero rows/columns).  total_elems = sum over blocks of the element count
+ * each add call will store (see below) -- lets the library make one allocation. */
+int vilma_ld_begin(vilma_ctx *ctx, int cohort, int n_blocks, int64_t n_ld, const int64_t *perm,
+                   int64_t total_elems);
+
+/* Element counts to use in total_elems (row padding to an even leading dimension). */
+int64_t vilma_ld_dense_elems(int n);
+int64_t vilma_ld_lowrank_elems(int n, int r);
+
+/* Add the next block as a dense symmetric n x n matrix R (row-major, host or device).  For the
+ * reference's blocks R must be the reconstruction U diag(s) U^T of the kept eigenpairs
+ * (LowRankMatrix, matrix_structures.py:95-152), NOT the raw .npy matrix. */
+int vilma_ld_add_dense(vilma_ctx *ctx, int cohort, int n, const double *R);
+
+/* Add the next block in eigen form: U [n*r] row-major, s [r]; dot = U (s * (U^T x))
+ * (LowRankMatrix.dot, matrix_structures.py:148-152). */
+int vilma_ld_add_lowrank(vilma_ctx *ctx, int cohort, int n, int r, const double *U,
+                         const double *s);
+
+int vilma_ld_end(vilma_ctx *ctx, int cohort);
+
+/* y = R_cohort . x for cohort in [0,P) or all cohorts when cohort < 0: BlockDiagonalMatrix.dot
+ * (matrix_structures.py:389-408) including the perm gather, inv_perm scatter and zeros at
+ * missing.  x, y: device pointers [P*N] in SNP order (row p = cohort p). */
+int vilma_ld_matvec(vilma_ctx *ctx, void *stream, int cohort, const double *x, double *y);
+
+/* Algorithmic bytes one vilma_eval/vilma_trial_beta streams from the LD store (all cohorts):
+ * 8 * sum_b n_b^2 (dense) or 8 * sum_b n_b r_b (eigen form, U counted once) -- SURVEY.md 8(d).
+ * stored_bytes = bytes actually resident (eigen form stores U and diag(s)U^T). */
+int vilma_ld_bytes(const vilma_ctx *ctx, int64_t *algorithmic_bytes, int64_t *stored_bytes);
+
+/* ---- variational state ---------------------------------------------------------------- */
+
+/* vi_mu [M*P*N] (reference layout [M][P][N]).  vi_delta is never stored: it is the function
+ * of (vi_mu, hyper, tau) given by _nat_to_not_vi_delta (variational_inference.py:632-641). */
+int vilma_set_mu(vilma_ctx *ctx, const double *vi_mu);
+int vilma_get_mu(vilma_ctx *ctx, double *vi_mu);
+/* vi_delta [N*M] (reference layout) of the current state. */
+int vilma_get_delta(vilma_ctx *ctx, double *vi_delta);
+/* posterior mean / marginal variance [P*N] of the current state, without scalings
+ * (_posterior_mean, _posterior_marginal_variance, variational_inference.py:753-760). */
+int vilma_get_moments(vilma_ctx *ctx, double *mean, double *var);
+
+/* ---- objective evaluations (asynchronous on `stream`) ---------------------------------- */
+
+/* Evaluate the ELBO pieces at the CURRENT vi_mu with the current hyper/tau: one fused per-SNP
+ * pass (fast_posterior_mean, fast_pmv, fast_invert_nat_vi_delta, fast_delta_kl,
+ * fast_inner_product_comp, fast_beta_kl: numerics.py:49-65, 98-146, 179-213) + one LD matvec
+ * per cohort + the fast_likelihood sums.  Results become the *trial* moments; writes
+ * VILMA_NTOTALS(P) doubles to totals_dev (device pointer).  Replaces elbo()/_log_likelihood/
+ * _beta_KL (variational_inference.py:412-417, 452-470, 873-885). */
+int vilma_eval(vilma_ctx *ctx, void *stream, double *totals_dev);
+
+/* One line-search trial of _update_beta (variational_inference.py:777-787) from the current
+ * state with step size `step` = 1/L: natural-gradient blend (sum_betas, numerics.py:11-15;
+ * _nat_grad_beta, variational_inference.py:804-823), new_mu, new_vi_delta, and the objective
+ * pieces of the candidate.  The candidate is held as the trial state. */
+int vilma_trial_beta(vilma_ctx *ctx, void *stream, double step, double *totals_dev);
+
+/* Make the trial state current.  take_mu != 0 after an accepted vilma_trial_beta; 0 after a
+ * vilma_eval (vi_mu unchanged, only the moments / LD product move). */
+int vilma_accept(vilma_ctx *ctx, int take_mu);
+
+/* sums [A*M] = sum_annotations(vi_delta) of the current state (numerics.py:118-129), the
+ * M-step statistic and the payload of the cross-GPU all-reduce. */
+int vilma_delta_sums(vilma_ctx *ctx, void *stream, double *sums_dev);
+
+/* Convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
+ * between the current state and the snapshot taken by the previous call (or by
+ * vilma_snapshot_mean): out_dev[0] = #entries violating |new-old| <= 1e-6 + 1e-6|old|,
+ * [1] = sum |new-old|, [2] = sum (new-old)^2, [3] = max |new|, [4] = max |new-old|,
+ * [5] = max |(new-old)/(old+1e-100)|.  Then the snapshot is replaced by the current mean. */
+int vilma_mean_diff(vilma_ctx *ctx, void *stream, double *out_dev);
+int vilma_snapshot_mean(vilma_ctx *ctx, void *stream);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+
+/* When enabled, every LD-matvec kernel launch is bracketed by HIP events on its stream.
+ * vilma_prof_read synchronises the device and returns accumulated kernel milliseconds and the
+ * number of launches since the last reset. */
+int vilma_prof_enable(vilma_ctx *ctx, int enable);
+int vilma_prof_read(vilma_ctx *ctx, double *ms_total, int64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VILMA_HIP_H */

@@ -38,3 +38,50 @@ def relerr(a, b):
     a = np.asarray(a, dtype=float)
     b = np.asarray(b, dtype=float)
     return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-300))) if a.size else 0.0
+
+
+def engine_blocks(ld, form):
+    """LD blocks of an oracle BlockDiagonalLD in the form the HIP engine takes."""
+    out = []
+    for b in ld.blocks:
+        n, r = b.u.shape
+        f = form
+        if form == 'auto':
+            f = 'dense' if 2 * r > n else 'eig'
+        if f == 'dense':
+            out.append(('dense', (b.u * b.s) @ b.u.T))
+        else:
+            out.append(('eig', b.u, b.s))
+    return out
+
+
+def engine_from_oracle(vi, ld, form='auto'):
+    """A HipEngine loaded with the same shard as the oracle object `vi`."""
+    from vilma_amd.engine import HipEngine
+    P, N, M, A = vi.num_pops, vi.num_loci, vi.num_mix, vi.num_annotations
+    eng = HipEngine(P, N, M, A)
+    eng.set_snp_data(vi.adj_marginal_effects, vi.std_errs, vi.scaled_ld_diags, vi.scalings,
+                     vi.annotations)
+    eng.set_mixture(vi.mixture_prec[:, :, :, 0], vi.log_det)
+    eng.set_tau(vi.error_scaling)
+    for p in range(P):
+        n_ld = int(ld[p].starts[-1])
+        eng.load_ld(p, engine_blocks(ld[p], form), ld[p].perm, n_ld)
+    return eng
+
+
+def oracle_totals(vi, params):
+    """The VILMA_NTOTALS(P) sums (include/vilma_hip.h) computed with the oracle."""
+    from oracle import numerics as nm
+    vi_mu, vi_delta, hyper = params
+    mean = vi._posterior_mean(vi_mu, vi_delta)
+    var = vi._posterior_marginal_variance(mean, vi_mu, vi_delta)
+    z = mean / vi.std_errs
+    linked = np.stack([vi.ld_mats[p].dot(z[p]) for p in range(vi.num_pops)])
+    return np.concatenate([
+        (mean * vi.adj_marginal_effects).sum(axis=1),
+        (vi.scaled_ld_diags * var).sum(axis=1),
+        (linked * z).sum(axis=1),
+        [nm.fast_delta_kl(vi_delta, hyper, vi.annotations),
+         nm.fast_inner_product_comp(vi_mu, vi.mixture_prec, vi_delta),
+         nm.fast_beta_kl(vi.sigma_summary, vi_delta)]])

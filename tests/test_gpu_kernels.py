@@ -1,0 +1,134 @@
+"""GPU parity, kernel level: every C-ABI evaluation entry point against the oracle on the
+golden problems (same seeded inputs).  Tolerances: 1e-9 relative on sums (the north-star bar is
+1e-5 on ELBO/posterior means; fp64 kernels with a different summation order land ~1e-13)."""
+import numpy as np
+import pytest
+
+from helpers import (golden, oracle_from_traj, engine_from_oracle, oracle_totals, TRAJ_NAMES)
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-9, atol=1e-9):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('form', ['dense', 'eig', 'auto'])
+@pytest.mark.parametrize('name', TRAJ_NAMES)
+def test_ld_matvec(name, form):
+    """vilma_ld_matvec == BlockDiagonalMatrix.dot incl. perm/missing (matrix_structures.py:389-408)."""
+    g = golden('traj_%s.npz' % name)
+    vi, ld = oracle_from_traj(g)
+    eng = engine_from_oracle(vi, ld, form)
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(vi.num_pops, vi.num_loci))
+    want = np.stack([ld[p].dot(x[p]) for p in range(vi.num_pops)])
+    got = eng.ld_matvec(x)
+    _close(got, want, rtol=1e-11, atol=1e-11)
+    assert np.all(got[:, g['missing']] == 0.0)
+    for p in range(vi.num_pops):           # one cohort at a time leaves the others untouched
+        solo = eng.ld_matvec(x, cohort=p)
+        _close(solo[p], want[p], rtol=1e-11, atol=1e-11)
+    alg, stored = eng.ld_bytes()
+    assert alg > 0 and stored >= alg
+    eng.close()
+
+
+@pytest.mark.parametrize('form', ['dense', 'eig'])
+@pytest.mark.parametrize('name', TRAJ_NAMES)
+def test_eval_trial_and_sums(name, form):
+    from oracle import numerics as nm
+    g = golden('traj_%s.npz' % name)
+    vi, ld = oracle_from_traj(g)
+    eng = engine_from_oracle(vi, ld, form)
+    np.random.seed(int(g['seed']))
+    vi_mu, vi_delta, hyper = vi._initialize()
+    eng.set_hyper(hyper)
+    eng.set_mu(vi_mu)
+
+    # ---- vilma_eval at the initial point
+    tot = eng.eval().cpu().numpy()
+    want = oracle_totals(vi, (vi_mu, vi_delta, hyper))
+    _close(tot, want, rtol=1e-9, atol=1e-8)
+    eng.accept(False)
+    mean, var = eng.get_moments()
+    omean = vi._posterior_mean(vi_mu, vi_delta)
+    _close(mean, omean, rtol=1e-10, atol=1e-14)
+    _close(var, vi._posterior_marginal_variance(omean, vi_mu, vi_delta), rtol=1e-9, atol=1e-16)
+    _close(eng.get_delta(), vi_delta, rtol=1e-9, atol=1e-300)
+    _close(eng.delta_sums().cpu().numpy().reshape(vi.num_annotations, vi.num_mix),
+           nm.sum_annotations(vi_delta, vi.annotations, vi.num_annotations), rtol=1e-10)
+
+    # ---- one line-search trial of _update_beta at step 1/L, L = 1 and 2
+    old_nat = nm.fast_nat_inner_product_m2(vi_mu, vi.nat_sigma)
+    grad = vi._nat_grad_beta(vi_mu, vi_delta, hyper)
+    const = np.copy(vi.vi_sigma_log_det.T)
+    for step in (1.0, 0.5):
+        nat_mu = nm.sum_betas(old_nat, grad, step)
+        new_mu = nm.fast_nat_inner_product(nat_mu, vi.vi_sigma)
+        new_delta = nm.fast_invert_nat_vi_delta(new_mu, nat_mu, const, vi.nat_grad_vi_delta)
+        tot = eng.trial(step).cpu().numpy()
+        _close(tot, oracle_totals(vi, (new_mu, new_delta, hyper)), rtol=1e-9, atol=1e-8)
+    eng.accept(True)
+    _close(eng.get_mu(), new_mu, rtol=1e-9, atol=1e-16)
+    _close(eng.get_delta(), new_delta, rtol=1e-8, atol=1e-300)
+    _close(eng.get_moments()[0], vi._posterior_mean(new_mu, new_delta), rtol=1e-9, atol=1e-14)
+
+    # ---- hyper update: new table, re-evaluate without moving vi_mu
+    new_hyper = nm.sum_annotations(new_delta, vi.annotations, vi.num_annotations)
+    new_hyper = np.maximum(new_hyper / (vi.annotation_counts.reshape((-1, 1)) + 1e-100), 1e-100)
+    new_hyper /= new_hyper.sum(axis=1, keepdims=True)
+    vi.nat_grad_vi_delta = nm.fast_vi_delta_grad(new_hyper, vi.log_det, vi.annotations)
+    _, d2, _ = vi._nat_to_not_vi_delta((new_mu, new_delta, new_hyper))
+    eng.set_hyper(new_hyper)
+    tot = eng.eval().cpu().numpy()
+    _close(tot, oracle_totals(vi, (new_mu, d2, new_hyper)), rtol=1e-9, atol=1e-8)
+    eng.accept(False)
+
+    # ---- error-scaling change re-derives every sigma-dependent constant on the fly
+    vi.error_scaling = np.linspace(0.8, 1.3, vi.num_pops)
+    vi._set_vi_sigma()
+    _, d3, _ = vi._nat_to_not_vi_delta((new_mu, d2, new_hyper))
+    eng.set_tau(vi.error_scaling)
+    tot = eng.eval().cpu().numpy()
+    _close(tot, oracle_totals(vi, (new_mu, d3, new_hyper)), rtol=1e-9, atol=1e-8)
+    eng.close()
+
+
+def test_mean_diff():
+    g = golden('traj_p2_scale_se.npz')
+    vi, ld = oracle_from_traj(g)
+    eng = engine_from_oracle(vi, ld)
+    np.random.seed(1)
+    vi_mu, vi_delta, hyper = vi._initialize()
+    eng.set_hyper(hyper)
+    eng.set_mu(vi_mu)
+    eng.eval(); eng.accept(False)
+    old = vi._posterior_mean(vi_mu, vi_delta) * vi.scalings
+    eng.snapshot_mean()
+    eng.trial(0.7); eng.accept(True)
+    new = eng.get_moments()[0] * vi.scalings
+    d = eng.mean_diff().cpu().numpy()
+    diff = np.abs(new - old)
+    assert d[0] == np.sum(diff > 1e-6 + 1e-6 * np.abs(old))
+    _close(d[1], diff.sum(), rtol=1e-10)
+    _close(d[2], (diff ** 2).sum(), rtol=1e-10)
+    _close(d[3], np.abs(new).max(), rtol=1e-12)
+    _close(d[4], diff.max(), rtol=1e-12)
+    _close(d[5], np.abs((new - old) / (old + 1e-100)).max(), rtol=1e-9)
+    d2 = eng.mean_diff().cpu().numpy()        # snapshot was replaced: no change now
+    assert d2[0] == 0 and d2[4] == 0
+    eng.close()
+
+
+def test_errors_are_loud():
+    from vilma_amd import _lib
+    from vilma_amd.engine import HipEngine
+    with pytest.raises(_lib.VilmaHipError):
+        HipEngine(5, 10, 3, 1)              # P > 4 unsupported
+    eng = HipEngine(1, 10, 3, 1)
+    with pytest.raises(_lib.VilmaHipError):
+        eng.eval()                          # LD not loaded
+    with pytest.raises(_lib.VilmaHipError):
+        eng.load_ld(0, [('dense', np.eye(4))], np.array([0, 1, 2, 3, 3, 5, 6, 7, 8, 9]), 4)
+    eng.close()

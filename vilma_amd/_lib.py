@@ -1,0 +1,82 @@
+"""ctypes binding of libvilma_hip.so (include/vilma_hip.h).
+
+There is no CPU fallback: if the library has not been built, or no GPU is present when a
+context is created, this raises -- the product path never computes the VI sweep on the host.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvilma_hip.so')
+
+_lib = None
+
+
+class VilmaHipError(RuntimeError):
+    pass
+
+
+def ntotals(P):
+    return 3 * P + 3
+
+
+NDIFF = 6
+
+_c_double_p = C.POINTER(C.c_double)
+_c_i32_p = C.POINTER(C.c_int32)
+_c_i64_p = C.POINTER(C.c_int64)
+
+
+def load():
+    """Load the shared library (once) and declare every entry point of vilma_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VilmaHipError(
+            'libvilma_hip.so is not built (%s). Run `python -m vilma_amd.build` or '
+            '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback '
+            'for the fit hot path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    sigs = {
+        'vilma_version': (C.c_char_p, []),
+        'vilma_last_error': (C.c_char_p, [vp]),
+        'vilma_create': (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(vp)]),
+        'vilma_destroy': (None, [vp]),
+        'vilma_set_snp_data': (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        'vilma_set_mixture': (C.c_int, [vp, vp, vp]),
+        'vilma_set_tau': (C.c_int, [vp, vp]),
+        'vilma_set_hyper': (C.c_int, [vp, vp]),
+        'vilma_ld_begin': (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, vp, C.c_int64]),
+        'vilma_ld_dense_elems': (C.c_int64, [C.c_int]),
+        'vilma_ld_lowrank_elems': (C.c_int64, [C.c_int, C.c_int]),
+        'vilma_ld_add_dense': (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        'vilma_ld_add_lowrank': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+        'vilma_ld_end': (C.c_int, [vp, C.c_int]),
+        'vilma_ld_matvec': (C.c_int, [vp, vp, C.c_int, vp, vp]),
+        'vilma_ld_bytes': (C.c_int, [vp, _c_i64_p, _c_i64_p]),
+        'vilma_set_mu': (C.c_int, [vp, vp]),
+        'vilma_get_mu': (C.c_int, [vp, vp]),
+        'vilma_get_delta': (C.c_int, [vp, vp]),
+        'vilma_get_moments': (C.c_int, [vp, vp, vp]),
+        'vilma_eval': (C.c_int, [vp, vp, vp]),
+        'vilma_trial_beta': (C.c_int, [vp, vp, C.c_double, vp]),
+        'vilma_accept': (C.c_int, [vp, C.c_int]),
+        'vilma_delta_sums': (C.c_int, [vp, vp, vp]),
+        'vilma_mean_diff': (C.c_int, [vp, vp, vp]),
+        'vilma_snapshot_mean': (C.c_int, [vp, vp]),
+        'vilma_prof_enable': (C.c_int, [vp, C.c_int]),
+        'vilma_prof_read': (C.c_int, [vp, _c_double_p, _c_i64_p, C.c_int]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)      # AttributeError if the header and the library diverge
+        fn.restype = res
+        fn.argtypes = args
+    lib._vilma_symbols = sorted(sigs)
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(load()._vilma_symbols)

@@ -1,0 +1,42 @@
+"""Build libvilma_hip.so (the hand-written gfx950 kernels + C-ABI) in-tree with hipcc."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libvilma_hip.so')
+SOURCES = ['kernels.hip', 'capi.hip']
+HEADERS = ['kernels.h', os.path.join('..', '..', 'include', 'vilma_hip.h')]
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=True):
+    """hipcc --offload-arch=gfx950 -O3 -shared; cross-compiles without a GPU."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-ffp-contract=on', '-Wall', '-Wno-unused-function',
+           '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv)

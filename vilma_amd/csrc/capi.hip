@@ -1,0 +1,620 @@
+// C-ABI of libvilma_hip.so (see include/vilma_hip.h): context, LD store, state and the
+// evaluation entry points.  Device memory is owned by the context (hipMalloc); kernels run on
+// the stream the caller passes.
+#include "../../include/vilma_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct BlockRec {
+    int form;            // 0 dense, 1 eigen
+    int n, r;
+    int64_t off_a;       // element offset of R or U in the cohort store
+    int64_t off_v;       // element offset of diag(s)U^T (eigen form)
+    int32_t start;       // LD position of the block's first SNP
+    int32_t t_off;       // offset in the cohort's t scratch (eigen form)
+};
+
+struct CohortLd {
+    bool begun = false, ended = false;
+    int n_blocks = 0;
+    int64_t n_ld = 0;
+    double *store = nullptr;
+    int64_t store_elems = 0, store_used = 0;
+    int32_t next_start = 0, t_used = 0;
+    std::vector<BlockRec> blocks;
+    int64_t alg_bytes = 0;
+    LdItem *solo_a = nullptr, *solo_b = nullptr;   // per-cohort item lists (vilma_ld_matvec)
+    int n_solo_a = 0, n_solo_b = 0;
+};
+
+inline int even_up(int n) { return (n + 1) & ~1; }
+
+}  // namespace
+
+struct vilma_ctx {
+    int P = 0, M = 0, A = 0, device = 0;
+    int64_t N = 0;
+    std::string err;
+
+    double *adj = nullptr, *se = nullptr, *sld = nullptr, *scal = nullptr;
+    int32_t *annot = nullptr, *invperm = nullptr;
+    double *prec = nullptr, *log_det = nullptr, *lh = nullptr;
+    std::vector<double> log_det_host;
+    double tau[VILMA_MAX_P];
+
+    double *mu[2] = {nullptr, nullptr};
+    int mu_cur = 0;
+    double *pool[2] = {nullptr, nullptr};
+    double *m[2] = {nullptr, nullptr}, *v[2] = {nullptr, nullptr}, *lse[2] = {nullptr, nullptr};
+    int mom_cur = 0;
+    int64_t pool_elems = 0;
+    bool have_moments = false;
+
+    double *snapshot = nullptr, *snp_partials = nullptr, *dot_partials = nullptr;
+    double *delta_partials = nullptr, *diff_partials = nullptr;
+    int32_t *dot_start = nullptr;
+
+    std::vector<CohortLd> ld;
+    LdItem *items_a = nullptr, *items_b = nullptr;
+    int n_a = 0, n_b = 0;
+    bool ready = false;
+
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+};
+
+namespace {
+
+int fail(vilma_ctx *c, const std::string &msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return 1;
+}
+
+#define HIPCHK(c, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail((c), std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <typename T>
+int dev_alloc(vilma_ctx *c, T **p, int64_t count, bool zero = true) {
+    if (count <= 0) count = 1;
+    HIPCHK(c, hipMalloc((void **)p, (size_t)count * sizeof(T)));
+    if (zero) HIPCHK(c, hipMemset(*p, 0, (size_t)count * sizeof(T)));
+    return 0;
+}
+
+void dev_free(void *p) { if (p) (void)hipFree(p); }
+
+void free_ready(vilma_ctx *c) {
+    for (int s = 0; s < 2; ++s) { dev_free(c->pool[s]); c->pool[s] = nullptr; }
+    dev_free(c->items_a); dev_free(c->items_b); dev_free(c->dot_partials);
+    c->items_a = c->items_b = nullptr; c->dot_partials = nullptr;
+    c->n_a = c->n_b = 0;
+    for (auto &co : c->ld) {
+        dev_free(co.solo_a); dev_free(co.solo_b);
+        co.solo_a = co.solo_b = nullptr; co.n_solo_a = co.n_solo_b = 0;
+    }
+    c->ready = false;
+    c->have_moments = false;
+}
+
+void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, int32_t &slot,
+                std::vector<LdItem> &A, std::vector<LdItem> &B) {
+    const int32_t PN = (int32_t)(c->P * c->N), pN = (int32_t)(p * c->N);
+    for (const BlockRec &b : co.blocks) {
+        if (b.form == 0) {
+            for (int c0 = 0; c0 < b.n; c0 += 128) {
+                LdItem it;
+                it.a = co.store + b.off_a; it.rows = b.n; it.ld = even_up(b.n); it.col0 = c0;
+                it.ncols = b.n; it.x_off = pN + b.start; it.y_off = PN + pN + b.start;
+                it.dot_off = pN + b.start; it.dot_slot = slot++;
+                A.push_back(it);
+            }
+        } else {
+            for (int c0 = 0; c0 < b.r; c0 += 128) {        // t = U^T x
+                LdItem it;
+                it.a = co.store + b.off_a; it.rows = b.n; it.ld = even_up(b.r); it.col0 = c0;
+                it.ncols = b.r; it.x_off = pN + b.start; it.y_off = 2 * PN + t_base + b.t_off;
+                it.dot_off = -1; it.dot_slot = -1;
+                A.push_back(it);
+            }
+            for (int c0 = 0; c0 < b.n; c0 += 128) {        // y = (diag(s) U^T)^T t
+                LdItem it;
+                it.a = co.store + b.off_v; it.rows = b.r; it.ld = even_up(b.n); it.col0 = c0;
+                it.ncols = b.n; it.x_off = 2 * PN + t_base + b.t_off; it.y_off = PN + pN + b.start;
+                it.dot_off = pN + b.start; it.dot_slot = slot++;
+                B.push_back(it);
+            }
+        }
+    }
+}
+
+void sort_items(std::vector<LdItem> &v) {
+    // longest first: workgroup run time ~ rows * slab width
+    std::stable_sort(v.begin(), v.end(), [](const LdItem &x, const LdItem &y) {
+        const int64_t cx = (int64_t)x.rows * std::min(128, x.ncols - x.col0);
+        const int64_t cy = (int64_t)y.rows * std::min(128, y.ncols - y.col0);
+        return cx > cy;
+    });
+}
+
+int upload_items(vilma_ctx *c, const std::vector<LdItem> &v, LdItem **dev) {
+    *dev = nullptr;
+    if (v.empty()) return 0;
+    HIPCHK(c, hipMalloc((void **)dev, v.size() * sizeof(LdItem)));
+    HIPCHK(c, hipMemcpy(*dev, v.data(), v.size() * sizeof(LdItem), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ensure_ready(vilma_ctx *c) {
+    if (c->ready) return 0;
+    for (int p = 0; p < c->P; ++p)
+        if (!c->ld[p].ended) return fail(c, "LD for cohort " + std::to_string(p) + " not loaded");
+    free_ready(c);
+    std::vector<LdItem> A, B;
+    std::vector<int32_t> dstart(c->P + 1, 0);
+    int32_t slot = 0, t_base = 0;
+    for (int p = 0; p < c->P; ++p) {
+        dstart[p] = slot;
+        std::vector<LdItem> sa, sb;
+        int32_t s0 = slot;
+        make_items(c, p, c->ld[p], t_base, s0, sa, sb);
+        // same items, same slots, for the whole-problem lists
+        make_items(c, p, c->ld[p], t_base, slot, A, B);
+        sort_items(sa); sort_items(sb);
+        if (upload_items(c, sa, &c->ld[p].solo_a) || upload_items(c, sb, &c->ld[p].solo_b)) return 1;
+        c->ld[p].n_solo_a = (int)sa.size(); c->ld[p].n_solo_b = (int)sb.size();
+        t_base += c->ld[p].t_used;
+    }
+    dstart[c->P] = slot;
+    sort_items(A); sort_items(B);
+    if (upload_items(c, A, &c->items_a) || upload_items(c, B, &c->items_b)) return 1;
+    c->n_a = (int)A.size(); c->n_b = (int)B.size();
+    const int64_t pool_elems = 2 * (int64_t)c->P * c->N + t_base + 2;
+    if (pool_elems >= (int64_t)1 << 31) return fail(c, "shard too large for 32-bit vector offsets");
+    c->pool_elems = pool_elems;
+    for (int s = 0; s < 2; ++s)
+        if (dev_alloc(c, &c->pool[s], pool_elems)) return 1;
+    if (dev_alloc(c, &c->dot_partials, slot)) return 1;
+    HIPCHK(c, hipMemcpy(c->dot_start, dstart.data(), (c->P + 1) * sizeof(int32_t),
+                        hipMemcpyHostToDevice));
+    c->ready = true;
+    return 0;
+}
+
+void prof_begin(vilma_ctx *c, hipStream_t s, hipEvent_t &e0) {
+    if (!c->prof) return;
+    (void)hipEventCreate(&e0);
+    (void)hipEventRecord(e0, s);
+}
+void prof_end(vilma_ctx *c, hipStream_t s, hipEvent_t e0) {
+    if (!c->prof) return;
+    hipEvent_t e1;
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e1, s);
+    c->pending.emplace_back(e0, e1);
+}
+void prof_resolve(vilma_ctx *c) {
+    for (auto &pr : c->pending) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(pr.second);
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            c->prof_ms += ms;
+            c->prof_launches += 1;
+        }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    c->pending.clear();
+}
+
+// the LD product on pool `pl` (x_ld section -> y_ld section), all cohorts or one
+void run_ld(vilma_ctx *c, hipStream_t s, double *pl, int cohort) {
+    const LdItem *ia = cohort < 0 ? c->items_a : c->ld[cohort].solo_a;
+    const LdItem *ib = cohort < 0 ? c->items_b : c->ld[cohort].solo_b;
+    const int na = cohort < 0 ? c->n_a : c->ld[cohort].n_solo_a;
+    const int nb = cohort < 0 ? c->n_b : c->ld[cohort].n_solo_b;
+    if (na > 0) {
+        hipEvent_t e0;
+        prof_begin(c, s, e0);
+        launch_ld_colsum(ia, na, pl, c->dot_partials, s);
+        prof_end(c, s, e0);
+    }
+    if (nb > 0) {
+        hipEvent_t e0;
+        prof_begin(c, s, e0);
+        launch_ld_colsum(ib, nb, pl, c->dot_partials, s);
+        prof_end(c, s, e0);
+    }
+    if (c->pending.size() > 8192) prof_resolve(c);
+}
+
+void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
+    const int cur = c->mom_cur, tr = 1 - cur;
+    a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
+    a.mu_in = c->mu[c->mu_cur];
+    a.mu_out = c->mu[1 - c->mu_cur];
+    a.adj = c->adj; a.se = c->se; a.sld = c->sld; a.annot = c->annot; a.invperm = c->invperm;
+    a.prec = c->prec; a.log_det = c->log_det; a.lh = c->lh;
+    a.pool_cur = c->pool[cur]; a.m_cur = c->m[cur];
+    a.pool_out = c->pool[tr]; a.m_out = c->m[tr]; a.v_out = c->v[tr]; a.lse_out = c->lse[tr];
+    a.partials = c->snp_partials;
+    a.step = step;
+    for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
+}
+
+void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out) {
+    a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
+    a.mu = c->mu[c->mu_cur]; a.sld = c->sld; a.annot = c->annot;
+    a.prec = c->prec; a.log_det = c->log_det; a.lh = c->lh;
+    a.lse = c->lse[c->mom_cur];
+    a.out = out;
+    for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
+}
+
+int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *totals_dev) {
+    if (ensure_ready(c)) return 1;
+    if (blend && !c->have_moments)
+        return fail(c, "vilma_trial_beta needs an accepted evaluation of the current state");
+    SnpKernelArgs a;
+    fill_snp_args(c, a, step);
+    launch_snp_pass(a, blend, s);
+    run_ld(c, s, c->pool[1 - c->mom_cur], -1);
+    launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start,
+                    totals_dev, s);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vilma_version(void) { return "vilma_hip 0.1 (gfx950)"; }
+
+const char *vilma_last_error(const vilma_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
+    if (!out) return fail(nullptr, "out is NULL");
+    *out = nullptr;
+    if (P < 1 || P > 4) return fail(nullptr, "P must be in 1..4 (cohorts)");
+    if (N < 1 || N >= ((int64_t)1 << 30)) return fail(nullptr, "N out of range");
+    if (M < 2) return fail(nullptr, "M must be >= 2 (mixture components)");
+    if (A < 1) return fail(nullptr, "A must be >= 1 (annotations)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, "no HIP device available");
+    vilma_ctx *c = new vilma_ctx();
+    c->P = P; c->N = N; c->M = M; c->A = A;
+    (void)hipGetDevice(&c->device);
+    c->ld.resize(P);
+    for (int p = 0; p < VILMA_MAX_P; ++p) c->tau[p] = 1.0;
+    const int64_t PN = (int64_t)P * N;
+    int rc = 0;
+    rc |= dev_alloc(c, &c->adj, PN); rc |= dev_alloc(c, &c->se, PN);
+    rc |= dev_alloc(c, &c->sld, PN); rc |= dev_alloc(c, &c->scal, PN);
+    rc |= dev_alloc(c, &c->annot, N); rc |= dev_alloc(c, &c->invperm, PN);
+    rc |= dev_alloc(c, &c->prec, (int64_t)M * P * P); rc |= dev_alloc(c, &c->log_det, M);
+    rc |= dev_alloc(c, &c->lh, (int64_t)A * M);
+    for (int s = 0; s < 2 && !rc; ++s) {
+        rc |= dev_alloc(c, &c->mu[s], (int64_t)M * PN);
+        rc |= dev_alloc(c, &c->m[s], PN); rc |= dev_alloc(c, &c->v[s], PN);
+        rc |= dev_alloc(c, &c->lse[s], N);
+    }
+    rc |= dev_alloc(c, &c->snapshot, PN);
+    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * P + 3));
+    rc |= dev_alloc(c, &c->delta_partials, (int64_t)delta_grid(N) * 4 * A * M);
+    rc |= dev_alloc(c, &c->diff_partials, (int64_t)mean_diff_grid(PN) * 6);
+    rc |= dev_alloc(c, &c->dot_start, P + 1);
+    if (rc) {
+        g_create_error = c->err;
+        vilma_destroy(c);
+        return 1;
+    }
+    c->log_det_host.assign(M, 0.0);
+    *out = c;
+    return 0;
+}
+
+void vilma_destroy(vilma_ctx *c) {
+    if (!c) return;
+    (void)hipDeviceSynchronize();
+    prof_resolve(c);
+    free_ready(c);
+    for (auto &co : c->ld) dev_free(co.store);
+    void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
+                    c->lh, c->mu[0], c->mu[1], c->m[0], c->m[1], c->v[0], c->v[1], c->lse[0],
+                    c->lse[1], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials,
+                    c->dot_start};
+    for (void *p : ptrs) dev_free(p);
+    delete c;
+}
+
+int vilma_set_snp_data(vilma_ctx *c, const double *adj, const double *se, const double *sld,
+                       const double *scalings, const int32_t *annot) {
+    if (!c) return 1;
+    const size_t b = (size_t)c->P * c->N * sizeof(double);
+    HIPCHK(c, hipMemcpy(c->adj, adj, b, hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(c->se, se, b, hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(c->sld, sld, b, hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(c->scal, scalings, b, hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(c->annot, annot, (size_t)c->N * sizeof(int32_t), hipMemcpyDefault));
+    c->have_moments = false;
+    return 0;
+}
+
+int vilma_set_mixture(vilma_ctx *c, const double *prec, const double *log_det) {
+    if (!c) return 1;
+    HIPCHK(c, hipMemcpy(c->prec, prec, (size_t)c->M * c->P * c->P * sizeof(double), hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(c->log_det, log_det, (size_t)c->M * sizeof(double), hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(c->log_det_host.data(), log_det, (size_t)c->M * sizeof(double), hipMemcpyDefault));
+    c->have_moments = false;
+    return 0;
+}
+
+int vilma_set_tau(vilma_ctx *c, const double *tau) {
+    if (!c) return 1;
+    for (int p = 0; p < c->P; ++p) {
+        if (!(tau[p] > 0.0) || !std::isfinite(tau[p])) return fail(c, "error_scaling must be positive");
+        c->tau[p] = tau[p];
+    }
+    return 0;
+}
+
+int vilma_set_hyper(vilma_ctx *c, const double *hyper) {
+    if (!c) return 1;
+    std::vector<double> lh((size_t)c->A * c->M);
+    for (int a = 0; a < c->A; ++a)
+        for (int k = 0; k < c->M; ++k) {
+            const double h = hyper[(size_t)a * c->M + k];
+            if (!(h > 0.0)) return fail(c, "hyper_delta entries must be positive");
+            lh[(size_t)a * c->M + k] = std::log(h) - 0.5 * c->log_det_host[k];
+        }
+    // ordered behind kernels already queued on any stream of this device
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(c->lh, lh.data(), lh.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int64_t vilma_ld_dense_elems(int n) { return (int64_t)n * even_up(n); }
+int64_t vilma_ld_lowrank_elems(int n, int r) {
+    return (int64_t)n * even_up(r) + (int64_t)r * even_up(n);
+}
+
+int vilma_ld_begin(vilma_ctx *c, int cohort, int n_blocks, int64_t n_ld, const int64_t *perm,
+                   int64_t total_elems) {
+    if (!c) return 1;
+    if (cohort < 0 || cohort >= c->P) return fail(c, "cohort out of range");
+    if (n_ld < 0 || n_ld > c->N || n_blocks < 0 || total_elems < 0) return fail(c, "bad LD sizes");
+    HIPCHK(c, hipDeviceSynchronize());
+    free_ready(c);
+    CohortLd &co = c->ld[cohort];
+    dev_free(co.store);
+    co = CohortLd();
+    co.begun = true; co.n_blocks = n_blocks; co.n_ld = n_ld; co.store_elems = total_elems;
+    if (dev_alloc(c, &co.store, total_elems + 2)) return 1;
+    // perm must be a permutation of 0..N-1; invperm[snp] = LD position
+    std::vector<int32_t> inv((size_t)c->N, -1);
+    for (int64_t t = 0; t < c->N; ++t) {
+        const int64_t sidx = perm[t];
+        if (sidx < 0 || sidx >= c->N || inv[(size_t)sidx] != -1)
+            return fail(c, "perm and missing should together contain all of the indices");
+        inv[(size_t)sidx] = (int32_t)t;
+    }
+    HIPCHK(c, hipMemcpy(c->invperm + (size_t)cohort * c->N, inv.data(),
+                        (size_t)c->N * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int vilma_ld_add_dense(vilma_ctx *c, int cohort, int n, const double *R) {
+    if (!c) return 1;
+    if (cohort < 0 || cohort >= c->P) return fail(c, "cohort out of range");
+    CohortLd &co = c->ld[cohort];
+    if (!co.begun || co.ended) return fail(c, "vilma_ld_begin not called for this cohort");
+    if (n < 1) return fail(c, "block size must be positive");
+    if ((int)co.blocks.size() >= co.n_blocks) return fail(c, "more blocks than announced");
+    if (co.next_start + (int64_t)n > co.n_ld) return fail(c, "blocks exceed n_ld");
+    const int64_t need = vilma_ld_dense_elems(n);
+    if (co.store_used + need > co.store_elems) return fail(c, "LD store overflow (total_elems)");
+    double *dst = co.store + co.store_used;
+    HIPCHK(c, hipMemcpy2D(dst, (size_t)even_up(n) * sizeof(double), R, (size_t)n * sizeof(double),
+                          (size_t)n * sizeof(double), (size_t)n, hipMemcpyDefault));
+    BlockRec b{0, n, n, co.store_used, 0, co.next_start, 0};
+    co.blocks.push_back(b);
+    co.store_used += need;
+    co.next_start += n;
+    co.alg_bytes += (int64_t)8 * n * n;
+    return 0;
+}
+
+int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U, const double *s) {
+    if (!c) return 1;
+    if (cohort < 0 || cohort >= c->P) return fail(c, "cohort out of range");
+    CohortLd &co = c->ld[cohort];
+    if (!co.begun || co.ended) return fail(c, "vilma_ld_begin not called for this cohort");
+    if (n < 1 || r < 1) return fail(c, "block size and rank must be positive");
+    if ((int)co.blocks.size() >= co.n_blocks) return fail(c, "more blocks than announced");
+    if (co.next_start + (int64_t)n > co.n_ld) return fail(c, "blocks exceed n_ld");
+    const int64_t need = vilma_ld_lowrank_elems(n, r);
+    if (co.store_used + need > co.store_elems) return fail(c, "LD store overflow (total_elems)");
+    double *dU = co.store + co.store_used;
+    double *dV = dU + (int64_t)n * even_up(r);
+    HIPCHK(c, hipMemcpy2D(dU, (size_t)even_up(r) * sizeof(double), U, (size_t)r * sizeof(double),
+                          (size_t)r * sizeof(double), (size_t)n, hipMemcpyDefault));
+    double *ds = nullptr;
+    HIPCHK(c, hipMalloc((void **)&ds, (size_t)r * sizeof(double)));
+    hipError_t e = hipMemcpy(ds, s, (size_t)r * sizeof(double), hipMemcpyDefault);
+    if (e == hipSuccess) {
+        launch_scaled_transpose(dU, n, r, even_up(r), ds, dV, even_up(n), nullptr);
+        e = hipDeviceSynchronize();
+    }
+    (void)hipFree(ds);
+    if (e != hipSuccess) return fail(c, std::string("eigen-form upload: ") + hipGetErrorString(e));
+    BlockRec b{1, n, r, co.store_used, co.store_used + (int64_t)n * even_up(r), co.next_start,
+               co.t_used};
+    co.blocks.push_back(b);
+    co.store_used += need;
+    co.next_start += n;
+    co.t_used += even_up(r);
+    co.alg_bytes += (int64_t)8 * n * r;
+    return 0;
+}
+
+int vilma_ld_end(vilma_ctx *c, int cohort) {
+    if (!c) return 1;
+    if (cohort < 0 || cohort >= c->P) return fail(c, "cohort out of range");
+    CohortLd &co = c->ld[cohort];
+    if (!co.begun) return fail(c, "vilma_ld_begin not called for this cohort");
+    if ((int)co.blocks.size() != co.n_blocks) return fail(c, "fewer blocks than announced");
+    if (co.next_start != co.n_ld) return fail(c, "blocks do not cover n_ld");
+    co.ended = true;
+    return 0;
+}
+
+int vilma_ld_bytes(const vilma_ctx *c, int64_t *alg, int64_t *stored) {
+    if (!c) return 1;
+    int64_t a = 0, s = 0;
+    for (const auto &co : c->ld) { a += co.alg_bytes; s += co.store_used * 8; }
+    if (alg) *alg = a;
+    if (stored) *stored = s;
+    return 0;
+}
+
+int vilma_ld_matvec(vilma_ctx *c, void *stream, int cohort, const double *x, double *y) {
+    if (!c) return 1;
+    if (cohort >= c->P) return fail(c, "cohort out of range");
+    if (ensure_ready(c)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    double *pl = c->pool[1 - c->mom_cur];     // the trial pool doubles as workspace
+    launch_gather_x(x, c->invperm, pl, (int)c->N, c->P, s);
+    run_ld(c, s, pl, cohort);
+    launch_scatter_y(pl + (int64_t)c->P * c->N, c->invperm, y, (int)c->N, c->P, s);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int vilma_set_mu(vilma_ctx *c, const double *vi_mu) {
+    if (!c) return 1;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(c->mu[c->mu_cur], vi_mu, (size_t)c->M * c->P * c->N * sizeof(double),
+                        hipMemcpyDefault));
+    c->have_moments = false;
+    return 0;
+}
+
+int vilma_get_mu(vilma_ctx *c, double *vi_mu) {
+    if (!c) return 1;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(vi_mu, c->mu[c->mu_cur], (size_t)c->M * c->P * c->N * sizeof(double),
+                        hipMemcpyDefault));
+    return 0;
+}
+
+int vilma_get_delta(vilma_ctx *c, double *vi_delta) {
+    if (!c) return 1;
+    if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    HIPCHK(c, hipDeviceSynchronize());
+    // the trial vi_mu buffer ([M][P][N] >= [M][N]) is free between evaluations: use it as scratch
+    double *scratch = c->mu[1 - c->mu_cur];
+    DeltaArgs a;
+    fill_delta_args(c, a, scratch);
+    launch_delta_write(a, nullptr);
+    HIPCHK(c, hipDeviceSynchronize());
+    std::vector<double> km((size_t)c->M * c->N);
+    HIPCHK(c, hipMemcpy(km.data(), scratch, km.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < c->N; ++i)
+        for (int k = 0; k < c->M; ++k) vi_delta[i * c->M + k] = km[(size_t)k * c->N + i];
+    return 0;
+}
+
+int vilma_get_moments(vilma_ctx *c, double *mean, double *var) {
+    if (!c) return 1;
+    if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    HIPCHK(c, hipDeviceSynchronize());
+    const size_t b = (size_t)c->P * c->N * sizeof(double);
+    if (mean) HIPCHK(c, hipMemcpy(mean, c->m[c->mom_cur], b, hipMemcpyDefault));
+    if (var) HIPCHK(c, hipMemcpy(var, c->v[c->mom_cur], b, hipMemcpyDefault));
+    return 0;
+}
+
+int vilma_eval(vilma_ctx *c, void *stream, double *totals_dev) {
+    if (!c) return 1;
+    return evaluate(c, (hipStream_t)stream, false, 0.0, totals_dev);
+}
+
+int vilma_trial_beta(vilma_ctx *c, void *stream, double step, double *totals_dev) {
+    if (!c) return 1;
+    return evaluate(c, (hipStream_t)stream, true, step, totals_dev);
+}
+
+int vilma_accept(vilma_ctx *c, int take_mu) {
+    if (!c) return 1;
+    if (!c->ready) return fail(c, "nothing to accept");
+    c->mom_cur = 1 - c->mom_cur;
+    if (take_mu) c->mu_cur = 1 - c->mu_cur;
+    c->have_moments = true;
+    return 0;
+}
+
+int vilma_delta_sums(vilma_ctx *c, void *stream, double *sums_dev) {
+    if (!c) return 1;
+    if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    DeltaArgs a;
+    fill_delta_args(c, a, c->delta_partials);
+    launch_delta_sums(a, sums_dev, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int vilma_mean_diff(vilma_ctx *c, void *stream, double *out_dev) {
+    if (!c) return 1;
+    if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,
+                     c->diff_partials, out_dev, true, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int vilma_snapshot_mean(vilma_ctx *c, void *stream) {
+    if (!c) return 1;
+    if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,
+                     c->diff_partials, nullptr, false, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int vilma_prof_enable(vilma_ctx *c, int enable) {
+    if (!c) return 1;
+    c->prof = enable != 0;
+    return 0;
+}
+
+int vilma_prof_read(vilma_ctx *c, double *ms_total, int64_t *launches, int reset) {
+    if (!c) return 1;
+    HIPCHK(c, hipDeviceSynchronize());
+    prof_resolve(c);
+    if (ms_total) *ms_total = c->prof_ms;
+    if (launches) *launches = c->prof_launches;
+    if (reset) { c->prof_ms = 0.0; c->prof_launches = 0; }
+    return 0;
+}
+
+}  // extern "C"

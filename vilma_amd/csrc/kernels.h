@@ -1,0 +1,79 @@
+// Internal launcher interface between capi.hip and kernels.hip (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VILMA_MAX_P 8
+
+// One work item of the block-diagonal LD product: a 128-column slab of one row-major matrix
+// (a dense symmetric block, U, or diag(s)U^T), all rows.  out[c] = sum_j a[j*ld + c] * x[j].
+struct LdItem {
+    const double *a;     // matrix base (row 0, col 0), 16-byte aligned, even ld
+    int32_t rows;        // number of rows (the reduction dimension)
+    int32_t ld;          // leading dimension in doubles (even)
+    int32_t col0;        // first column of this slab (multiple of 128)
+    int32_t ncols;       // total columns of the matrix
+    int32_t x_off;       // offset of x[0] in the vector pool
+    int32_t y_off;       // offset of out[0] (column 0) in the vector pool
+    int32_t dot_off;     // offset in the pool of the vector to dot the output with, or -1
+    int32_t dot_slot;    // where to store this item's partial of that dot product
+};
+
+struct TauArg { double v[VILMA_MAX_P]; };
+
+struct SnpKernelArgs {
+    int32_t N, M, A, P;
+    const double *mu_in;      // [M][P][N]
+    double *mu_out;           // [M][P][N] (trial) or nullptr
+    const double *adj, *se, *sld;        // [P][N]
+    const int32_t *annot;     // [N]
+    const int32_t *invperm;   // [P][N] SNP -> LD position
+    const double *prec;       // [M][P][P]
+    const double *log_det;    // [M]
+    const double *lh;         // [A][M] log hyper - 0.5 log_det
+    const double *pool_cur;   // current vector pool: x_ld [P][N] | y_ld [P][N] | t scratch
+    const double *m_cur;      // [P][N] posterior mean of the current state
+    double *pool_out;         // trial pool (x_ld written)
+    double *m_out, *v_out;    // [P][N]
+    double *lse_out;          // [N]
+    double *partials;         // [grid][2P+3]
+    double step;
+    TauArg tau;
+};
+
+void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s);
+int snp_pass_grid(int64_t N);
+
+void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *dot_partials,
+                      hipStream_t s);
+
+// totals[0..2P) and [3P..3P+3) from the per-SNP partials, totals[2P..3P) from the matvec dots
+void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
+                     const int32_t *dot_start /*[P+1] device*/, double *totals, hipStream_t s);
+
+struct DeltaArgs {
+    int32_t N, M, A, P;
+    const double *mu;         // [M][P][N]
+    const double *sld;        // [P][N]
+    const int32_t *annot;
+    const double *prec, *log_det, *lh;
+    const double *lse;        // [N]
+    double *out;              // mode 0: partial rows [grid*4][A*M]; mode 1: delta [M][N]
+    TauArg tau;
+};
+void launch_delta_sums(const DeltaArgs &a, double *sums_out /*[A*M]*/, hipStream_t s);
+void launch_delta_write(const DeltaArgs &a, hipStream_t s);
+int delta_grid(int64_t N);
+
+void launch_gather_x(const double *x_snp, const int32_t *invperm, double *pool_x, int N, int P,
+                     hipStream_t s);
+void launch_scatter_y(const double *pool_y, const int32_t *invperm, double *y_snp, int N, int P,
+                      hipStream_t s);
+
+// V[c][i] = s[c] * U[i][c]  (U: n x ldu, V: r x ldv)
+void launch_scaled_transpose(const double *U, int n, int r, int ldu, const double *s, double *V,
+                             int ldv, hipStream_t st);
+
+void launch_mean_diff(const double *m_cur, const double *scalings, double *snapshot, int64_t PN,
+                      double *partials, double *out6, bool compare, hipStream_t s);
+int mean_diff_grid(int64_t PN);

@@ -1,0 +1,672 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for the `vilma fit` hot path.
+//
+//   ld_colsum_kernel   block-diagonal LD product (dense blocks and both passes of the eigen
+//                      form) -- replaces BlockDiagonalMatrix.dot / LowRankMatrix.dot
+//                      (reference matrix_structures.py:389-408, 148-152).  HBM-streaming:
+//                      every matrix element is read exactly once with 16-byte coalesced loads.
+//   snp_pass_kernel    fused per-SNP pass: natural-gradient blend, new_mu, mixture
+//                      responsibilities (online softmax), posterior moments, KL and likelihood
+//                      partial sums -- replaces numerics.py:11-146, 179-213 and
+//                      variational_inference.py:762-823, 873-885 for one candidate point.
+//   delta_kernel       responsibilities of the current state reduced per annotation
+//                      (numerics.py:118-129) or written out.
+//   finalize / reduce  deterministic fixed-order reductions of per-workgroup partials.
+//
+// All arithmetic is IEEE double.  vi_sigma, nat_sigma, vi_sigma_log_det, vi_sigma_matches and
+// sigma_summary ([M,P,P,N] / [N,M] arrays in the reference, variational_inference.py:712-733)
+// are never materialised: they are recomputed per (component, SNP) from mixture_prec [M,P,P]
+// and scaled_ld_diags/tau, which turns ~5 full-array streams per pass into ALU work.
+#include "kernels.h"
+
+#define NEG_INF (-__builtin_huge_val())
+
+static __device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+static __device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// --------------------------------------------------------------------------------------------
+// LD product: out[c] = sum_j a[j][c] * x[j] for a 128-column slab.  Lanes run along the columns
+// (2 doubles = 16 B per lane, 1 KiB per wave-load, fully coalesced), the 4 waves of the
+// workgroup take interleaved groups of 8 rows, x[j] is wave-uniform (scalar loads), and there
+// is no cross-lane reduction at all: each lane owns its two output columns.  The four per-wave
+// partials are combined through LDS in a fixed order, so the result is deterministic.
+// --------------------------------------------------------------------------------------------
+#define CS_WAVES 4
+#define CS_ROWS 8
+
+// the matrix pointer comes out of the item table, so hipcc would treat it as a generic (flat)
+// pointer; pin it to the global address space to get global_load_dwordx4
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef const v2d __attribute__((address_space(1))) *gd2_ptr;
+
+__global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
+    const LdItem *__restrict__ items, const double *__restrict__ xpool, double *__restrict__ ypool,
+    const double *__restrict__ dpool, double *__restrict__ dot_partials) {
+    __shared__ double red[CS_WAVES][128];
+    __shared__ double dred[2];
+    const LdItem it = items[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = it.col0 + 2 * lane;
+    const int rows = it.rows;
+    const int64_t ld = it.ld;
+    const double *__restrict__ xp = xpool + it.x_off;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (c < it.ncols) {
+        const double *ap = it.a + c;
+        for (int j = w * CS_ROWS; j < rows; j += CS_WAVES * CS_ROWS) {
+            if (j + CS_ROWS <= rows) {
+                v2d v[CS_ROWS];
+#pragma unroll
+                for (int u = 0; u < CS_ROWS; ++u)
+                    v[u] = *(gd2_ptr)(ap + (int64_t)(j + u) * ld);
+#pragma unroll
+                for (int u = 0; u < CS_ROWS; ++u) {
+                    const double xv = xp[j + u];
+                    acc0 = fma(v[u].x, xv, acc0);
+                    acc1 = fma(v[u].y, xv, acc1);
+                }
+            } else {
+                for (int jj = j; jj < rows; ++jj) {
+                    const v2d v = *(gd2_ptr)(ap + (int64_t)jj * ld);
+                    const double xv = xp[jj];
+                    acc0 = fma(v.x, xv, acc0);
+                    acc1 = fma(v.y, xv, acc1);
+                }
+            }
+        }
+    }
+    red[w][2 * lane] = acc0;
+    red[w][2 * lane + 1] = acc1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int col = it.col0 + threadIdx.x;
+        double s = red[0][threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < CS_WAVES; ++ww) s += red[ww][threadIdx.x];
+        double dv = 0.0;
+        if (col < it.ncols) {
+            ypool[it.y_off + col] = s;
+            if (it.dot_off >= 0) dv = s * dpool[it.dot_off + col];
+        }
+        if (it.dot_off >= 0) {
+            dv = wave_sum(dv);
+            if (lane == 0) dred[threadIdx.x >> 6] = dv;
+        }
+    }
+    if (it.dot_off >= 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) dot_partials[it.dot_slot] = dred[0] + dred[1];
+    }
+}
+
+void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *dot_partials,
+                      hipStream_t s) {
+    if (n_items <= 0) return;
+    // x, y and the dot vector live in one pool; within a launch the regions read and written
+    // are disjoint, so handing the same base to the three restrict parameters is sound
+    hipLaunchKernelGGL(ld_colsum_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items,
+                       (const double *)pool, pool, (const double *)pool, dot_partials);
+}
+
+// --------------------------------------------------------------------------------------------
+// small SPD helpers, fully unrolled so everything stays in registers
+// --------------------------------------------------------------------------------------------
+template <int P>
+static __device__ __forceinline__ double spd_det(const double (&lam)[P][P]) {
+    if constexpr (P == 1) {
+        return lam[0][0];
+    } else if constexpr (P == 2) {
+        return lam[0][0] * lam[1][1] - lam[0][1] * lam[1][0];
+    } else {
+        double G[P][P];
+        double det = 1.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            double s = lam[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= G[j][k] * G[j][k];
+            det *= s;
+            const double gjj = sqrt(s);
+            G[j][j] = gjj;
+            const double inv = 1.0 / gjj;
+#pragma unroll
+            for (int i = j + 1; i < P; ++i) {
+                double t = lam[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) t -= G[i][k] * G[j][k];
+                G[i][j] = t * inv;
+            }
+        }
+        return det;
+    }
+}
+
+// sig = inverse(lam), returns det(lam); lam symmetric positive definite
+template <int P>
+static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], double (&sig)[P][P]) {
+    if constexpr (P == 1) {
+        sig[0][0] = 1.0 / lam[0][0];
+        return lam[0][0];
+    } else if constexpr (P == 2) {
+        // closed form of the reference's 2x2 helper (numerics.py:223-232)
+        const double det = lam[0][0] * lam[1][1] - lam[0][1] * lam[1][0];
+        const double r = 1.0 / det;
+        sig[0][0] = lam[1][1] * r;
+        sig[1][1] = lam[0][0] * r;
+        sig[0][1] = -lam[1][0] * r;
+        sig[1][0] = sig[0][1];
+        return det;
+    } else {
+        double G[P][P], Gi[P][P];
+        double det = 1.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            double s = lam[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= G[j][k] * G[j][k];
+            det *= s;
+            const double gjj = sqrt(s);
+            G[j][j] = gjj;
+            Gi[j][j] = 1.0 / gjj;
+#pragma unroll
+            for (int i = j + 1; i < P; ++i) {
+                double t = lam[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) t -= G[i][k] * G[j][k];
+                G[i][j] = t * Gi[j][j];
+            }
+        }
+        // Gi = inverse of lower-triangular G
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+#pragma unroll
+            for (int i = j + 1; i < P; ++i) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = j; k < i; ++k) t += G[i][k] * Gi[k][j];
+                Gi[i][j] = -t * Gi[i][i];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = a; k < P; ++k) t += Gi[k][a] * Gi[k][b];
+                sig[a][b] = t;
+                sig[b][a] = t;
+            }
+        }
+        return det;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// fused per-SNP pass (one thread per SNP, coalesced along the SNP axis of vi_mu [M][P][N])
+// --------------------------------------------------------------------------------------------
+#define SNP_THREADS 256
+#define KC 4
+
+template <int P, bool BLEND, bool ONE_ANNOT>
+__global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
+    constexpr int NT = 2 * P + 3;
+    __shared__ double red[SNP_THREADS / 64][NT];
+    const int N = a.N, M = a.M;
+    const int64_t N64 = N;
+    const int i = blockIdx.x * SNP_THREADS + threadIdx.x;
+    const bool live = i < N;
+    const int ii = live ? i : N - 1;
+
+    double d[P], se[P], adj[P], sld[P], g[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        se[p] = a.se[p * N64 + ii];
+        adj[p] = a.adj[p * N64 + ii];
+        sld[p] = a.sld[p * N64 + ii];
+        d[p] = sld[p] / a.tau.v[p];
+        g[p] = 0.0;
+    }
+    if (BLEND) {
+        // _nat_grad_beta (variational_inference.py:804-823); identical for every component k
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int pos = a.invperm[p * N64 + ii];
+            const double linked = a.pool_cur[(int64_t)(P + p) * N64 + pos];
+            const double m = a.m_cur[p * N64 + ii];
+            g[p] = (adj[p] - (linked / se[p] - m * sld[p])) / a.tau.v[p];
+        }
+    }
+    const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
+    const double step = a.step;
+
+    double mx = NEG_INF, Z = 0.0, Sdk = 0.0, Sip = 0.0, Sbk = 0.0;
+    double Sm[P], S2[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { Sm[p] = 0.0; S2[p] = 0.0; }
+
+    for (int k0 = 0; k0 < M; k0 += KC) {
+        double u[KC], wk[KC], ipk[KC], ssk[KC], mun[KC][P], sdg[KC][P];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const int k = k0 + kk;
+            if (k < M) {
+                double pr[P][P], lam[P][P], sig[P][P], mu[P], nat[P];
+                const double *pk = a.prec + (int64_t)k * P * P;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+#pragma unroll
+                    for (int q = 0; q < P; ++q) { pr[p][q] = pk[p * P + q]; lam[p][q] = pr[p][q]; }
+                    lam[p][p] += d[p];
+                    mu[p] = a.mu_in[((int64_t)k * P + p) * N64 + ii];
+                }
+                const double det = spd_inverse<P>(lam, sig);
+                const double logdet = log(det);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int q = 0; q < P; ++q) t += lam[p][q] * mu[q];
+                    nat[p] = BLEND ? (step * g[p] + (1.0 - step) * t) : t;
+                }
+                double quad = 0.0;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double t = mu[p];
+                    if (BLEND) {
+                        t = 0.0;
+#pragma unroll
+                        for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+                        if (live) a.mu_out[((int64_t)k * P + p) * N64 + i] = t;
+                    }
+                    mun[kk][p] = t;
+                    sdg[kk][p] = sig[p][p];
+                    quad += t * nat[p];
+                }
+                double ip = 0.0, tr = 0.0;
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        ip += mun[kk][p] * mun[kk][q] * pr[q][p];
+                        tr += pr[p][q] * sig[q][p];
+                    }
+                const double ldk = a.log_det[k];
+                u[kk] = 0.5 * (quad - logdet) + lh[k];
+                wk[kk] = 0.5 * (quad - logdet - ldk);
+                ssk[kk] = ldk + logdet + tr;
+                ipk[kk] = ip;
+            } else {
+                u[kk] = NEG_INF; wk[kk] = 0.0; ssk[kk] = 0.0; ipk[kk] = 0.0;
+#pragma unroll
+                for (int p = 0; p < P; ++p) { mun[kk][p] = 0.0; sdg[kk][p] = 0.0; }
+            }
+        }
+        double cmax = u[0];
+#pragma unroll
+        for (int kk = 1; kk < KC; ++kk) cmax = fmax(cmax, u[kk]);
+        const double nmx = fmax(mx, cmax);
+        const double sc = exp(mx - nmx);
+        mx = nmx;
+        Z *= sc; Sdk *= sc; Sip *= sc; Sbk *= sc;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { Sm[p] *= sc; S2[p] *= sc; }
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const double e = exp(u[kk] - mx);
+            Z += e;
+            Sdk = fma(e, wk[kk], Sdk);
+            Sip = fma(e, ipk[kk], Sip);
+            Sbk = fma(e, ssk[kk], Sbk);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                Sm[p] = fma(e, mun[kk][p], Sm[p]);
+                S2[p] = fma(e, sdg[kk][p] + mun[kk][p] * mun[kk][p], S2[p]);
+            }
+        }
+    }
+    const double invZ = 1.0 / Z;
+    const double lse = mx + log(Z);
+    double part[NT];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const double m = Sm[p] * invZ;
+        const double v = S2[p] * invZ - m * m;
+        if (live) {
+            a.m_out[p * N64 + i] = m;
+            a.v_out[p * N64 + i] = v;
+            a.pool_out[p * N64 + a.invperm[p * N64 + i]] = m / se[p];
+        }
+        part[p] = live ? m * adj[p] : 0.0;
+        part[P + p] = live ? sld[p] * v : 0.0;
+    }
+    if (live) a.lse_out[i] = lse;
+    part[2 * P] = live ? (Sdk * invZ - lse) : 0.0;
+    part[2 * P + 1] = live ? 0.5 * Sip * invZ : 0.0;
+    part[2 * P + 2] = live ? 0.5 * Sbk * invZ : 0.0;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const double s = wave_sum(part[t]);
+        if (lane == 0) red[w][t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NT) {
+        double s = red[0][threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < SNP_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
+        a.partials[(int64_t)blockIdx.x * NT + threadIdx.x] = s;
+    }
+}
+
+int snp_pass_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
+
+template <int P>
+static void launch_snp_pass_p(const SnpKernelArgs &a, bool blend, hipStream_t s) {
+    const dim3 grid(snp_pass_grid(a.N)), block(SNP_THREADS);
+    const bool one = a.A == 1;
+    if (blend) {
+        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((snp_pass_kernel<P, true, false>), grid, block, 0, s, a);
+    } else {
+        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((snp_pass_kernel<P, false, false>), grid, block, 0, s, a);
+    }
+}
+
+void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s) {
+    switch (a.P) {
+        case 1: launch_snp_pass_p<1>(a, blend, s); break;
+        case 2: launch_snp_pass_p<2>(a, blend, s); break;
+        case 3: launch_snp_pass_p<3>(a, blend, s); break;
+        case 4: launch_snp_pass_p<4>(a, blend, s); break;
+        default: break;   // rejected in vilma_create
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// responsibilities of the current state: delta_ik = max(exp(u_ik - lse_i), 1e-100)
+// (invert_nat_cat_2D's clamp, numerics.py:192-194)
+// --------------------------------------------------------------------------------------------
+template <int P, bool ONE_ANNOT, bool WRITE>
+__global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
+    const int N = a.N, M = a.M, A = a.A;
+    const int64_t N64 = N;
+    const int i = blockIdx.x * SNP_THREADS + threadIdx.x;
+    const bool live = i < N;
+    const int ii = live ? i : N - 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double d[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / a.tau.v[p];
+    const int ann = ONE_ANNOT ? 0 : a.annot[ii];
+    const double *lh = a.lh + (int64_t)ann * M;
+    const double lse = a.lse[ii];
+    double *prow = WRITE ? nullptr : a.out + ((int64_t)blockIdx.x * (SNP_THREADS / 64) + w) * A * M;
+    for (int k = 0; k < M; ++k) {
+        double lam[P][P], mu[P];
+        const double *pk = a.prec + (int64_t)k * P * P;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) lam[p][q] = pk[p * P + q];
+            lam[p][p] += d[p];
+            mu[p] = a.mu[((int64_t)k * P + p) * N64 + ii];
+        }
+        const double logdet = log(spd_det<P>(lam));
+        double quad = 0.0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < P; ++q) t += lam[p][q] * mu[q];
+            quad += mu[p] * t;
+        }
+        const double u = 0.5 * (quad - logdet) + lh[k];
+        const double delta = fmax(exp(u - lse), 1e-100);
+        if (WRITE) {
+            if (live) a.out[(int64_t)k * N64 + i] = delta;
+        } else if (ONE_ANNOT) {
+            const double s = wave_sum(live ? delta : 0.0);
+            if (lane == 0) prow[k] = s;
+        } else {
+            for (int aa = 0; aa < A; ++aa) {
+                const double s = wave_sum((live && ann == aa) ? delta : 0.0);
+                if (lane == 0) prow[(int64_t)aa * M + k] = s;
+            }
+        }
+    }
+}
+
+int delta_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
+
+// out[c] = sum over rows of partials[r][c]; lanes along columns, 16 waves over interleaved rows,
+// fixed combination order
+__global__ __launch_bounds__(1024) void reduce_cols_kernel(const double *__restrict__ partials,
+                                                            int rows, int ncols,
+                                                            double *__restrict__ out) {
+    __shared__ double red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (c < ncols)
+        for (int r = w; r < rows; r += 16) s += partials[(int64_t)r * ncols + c];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < ncols) {
+        double t = red[0][lane];
+#pragma unroll
+        for (int ww = 1; ww < 16; ++ww) t += red[ww][lane];
+        out[c] = t;
+    }
+}
+
+template <int P, bool WRITE>
+static void launch_delta_p(const DeltaArgs &a, hipStream_t s) {
+    const dim3 grid(delta_grid(a.N)), block(SNP_THREADS);
+    if (a.A == 1) hipLaunchKernelGGL((delta_kernel<P, true, WRITE>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((delta_kernel<P, false, WRITE>), grid, block, 0, s, a);
+}
+
+template <bool WRITE>
+static void launch_delta_any(const DeltaArgs &a, hipStream_t s) {
+    switch (a.P) {
+        case 1: launch_delta_p<1, WRITE>(a, s); break;
+        case 2: launch_delta_p<2, WRITE>(a, s); break;
+        case 3: launch_delta_p<3, WRITE>(a, s); break;
+        case 4: launch_delta_p<4, WRITE>(a, s); break;
+        default: break;
+    }
+}
+
+void launch_delta_sums(const DeltaArgs &a, double *sums_out, hipStream_t s) {
+    launch_delta_any<false>(a, s);
+    const int ncols = a.A * a.M;
+    const int rows = delta_grid(a.N) * (SNP_THREADS / 64);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, s, a.out, rows,
+                       ncols, sums_out);
+}
+
+void launch_delta_write(const DeltaArgs &a, hipStream_t s) { launch_delta_any<true>(a, s); }
+
+// --------------------------------------------------------------------------------------------
+// deterministic block-wide sum helper for single-workgroup finalisers
+// --------------------------------------------------------------------------------------------
+static __device__ double block_sum_1024(double v, double *sh /*[16]*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = sh[0];
+#pragma unroll
+    for (int ww = 1; ww < 16; ++ww) t += sh[ww];
+    return t;
+}
+static __device__ double block_max_1024(double v, double *sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = sh[0];
+#pragma unroll
+    for (int ww = 1; ww < 16; ++ww) t = fmax(t, sh[ww]);
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict__ snp_partials,
+                                                         int snp_rows, int P,
+                                                         const double *__restrict__ dot_partials,
+                                                         const int32_t *__restrict__ dot_start,
+                                                         double *__restrict__ totals) {
+    __shared__ double sh[16];
+    const int NT = 2 * P + 3;
+    for (int c = 0; c < NT; ++c) {
+        double s = 0.0;
+        for (int r = threadIdx.x; r < snp_rows; r += 1024) s += snp_partials[(int64_t)r * NT + c];
+        s = block_sum_1024(s, sh);
+        if (threadIdx.x == 0) totals[c < 2 * P ? c : (3 * P + (c - 2 * P))] = s;
+    }
+    for (int p = 0; p < P; ++p) {
+        double s = 0.0;
+        for (int r = dot_start[p] + threadIdx.x; r < dot_start[p + 1]; r += 1024) s += dot_partials[r];
+        s = block_sum_1024(s, sh);
+        if (threadIdx.x == 0) totals[2 * P + p] = s;
+    }
+}
+
+void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
+                     const int32_t *dot_start, double *totals, hipStream_t s) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, snp_partials, snp_rows, P,
+                       dot_partials, dot_start, totals);
+}
+
+// --------------------------------------------------------------------------------------------
+// perm gather / scatter for the stand-alone BlockDiagonalMatrix.dot entry point
+// --------------------------------------------------------------------------------------------
+__global__ void gather_x_kernel(const double *__restrict__ x, const int32_t *__restrict__ invperm,
+                                double *__restrict__ pool_x, int N, int64_t PN) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < PN) {
+        const int64_t p = t / N;
+        pool_x[p * N + invperm[t]] = x[t];
+    }
+}
+__global__ void scatter_y_kernel(const double *__restrict__ pool_y, const int32_t *__restrict__ invperm,
+                                 double *__restrict__ y, int N, int64_t PN) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < PN) {
+        const int64_t p = t / N;
+        y[t] = pool_y[p * N + invperm[t]];
+    }
+}
+void launch_gather_x(const double *x_snp, const int32_t *invperm, double *pool_x, int N, int P,
+                     hipStream_t s) {
+    const int64_t PN = (int64_t)N * P;
+    hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)((PN + 255) / 256)), dim3(256), 0, s, x_snp,
+                       invperm, pool_x, N, PN);
+}
+void launch_scatter_y(const double *pool_y, const int32_t *invperm, double *y_snp, int N, int P,
+                      hipStream_t s) {
+    const int64_t PN = (int64_t)N * P;
+    hipLaunchKernelGGL(scatter_y_kernel, dim3((unsigned)((PN + 255) / 256)), dim3(256), 0, s,
+                       pool_y, invperm, y_snp, N, PN);
+}
+
+// --------------------------------------------------------------------------------------------
+// convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_diff_kernel(const double *__restrict__ m_cur,
+                                                         const double *__restrict__ scalings,
+                                                         double *__restrict__ snapshot, int64_t PN,
+                                                         double *__restrict__ partials, int compare) {
+    __shared__ double red[4][6];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    if (t < PN) {
+        const double nw = m_cur[t] * scalings[t];
+        if (compare) {
+            const double od = snapshot[t];
+            const double df = fabs(nw - od);
+            v[0] = (df <= 1e-6 + 1e-6 * fabs(od)) ? 0.0 : 1.0;
+            v[1] = df;
+            v[2] = df * df;
+            v[3] = fabs(nw);
+            v[4] = df;
+            v[5] = fabs((nw - od) / (od + 1e-100));
+        }
+        snapshot[t] = nw;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double s = c < 3 ? wave_sum(v[c]) : wave_max(v[c]);
+        if (lane == 0) red[w][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        double s = red[0][c];
+        for (int ww = 1; ww < 4; ++ww) s = c < 3 ? s + red[ww][c] : fmax(s, red[ww][c]);
+        partials[(int64_t)blockIdx.x * 6 + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void mean_diff_final_kernel(const double *__restrict__ partials,
+                                                                int rows, double *__restrict__ out) {
+    __shared__ double sh[16];
+    for (int c = 0; c < 6; ++c) {
+        double s = 0.0;
+        for (int r = threadIdx.x; r < rows; r += 1024) {
+            const double x = partials[(int64_t)r * 6 + c];
+            s = c < 3 ? s + x : fmax(s, x);
+        }
+        s = c < 3 ? block_sum_1024(s, sh) : block_max_1024(s, sh);
+        if (threadIdx.x == 0) out[c] = s;
+    }
+}
+
+int mean_diff_grid(int64_t PN) { return (int)((PN + 255) / 256); }
+
+void launch_mean_diff(const double *m_cur, const double *scalings, double *snapshot, int64_t PN,
+                      double *partials, double *out6, bool compare, hipStream_t s) {
+    const int grid = mean_diff_grid(PN);
+    hipLaunchKernelGGL(mean_diff_kernel, dim3(grid), dim3(256), 0, s, m_cur, scalings, snapshot, PN,
+                       partials, compare ? 1 : 0);
+    if (compare)
+        hipLaunchKernelGGL(mean_diff_final_kernel, dim3(1), dim3(1024), 0, s, partials, grid, out6);
+}
+
+// --------------------------------------------------------------------------------------------
+// load-time helper for the eigen form: V = diag(s) U^T
+// --------------------------------------------------------------------------------------------
+__global__ void scaled_transpose_kernel(const double *__restrict__ U, int n, int r, int ldu,
+                                        const double *__restrict__ s, double *__restrict__ V,
+                                        int ldv) {
+    __shared__ double tile[32][33];
+    const int i0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
+        const int i = i0 + dy, c = c0 + threadIdx.x;
+        tile[dy][threadIdx.x] = (i < n && c < r) ? U[(int64_t)i * ldu + c] : 0.0;
+    }
+    __syncthreads();
+    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
+        const int c = c0 + dy, i = i0 + threadIdx.x;
+        if (c < r && i < n) V[(int64_t)c * ldv + i] = s[c] * tile[threadIdx.x][dy];
+    }
+}
+void launch_scaled_transpose(const double *U, int n, int r, int ldu, const double *s, double *V,
+                             int ldv, hipStream_t st) {
+    hipLaunchKernelGGL(scaled_transpose_kernel, dim3((n + 31) / 32, (r + 31) / 32), dim3(32, 8), 0,
+                       st, U, n, r, ldu, s, V, ldv);
+}

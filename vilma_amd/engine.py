@@ -1,0 +1,195 @@
+"""HipEngine: the device side of one shard of the VI problem, driven through the C-ABI.
+
+The engine owns one `vilma_ctx` (include/vilma_hip.h).  torch is used only for the small
+result vectors (so they can be all-reduced with torch.distributed / RCCL) and for the current
+HIP stream; the LD store and the variational state live in memory the library allocates.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class HipEngine:
+    """One GPU, one shard: P cohorts x N SNPs x M mixture components, A annotations."""
+
+    def __init__(self, P, N, M, A, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.VilmaHipError('no GPU visible to this process: the vilma fit hot path '
+                                     'runs only on the HIP device (no CPU fallback)')
+        self.torch = torch
+        self.lib = _lib.load()
+        if device is not None:
+            torch.cuda.set_device(device)
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.P, self.N, self.M, self.A = int(P), int(N), int(M), int(A)
+        ctx = C.c_void_p()
+        if self.lib.vilma_create(self.P, self.N, self.M, self.A, C.byref(ctx)):
+            raise _lib.VilmaHipError(self.lib.vilma_last_error(None).decode())
+        self.ctx = ctx
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._totals = torch.zeros(_lib.ntotals(self.P), **f64)
+        self._sums = torch.zeros(self.A * self.M, **f64)
+        self._diff = torch.zeros(_lib.NDIFF, **f64)
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc:
+            raise _lib.VilmaHipError(self.lib.vilma_last_error(self.ctx).decode())
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.vilma_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def new_result(self, n):
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ static data
+    def set_snp_data(self, adj, se, sld, scalings, annot):
+        adj, se, sld, scalings = _f64(adj), _f64(se), _f64(sld), _f64(scalings)
+        annot = np.ascontiguousarray(annot, dtype=np.int32)
+        assert adj.shape == (self.P, self.N) and annot.shape == (self.N,)
+        self._check(self.lib.vilma_set_snp_data(self.ctx, _ptr(adj), _ptr(se), _ptr(sld),
+                                                _ptr(scalings), _ptr(annot)))
+
+    def set_mixture(self, prec, log_det):
+        prec, log_det = _f64(prec).reshape(self.M, self.P, self.P), _f64(log_det)
+        self._check(self.lib.vilma_set_mixture(self.ctx, _ptr(prec), _ptr(log_det)))
+
+    def set_tau(self, tau):
+        tau = _f64(tau)
+        self._check(self.lib.vilma_set_tau(self.ctx, _ptr(tau)))
+
+    def set_hyper(self, hyper):
+        hyper = _f64(hyper).reshape(self.A, self.M)
+        self._check(self.lib.vilma_set_hyper(self.ctx, _ptr(hyper)))
+
+    # ------------------------------------------------------------------ LD store
+    def load_ld(self, cohort, blocks, perm, n_ld):
+        """blocks: list of ('dense', R[n,n]) or ('eig', U[n,r], s[r]) in LD order.  Arrays may
+        be numpy (host) or torch CUDA tensors (device-resident synthetic LD)."""
+        lib = self.lib
+        total = 0
+        for b in blocks:
+            if b[0] == 'dense':
+                total += lib.vilma_ld_dense_elems(int(b[1].shape[0]))
+            else:
+                total += lib.vilma_ld_lowrank_elems(int(b[1].shape[0]), int(b[1].shape[1]))
+        perm = np.ascontiguousarray(perm, dtype=np.int64)
+        assert perm.shape == (self.N,)
+        self._check(lib.vilma_ld_begin(self.ctx, cohort, len(blocks), int(n_ld), _ptr(perm), total))
+        for b in blocks:
+            if b[0] == 'dense':
+                R = self._as_block(b[1])
+                self._check(lib.vilma_ld_add_dense(self.ctx, cohort, int(b[1].shape[0]), R[1]))
+            else:
+                U = self._as_block(b[1])
+                s = self._as_block(b[2])
+                self._check(lib.vilma_ld_add_lowrank(self.ctx, cohort, int(b[1].shape[0]),
+                                                     int(b[1].shape[1]), U[1], s[1]))
+        self._check(lib.vilma_ld_end(self.ctx, cohort))
+
+    def _as_block(self, a):
+        if isinstance(a, np.ndarray):
+            a = _f64(a)
+            return a, _ptr(a)
+        a = a.contiguous()      # torch tensor (device or host), float64
+        assert a.dtype == self.torch.float64
+        return a, C.c_void_p(a.data_ptr())
+
+    def ld_bytes(self):
+        alg, stored = C.c_int64(), C.c_int64()
+        self._check(self.lib.vilma_ld_bytes(self.ctx, C.byref(alg), C.byref(stored)))
+        return alg.value, stored.value
+
+    def ld_matvec(self, x, cohort=-1):
+        """BlockDiagonalMatrix.dot for all cohorts (x [P,N]) -> numpy [P,N]."""
+        t = self.torch
+        xd = t.as_tensor(_f64(x).reshape(self.P, self.N), device=self.device)
+        yd = t.zeros_like(xd)
+        self.ld_matvec_device(xd, yd, cohort)
+        return yd.cpu().numpy()
+
+    def ld_matvec_device(self, xd, yd, cohort=-1):
+        self._check(self.lib.vilma_ld_matvec(self.ctx, self._stream(), cohort,
+                                             C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr())))
+
+    # ------------------------------------------------------------------ state
+    def set_mu(self, vi_mu):
+        vi_mu = _f64(vi_mu)
+        assert vi_mu.shape == (self.M, self.P, self.N)
+        self._check(self.lib.vilma_set_mu(self.ctx, _ptr(vi_mu)))
+
+    def get_mu(self):
+        out = np.empty((self.M, self.P, self.N))
+        self._check(self.lib.vilma_get_mu(self.ctx, _ptr(out)))
+        return out
+
+    def get_delta(self):
+        out = np.empty((self.N, self.M))
+        self._check(self.lib.vilma_get_delta(self.ctx, _ptr(out)))
+        return out
+
+    def get_moments(self):
+        mean, var = np.empty((self.P, self.N)), np.empty((self.P, self.N))
+        self._check(self.lib.vilma_get_moments(self.ctx, _ptr(mean), _ptr(var)))
+        return mean, var
+
+    # ------------------------------------------------------------------ evaluations
+    def eval(self):
+        self._check(self.lib.vilma_eval(self.ctx, self._stream(),
+                                        C.c_void_p(self._totals.data_ptr())))
+        return self._totals
+
+    def trial(self, step):
+        self._check(self.lib.vilma_trial_beta(self.ctx, self._stream(), float(step),
+                                              C.c_void_p(self._totals.data_ptr())))
+        return self._totals
+
+    def accept(self, take_mu):
+        self._check(self.lib.vilma_accept(self.ctx, 1 if take_mu else 0))
+
+    def delta_sums(self):
+        self._check(self.lib.vilma_delta_sums(self.ctx, self._stream(),
+                                              C.c_void_p(self._sums.data_ptr())))
+        return self._sums
+
+    def mean_diff(self):
+        self._check(self.lib.vilma_mean_diff(self.ctx, self._stream(),
+                                             C.c_void_p(self._diff.data_ptr())))
+        return self._diff
+
+    def snapshot_mean(self):
+        self._check(self.lib.vilma_snapshot_mean(self.ctx, self._stream()))
+
+    # ------------------------------------------------------------------ measurement
+    def prof_enable(self, on=True):
+        self._check(self.lib.vilma_prof_enable(self.ctx, 1 if on else 0))
+
+    def prof_read(self, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.lib.vilma_prof_read(self.ctx, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
