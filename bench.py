@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: full VI sweeps/s of the `vilma fit` loop on synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W [--workload C3]
+
+A "step" is one outer sweep of the fit loop (reference MultiPopVI._optimize_step + the
+convergence statistics, variational_inference.py:361-389) over the whole synthetic problem.
+Workload C3 (BASELINE.json configs[2], the one the metric is quoted on): 2 cohorts, 1,000,000
+SNPs in 1700 LDetect-sized AR(1) LD blocks (+5% LD-missing SNPs), M=40 mixture components,
+dense-rank LD held in fp64 (11.98 GB), inputs resident in HBM before the timed region.
+With N>1 (launched by torch.distributed.run, one rank per GPU) the same global problem is
+sharded by LD blocks (strong scaling); the 3P+3 sums are all-reduced over RCCL per evaluation.
+
+Prints ONE JSON line (rank 0) with the sweep throughput, the roofline object of the dominant
+kernel (ld_colsum_kernel, timed with HIP events on its launch stream inside the library) and,
+at N=1, the CPU baseline: the oracle (a port following the reference's operation schedule)
+timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='C3')
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-blocks', type=int, default=96,
+                    help='blocks of the workload in the CPU-baseline sample')
+    ap.add_argument('--cpu-sweeps', type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, seed, n_blocks, n_sweeps):
+    """The oracle (oracle/vi.py, reference schedule) on the first `n_blocks` blocks of the same
+    synthetic problem, on this host.  Returns the JSON object."""
+    from vilma_amd.synthetic import SyntheticShard, WORKLOADS, ar1_numpy
+    from oracle.ldop import EigenBlock, BlockDiagonalLD
+    from oracle.vi import MultiPopVIOracle
+    cfg = dict(WORKLOADS[workload])
+    full = SyntheticShard(seed=seed, **cfg)
+    n_blocks = min(n_blocks, len(full.sizes_all))
+    sh = SyntheticShard(seed=seed, block_range=(0, n_blocks), **cfg).build(None)
+    P = sh.P
+    ld = [BlockDiagonalLD([EigenBlock(ar1_numpy(b.n, b.rho[p]), 1.0) for b in sh.blocks],
+                          perm=sh.perm, missing=sh.missing) for p in range(P)]
+    annotations = np.ones((sh.N, 1))
+    vi = MultiPopVIOracle(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
+                          annotations=annotations, mixture_covs=list(sh.covs), checkpoint=False,
+                          checkpoint_freq=-1, scaled=False, scale_se=False, gwas_N=sh.gwas_N,
+                          init_hg=sh.init_hg, num_its=n_sweeps)
+    # the GPU box gives one GPU's share of the host (16 cores); keep BLAS inside it
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(16, avail))
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=threads):
+        np.random.seed(42)
+        params = vi._initialize()
+        elbo = vi.elbo(params)
+        L, red = np.ones(5), None
+        params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)       # warm-up sweep
+        t0 = time.perf_counter()
+        for _ in range(n_sweeps):
+            params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
+        dt = time.perf_counter() - t0
+    frac = sh.N / full.N_global
+    return {
+        'value': (n_sweeps / dt) * frac, 'unit': 'sweeps/s', 'cores': int(threads),
+        'kind': 'port',
+        'sample': ('oracle (numpy restatement of the reference schedule; BLAS gemv threaded on '
+                   '%d threads, per-SNP passes single-threaded) on the first %d of %d blocks '
+                   '(%d of %d SNPs, all %d cohorts, M=%d): %d sweeps in %.2f s after 1 warm-up; '
+                   'value = measured sample sweeps/s x SNP fraction %.5f'
+                   % (threads, n_blocks, len(full.sizes_all), sh.N, full.N_global, P, sh.M,
+                      n_sweeps, dt, frac)),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from vilma_amd.synthetic import SyntheticShard, WORKLOADS
+    from vilma_amd.engine import HipEngine
+    from vilma_amd.sharding import Comm
+    from vilma_amd.variational_inference import SweepDriver, initial_vi_mu, initial_hyper
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    comm = Comm()
+
+    cfg = dict(WORKLOADS[args.workload])
+    t_setup = time.perf_counter()
+    shard = SyntheticShard(seed=args.seed, rank=rank, world=world, **cfg).build(device)
+    P, M = shard.P, shard.M
+    g = comm.allreduce_np(np.concatenate([shard.chi_local, shard.rank_local, shard.inv_se2_local]))
+    chi, ranks, inv_se2 = g[:P], g[P:2 * P], g[2 * P:]
+    shard.finish_init(inv_se2)
+
+    engine = HipEngine(P, shard.N, M, 1)
+    engine.set_snp_data(shard.adj, shard.se, shard.sld, shard.scalings, shard.annot)
+    prec = np.linalg.inv(shard.covs)
+    log_det = np.linalg.slogdet(shard.covs)[1]
+    engine.set_mixture(prec, log_det)
+    for p in range(P):
+        engine.load_ld(p, shard.ld_blocks_torch(p, device), shard.perm, shard.n_ld,
+                       specs=shard.block_specs())
+    torch.cuda.synchronize()
+
+    driver = SweepDriver()
+    driver._setup_driver(engine, comm, P, M, 1, chi, ranks, [shard.N_global], log_det,
+                         scale_se=False, num_its=args.steps + args.warmup)
+    tau = np.ones(P)
+    vi_mu0, sums = initial_vi_mu(shard.fake_mu, shard.sld, tau, prec, log_det, shard.annot, 1)
+    driver.start_from(vi_mu0, initial_hyper(comm.allreduce_np(sums)))
+    setup_s = time.perf_counter() - t_setup
+    elbo0 = driver._objective
+
+    state = None
+    for _ in range(args.warmup):
+        state, _ = driver.sweep(state)
+    if state is None:
+        engine.snapshot_mean()
+        state = {'L': np.ones(5), 'elbo': driver._objective, 'running': None}
+
+    engine.prof_enable(True)
+    engine.prof_read(reset=True)
+    ev0, tr0 = driver.n_evaluations, driver.n_trials
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    elbos = []
+    for _ in range(args.steps):
+        state, _ = driver.sweep(state)
+        elbos.append(state['elbo'])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = engine.prof_read(reset=True)
+    engine.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_eval = driver.n_evaluations - ev0
+    alg_launch = float(engine.ld_bytes()[0])            # this rank's LD bytes per launch
+    avg_ms = kernel_ms / max(launches, 1)
+    achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+    state_bytes = 8.0 * shard.N * (2 * M * P)            # per-SNP pass: read mu, write mu'
+
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('ld_colsum_kernel_bytes_per_launch')
+        except Exception:
+            traffic = None
+
+    out = {
+        'metric': 'full VI sweeps/sec (1M SNPs, 2 cohorts)' if args.workload == 'C3'
+                  else 'full VI sweeps/sec',
+        'value': args.steps / elapsed, 'unit': 'sweeps/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {
+            'workload': '%s: %d cohorts, %d SNPs (%d in %d AR(1) LD blocks + %d LD-missing), '
+                        'M=%d mixture components, dense-rank fp64 LD %.2f GB, A=1, no '
+                        '--learn-scaling' % (args.workload, P, shard.N_global, shard.n_ld_global,
+                                             len(shard.sizes_all),
+                                             shard.N_global - shard.n_ld_global, M,
+                                             8e-9 * P * float((shard.sizes_all.astype(np.float64) ** 2).sum())),
+            'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
+            'points_evaluated_per_sweep': n_eval / args.steps,
+            'beta_trials_per_sweep': (driver.n_trials - tr0) / args.steps,
+            'elbo_start': elbo0, 'elbo_end': elbos[-1] if elbos else elbo0,
+            'setup_seconds': setup_s,
+        },
+        'roofline': {
+            'bound': 'hbm', 'kernel': 'ld_colsum_kernel', 'achieved': achieved,
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': traffic, 'algorithmic_bytes_per_launch': alg_launch,
+            'avg_launch_ms': avg_ms, 'launches': int(launches),
+            'sweep_algorithmic_GBps': (n_eval * (alg_launch + state_bytes)) / elapsed / 1e9,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, args.cpu_blocks,
+                                               args.cpu_sweeps)
+        except Exception as exc:      # the GPU number stands on its own
+            out['cpu_baseline'] = {'value': None, 'unit': 'sweeps/s', 'cores': 0,
+                                   'kind': 'port', 'sample': 'failed: %r' % (exc,)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    engine.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -16,6 +16,7 @@ Outputs (committed, data only):
     tests/golden/traj_<name>.npz           class-API trajectories driven through
                                            MultiPopVI._optimize_step (variational_inference.py:396)
     tests/golden/mixgrid_kat.npz           vi_options._make_simple outputs (RNG order pin)
+    tests/golden/loader_kat.npz            load.py outputs on the reference's own fixtures
 """
 import io
 import logging
@@ -30,6 +31,7 @@ from vilma import numerics as rn                      # noqa: E402
 from vilma import matrix_structures as rms            # noqa: E402
 from vilma import variational_inference as rvi        # noqa: E402
 from vilma import vi_options as rvo                   # noqa: E402
+from vilma import load as rload                       # noqa: E402
 
 
 # --------------------------------------------------------------------------------------
@@ -336,6 +338,62 @@ def mixgrid_kat():
     np.savez_compressed(os.path.join(HERE, 'mixgrid_kat.npz'), **out)
 
 
+def loader_kat():
+    """Reference loaders on the reference's own fixtures (copied to tests/golden/refdata and
+    tests/golden/example): pins perm / missing / block contents / sumstats alignment."""
+    import warnings
+    warnings.simplefilter('ignore')
+    ref = os.path.join(HERE, 'refdata')
+    ex = os.path.join(HERE, 'example')
+    out = {}
+    cases = {
+        'plain': ('ld_manifest.tsv', 'good_variants.tsv', [], 1.0),
+        'thresh': ('ld_manifest.tsv', 'good_variants.tsv', [], 0.8),
+        'deny': ('ld_manifest.tsv', 'good_variants.tsv', [3, 4, 5], 1.0),
+        'svd': ('ld_manifest_svd.tsv', 'good_variants.tsv', [], 1.0),
+        'svd_deny': ('ld_manifest_svd.tsv', 'good_variants.tsv', [3, 4, 5], 0.8),
+        'plusmissing': ('ld_manifest.tsv', 'good_variants_plus_missing.tsv', [], 1.0),
+    }
+    for tag, (manifest, varfile, deny, t) in cases.items():
+        variants = rload.load_variant_list(os.path.join(ref, varfile))
+        bd, miss = rload.load_ld_from_schema(os.path.join(ref, manifest), variants, deny, t, False)
+        out[tag + '_perm'] = bd.perm
+        out[tag + '_missing_list'] = np.array(miss, dtype=np.int64)
+        out[tag + '_missing'] = bd.missing
+        out[tag + '_starts'] = bd.starts
+        out[tag + '_diag'] = bd.diag()
+        out[tag + '_rank'] = bd.get_rank()
+        for b, m in enumerate(bd.matrices):
+            out[tag + '_recon%d' % b] = (np.asarray(m.u) * m.s) @ np.asarray(m.v)
+            out[tag + '_s%d' % b] = m.s
+        v = np.linspace(-1, 1, bd.shape[0])
+        out[tag + '_dot'] = bd.dot(v)
+        out[tag + '_invdot'] = bd.inverse.dot(v)
+    variants = rload.load_variant_list(os.path.join(ex, 'keep_variants.txt'))
+    bd, miss = rload.load_ld_from_schema(os.path.join(ex, 'ld_mat', 'example_schema.schema'),
+                                         variants, [], 1.0, False)
+    out['example_perm'] = bd.perm
+    out['example_missing_list'] = np.array(miss, dtype=np.int64)
+    out['example_starts'] = bd.starts
+    for b, m in enumerate(bd.matrices):
+        out['example_recon%d' % b] = (np.asarray(m.u) * m.s) @ np.asarray(m.v)
+    variants = rload.load_variant_list(os.path.join(ref, 'good_variants.tsv'))
+    for name in ('good_sumstats_beta', 'good_sumstats_or', 'good_sumstats_flip'):
+        st, miss = rload.load_sumstats(os.path.join(ref, name + '.tsv'), variants)
+        out[name + '_BETA'] = np.array(st.BETA, dtype=float)
+        out[name + '_SE'] = np.array(st.SE, dtype=float)
+        out[name + '_missing'] = np.array(miss, dtype=np.int64)
+    vpm = rload.load_variant_list(os.path.join(ref, 'good_variants_plus_missing.tsv'))
+    st, miss = rload.load_sumstats(os.path.join(ref, 'good_sumstats_beta_plus_missing.tsv'), vpm)
+    out['plusmissing_BETA'] = np.array(st.BETA, dtype=float)
+    out['plusmissing_SE'] = np.array(st.SE, dtype=float)
+    out['plusmissing_sumstats_missing'] = np.array(miss, dtype=np.int64)
+    ann, deny = rload.load_annotations(os.path.join(ref, 'good_annotations.tsv'), variants)
+    out['annotations'] = np.asarray(ann, dtype=float)
+    out['annotations_denylist'] = np.array(deny, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'loader_kat.npz'), **out)
+
+
 def main():
     which = set(sys.argv[1:])
 
@@ -343,7 +401,7 @@ def main():
         return not which or name in which
 
     if want('kat'):
-        numerics_kat(); ldop_kat(); mixgrid_kat()
+        numerics_kat(); ldop_kat(); mixgrid_kat(); loader_kat()
     if want('p1_dense'):
         prob = make_problem(1, P=1, sizes=[90, 60, 120, 75, 100, 55], M=25, ldthresh=1.0,
                             kind='ar1', frac_missing=0.0, A=1, shuffle=False)

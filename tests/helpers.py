@@ -85,3 +85,58 @@ def oracle_totals(vi, params):
         [nm.fast_delta_kl(vi_delta, hyper, vi.annotations),
          nm.fast_inner_product_comp(vi_mu, vi.mixture_prec, vi_delta),
          nm.fast_beta_kl(vi.sigma_summary, vi_delta)]])
+
+
+def product_vi_from_traj(g, num_its=None, engine_factory=None, comm=None, form='auto'):
+    """vilma_amd.MultiPopVI built from a golden problem through the product's own
+    LowRankMatrix / BlockDiagonalMatrix (class-API depth of SURVEY.md section 8b)."""
+    from vilma_amd.matrix_structures import LowRankMatrix, BlockDiagonalMatrix
+    from vilma_amd.variational_inference import MultiPopVI
+    t = float(g['ldthresh'])
+    ld = [BlockDiagonalMatrix([LowRankMatrix(X, t) for X in blocks], perm=g['perm'],
+                              missing=g['missing'])
+          for blocks in traj_blocks(g)]
+    vi = MultiPopVI(marginal_effects=g['betahat'], std_errs=g['se'], ld_mats=ld,
+                    mixture_covs=list(g['covs']), annotations=g['annotations'],
+                    checkpoint=False, checkpoint_freq=-1, output='t',
+                    scaled=bool(g['scaled']), scale_se=bool(g['scale_se']),
+                    gwas_N=g['gwas_N'], init_hg=g['init_hg'],
+                    num_its=len(g['elbo']) if num_its is None else num_its, form=form,
+                    _engine_factory=engine_factory, _comm=comm)
+    return vi, ld
+
+
+def check_trajectory(vi, g, rtol_elbo=1e-9, rtol_mean=1e-7):
+    """Drive `vi` (product class) through the golden's sweeps exactly as the reference loop
+    does (variational_inference.py:353-389) and compare with what the reference recorded."""
+    for key in ('ld_diags', 'adj_marginal_effects', 'chi_stat', 'ld_ranks', 'inverse_betas',
+                'scalings', 'mixture_prec', 'log_det'):
+        np.testing.assert_allclose(getattr(vi, key), g[key], rtol=1e-8, atol=1e-12, err_msg=key)
+    np.random.seed(int(g['seed']))
+    params = vi._initialize()
+    elbo = vi.elbo(params)
+    assert abs(elbo - float(g['init_elbo'])) < rtol_elbo * abs(elbo)
+    np.testing.assert_allclose(params[2], g['init_hyper_delta'], rtol=1e-10)
+    L = np.ones(5)
+    red = None
+    n_sweeps = len(g['elbo'])
+    for it in range(n_sweeps):
+        e0 = vi.n_evaluations
+        params, L, elbo, red = vi._optimize_step(params, L=L, curr_elbo=elbo,
+                                                 line_search_rate=2., running_elbo_delta=red)
+        assert abs(elbo - g['elbo'][it]) < rtol_elbo * abs(elbo), (it, elbo, g['elbo'][it])
+        assert np.array_equal(L, g['L'][it]), (it, L, g['L'][it])
+        np.testing.assert_allclose(vi.error_scaling, g['error_scaling'][it], rtol=1e-8)
+        np.testing.assert_allclose(params[2], g['hyper_delta'][it], rtol=1e-6, atol=1e-300)
+        # one LD product per cohort per DISTINCT candidate point: the reference's count minus
+        # its redundant re-evaluations (2 per sweep + 1 per inner beta step, +1 with scale_se)
+        assert vi.n_evaluations - e0 <= int(g['objs_per_sweep'][it])
+        if it in (0, n_sweeps - 1):
+            np.testing.assert_allclose(vi.real_posterior_mean(params), g['post_mean'][it],
+                                       rtol=rtol_mean, atol=1e-12)
+    np.testing.assert_allclose(params[0], g['final_vi_mu'], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(params[1], g['final_vi_delta'], rtol=1e-6, atol=1e-300)
+    np.testing.assert_allclose(vi.real_posterior_variance(params), g['final_post_var'],
+                               rtol=1e-7)
+    np.testing.assert_allclose(vi.vi_sigma, g['final_vi_sigma'], rtol=1e-9)
+    return params

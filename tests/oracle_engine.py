@@ -1,0 +1,163 @@
+"""A CPU engine with the HipEngine interface, built on the oracle -- TEST ONLY.
+
+Lets the host driver (vilma_amd.variational_inference.MultiPopVI) and the sharding / all-reduce
+protocol be exercised without a GPU (`-m "not gpu"`, gloo world_size 2).  The product never
+imports this: the default engine is the HIP one and there is no CPU fallback.
+"""
+import numpy as np
+import torch
+
+from oracle import numerics as nm
+from oracle.ldop import BlockDiagonalLD
+
+
+class _Block:
+    def __init__(self, spec):
+        if spec[0] == 'dense':
+            self.R = np.asarray(spec[1])
+            self.n = self.R.shape[0]
+            self.dot = lambda x: self.R @ x
+        else:
+            U, s = np.asarray(spec[1]), np.asarray(spec[2])
+            self.n = U.shape[0]
+            self.dot = lambda x: U @ (s * (U.T @ x))
+        self.shape = (self.n, self.n)
+
+
+class OracleEngine:
+    def __init__(self, P, N, M, A):
+        self.P, self.N, self.M, self.A = P, N, M, A
+        self.tau = np.ones(P)
+        self.ld = [None] * P
+        self.cur = None          # dict(mean, var, z, linked, delta)
+        self.trial_state = None
+        self.mu = None
+        self.mu_trial = None
+        self.snap = None
+        self._c = None
+
+    # ---- static data
+    def set_snp_data(self, adj, se, sld, scalings, annot):
+        self.adj, self.se, self.sld = np.array(adj), np.array(se), np.array(sld)
+        self.scal, self.annot = np.array(scalings), np.array(annot, dtype=np.int64)
+        self._c = None
+
+    def set_mixture(self, prec, log_det):
+        self.prec = np.array(prec).reshape(self.M, self.P, self.P)
+        self.log_det = np.array(log_det)
+        self._c = None
+
+    def set_tau(self, tau):
+        self.tau = np.array(tau, dtype=float)
+        self._c = None
+
+    def set_hyper(self, hyper):
+        self.hyper = np.array(hyper).reshape(self.A, self.M)
+
+    def load_ld(self, cohort, blocks, perm, n_ld):
+        perm = np.asarray(perm)
+        self.ld[cohort] = BlockDiagonalLD([_Block(b) for b in blocks], perm=perm,
+                                          missing=perm[n_ld:])
+
+    def ld_matvec(self, x, cohort=-1):
+        x = np.asarray(x).reshape(self.P, self.N)
+        out = np.zeros_like(x)
+        for p in range(self.P):
+            if cohort < 0 or cohort == p:
+                out[p] = self.ld[p].dot(x[p])
+        return out
+
+    def ld_bytes(self):
+        return 0, 0
+
+    # ---- sigma-dependent constants (variational_inference.py:712-733)
+    def _consts(self):
+        if self._c is None:
+            lam = np.zeros((self.M, self.P, self.P, self.N))
+            idx = np.arange(self.P)
+            lam[:, idx, idx, :] = self.sld / self.tau[:, None]
+            lam += self.prec[:, :, :, None]
+            sigma = nm.vi_sigma_inv(lam)
+            logdet = nm.vi_sigma_log_det(sigma)
+            matches = np.einsum('kpq,kqpi->ik', self.prec, sigma)
+            self._c = dict(sigma=sigma, nat_sigma=-0.5 * lam, logdet=logdet,
+                           summary=self.log_det - logdet.T + matches)
+        return self._c
+
+    def _delta(self, mu, nat_mu=None):
+        c = self._consts()
+        if nat_mu is None:
+            nat_mu = nm.fast_nat_inner_product_m2(mu, c['nat_sigma'])
+        grad = nm.fast_vi_delta_grad(self.hyper, self.log_det, self.annot)
+        return nm.fast_invert_nat_vi_delta(mu, nat_mu, np.copy(c['logdet'].T), grad)
+
+    def _moments(self, mu, delta):
+        c = self._consts()
+        mean = nm.fast_posterior_mean(mu, delta)
+        var = nm.fast_pmv(mean, mu, delta, np.einsum('kppi->kpi', c['sigma']))
+        z = mean / self.se
+        linked = self.ld_matvec(z)
+        st = dict(mean=mean, var=var, z=z, linked=linked, delta=delta)
+        totals = np.concatenate([
+            (mean * self.adj).sum(axis=1), (self.sld * var).sum(axis=1),
+            (linked * z).sum(axis=1),
+            [nm.fast_delta_kl(delta, self.hyper, self.annot),
+             nm.fast_inner_product_comp(mu, self.prec[:, :, :, None], delta),
+             nm.fast_beta_kl(c['summary'], delta)]])
+        return st, torch.as_tensor(totals)
+
+    # ---- state
+    def set_mu(self, vi_mu):
+        self.mu = np.array(vi_mu)
+        self.cur = None
+
+    def get_mu(self):
+        return np.copy(self.mu)
+
+    def get_delta(self):
+        return np.copy(self.cur['delta'])
+
+    def get_moments(self):
+        return np.copy(self.cur['mean']), np.copy(self.cur['var'])
+
+    # ---- evaluations
+    def eval(self):
+        self.mu_trial = None
+        self.trial_state, totals = self._moments(self.mu, self._delta(self.mu))
+        return totals
+
+    def trial(self, step):
+        c = self._consts()
+        cur = self.cur
+        old_nat = nm.fast_nat_inner_product_m2(self.mu, c['nat_sigma'])
+        linked = nm.fast_linked_ests(cur['linked'], self.se, cur['mean'], self.sld)
+        grad = np.broadcast_to(((self.adj - linked) / self.tau[:, None])[None], self.mu.shape)
+        nat_mu = nm.sum_betas(old_nat, grad, step)
+        new_mu = nm.fast_nat_inner_product(nat_mu, c['sigma'])
+        self.mu_trial = new_mu
+        self.trial_state, totals = self._moments(new_mu, self._delta(new_mu, nat_mu))
+        return totals
+
+    def accept(self, take_mu):
+        if take_mu:
+            self.mu = self.mu_trial
+        self.cur = self.trial_state
+
+    def delta_sums(self):
+        return torch.as_tensor(nm.sum_annotations(self.cur['delta'], self.annot, self.A).ravel())
+
+    def snapshot_mean(self):
+        self.snap = self.cur['mean'] * self.scal
+
+    def mean_diff(self):
+        new = self.cur['mean'] * self.scal
+        old = self.snap
+        df = np.abs(new - old)
+        out = np.array([np.sum(df > 1e-6 + 1e-6 * np.abs(old)), df.sum(), (df ** 2).sum(),
+                        np.abs(new).max(), df.max(), np.abs((new - old) / (old + 1e-100)).max()],
+                       dtype=float)
+        self.snap = new
+        return torch.as_tensor(out)
+
+    def close(self):
+        pass

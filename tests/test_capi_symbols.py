@@ -1,0 +1,36 @@
+"""The C-ABI library loads and exports every symbol include/vilma_hip.h declares (no compute)."""
+import os
+import re
+
+from vilma_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    header = open(os.path.join(ROOT, 'include', 'vilma_hip.h')).read()
+    declared = set(re.findall(r'\b(vilma_[a-z0-9_]+)\s*\(', header))
+    declared.discard('vilma_ctx')
+    assert len(declared) >= 25
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libvilma_hip.so does not export %s' % name
+    assert declared == set(_lib.exported_symbols())
+    assert lib.vilma_version().decode().startswith('vilma_hip')
+
+
+def test_sizes_helpers():
+    lib = _lib.load()
+    assert lib.vilma_ld_dense_elems(5) == 5 * 6
+    assert lib.vilma_ld_lowrank_elems(5, 3) == 5 * 4 + 3 * 6
+    assert _lib.ntotals(2) == 9
+
+
+def test_no_cpu_fallback_in_product():
+    """Nothing under vilma_amd/ imports the oracle."""
+    pkg = os.path.join(ROOT, 'vilma_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f

@@ -1,0 +1,142 @@
+"""Loaders and mixture grid of the product against the reference's own fixtures and vectors
+recorded from the reference's load.py / vi_options.py (tests/golden/loader_kat.npz,
+mixgrid_kat.npz).  Assertions mirror reference tests/test.py:486-706."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden, GOLDEN
+from vilma_amd import load
+from vilma_amd import vi_options
+
+REF = os.path.join(GOLDEN, 'refdata')
+EX = os.path.join(GOLDEN, 'example')
+K = golden('loader_kat.npz')
+
+
+def ref(name):
+    return os.path.join(REF, name)
+
+
+def test_load_variant_list():
+    for bad in ('bad_variants_missing_id.tsv', 'bad_variants_missing_a1.tsv',
+                'bad_variants_missing_a2.tsv'):
+        with pytest.raises(ValueError):
+            load.load_variant_list(ref(bad))
+    variants = load.load_variant_list(ref('good_variants.tsv'))
+    assert len(variants) == 13
+    assert list(variants.columns) == ['ID', 'A1', 'A2']
+
+
+def test_load_annotations():
+    variants = load.load_variant_list(ref('good_variants.tsv'))
+    null, deny = load.load_annotations(None, variants)
+    assert null.shape == (13, 1) and np.allclose(null, 1) and deny == []
+    ann, deny = load.load_annotations(ref('good_annotations.tsv'), variants)
+    assert ann.shape == (13, 6)
+    assert np.array_equal(np.asarray(ann, dtype=float), K['annotations'])
+    assert deny == K['annotations_denylist'].tolist() == [12]
+    with pytest.raises(ValueError):
+        load.load_annotations(ref('bad_annotations_missing_id.tsv'), variants)
+    with pytest.raises(ValueError):
+        load.load_annotations(ref('bad_annotations_missing_annotation.tsv'), variants)
+
+
+@pytest.mark.parametrize('name', ['good_sumstats_beta', 'good_sumstats_or', 'good_sumstats_flip'])
+def test_load_sumstats(name):
+    variants = load.load_variant_list(ref('good_variants.tsv'))
+    stats, missing = load.load_sumstats(ref(name + '.tsv'), variants)
+    assert len(stats) == 13
+    assert missing == K[name + '_missing'].tolist()
+    assert np.array_equal(np.array(stats.BETA, dtype=float), K[name + '_BETA'])
+    assert np.array_equal(np.array(stats.SE, dtype=float), K[name + '_SE'])
+
+
+def test_load_sumstats_errors_and_missing():
+    variants = load.load_variant_list(ref('good_variants.tsv'))
+    for bad in ('id', 'beta', 'se', 'a1', 'a2'):
+        with pytest.raises(ValueError):
+            load.load_sumstats(ref('bad_sumstats_missing_%s.tsv' % bad), variants)
+    vpm = load.load_variant_list(ref('good_variants_plus_missing.tsv'))
+    stats, missing = load.load_sumstats(ref('good_sumstats_beta_plus_missing.tsv'), vpm)
+    assert missing == K['plusmissing_sumstats_missing'].tolist()
+    assert sorted(missing) == [10, 11, 12, 14]
+    assert np.array_equal(np.array(stats.BETA, dtype=float), K['plusmissing_BETA'])
+    assert np.array_equal(np.array(stats.SE, dtype=float), K['plusmissing_SE'])
+
+
+CASES = {
+    'plain': ('ld_manifest.tsv', 'good_variants.tsv', [], 1.0),
+    'thresh': ('ld_manifest.tsv', 'good_variants.tsv', [], 0.8),
+    'deny': ('ld_manifest.tsv', 'good_variants.tsv', [3, 4, 5], 1.0),
+    'svd': ('ld_manifest_svd.tsv', 'good_variants.tsv', [], 1.0),
+    'svd_deny': ('ld_manifest_svd.tsv', 'good_variants.tsv', [3, 4, 5], 0.8),
+    'plusmissing': ('ld_manifest.tsv', 'good_variants_plus_missing.tsv', [], 1.0),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(CASES))
+def test_load_ld_from_schema(tag):
+    """SNP -> block assignment (perm, missing, starts) is BIT exact; block contents match."""
+    manifest, varfile, deny, t = CASES[tag]
+    variants = load.load_variant_list(ref(varfile))
+    bd, missing = load.load_ld_from_schema(ref(manifest), variants, deny, t, False)
+    assert np.array_equal(bd.perm, K[tag + '_perm']) and bd.perm.dtype == K[tag + '_perm'].dtype
+    assert missing == K[tag + '_missing_list'].tolist()
+    assert np.array_equal(bd.missing, K[tag + '_missing'])
+    assert np.array_equal(bd.starts, K[tag + '_starts'])
+    assert bd.get_rank() == int(K[tag + '_rank'])
+    np.testing.assert_allclose(bd.diag(), K[tag + '_diag'], atol=1e-13)
+    for b, m in enumerate(bd.matrices):
+        np.testing.assert_allclose(m.reconstruct(), K[tag + '_recon%d' % b], atol=1e-13)
+        np.testing.assert_allclose(m.s, K[tag + '_s%d' % b], rtol=1e-12)
+    v = np.linspace(-1, 1, bd.shape[0])
+    np.testing.assert_allclose(bd.inverse.dot(v), K[tag + '_invdot'], rtol=1e-9, atol=1e-12)
+
+
+def test_load_missing_and_flips():
+    """reference tests/test.py:594-606, 674-696: flips at rows 0,2 => R[0,2] = -1; SNPs 5 and
+    12 (and 13, 14 with the extended variant list) have no LD."""
+    variants = load.load_variant_list(ref('good_variants.tsv'))
+    bd, missing = load.load_ld_from_schema(ref('ld_manifest.tsv'), variants, [], 1., False)
+    assert sorted(missing) == [5, 12]
+    dense = np.zeros((13, 13))
+    n_ld = int(bd.starts[-1])
+    dense[np.ix_(bd.perm[:n_ld], bd.perm[:n_ld])] = bd.matrices[0].reconstruct()
+    want = np.eye(13)
+    want[0, 2] = want[2, 0] = -1
+    want[5, 5] = want[12, 12] = 0
+    # the fixture block is singular (rows 0 and 2 are anti-correlated copies): the operator is
+    # the PSD reconstruction, which reproduces the matrix itself here
+    np.testing.assert_allclose(dense, want, atol=1e-12)
+    vpm = load.load_variant_list(ref('good_variants_plus_missing.tsv'))
+    bd, missing = load.load_ld_from_schema(ref('ld_manifest.tsv'), vpm, [], 1., False)
+    assert sorted(missing) == [5, 12, 13, 14] and len(missing) == 4
+    with pytest.raises(NotImplementedError):
+        load.load_ld_from_schema(ref('ld_manifest.tsv'), vpm, [], 1., True)    # --mmap
+
+
+def test_example_schema():
+    variants = load.load_variant_list(os.path.join(EX, 'keep_variants.txt'))
+    bd, missing = load.load_ld_from_schema(os.path.join(EX, 'ld_mat', 'example_schema.schema'),
+                                           variants, [], 1.0, False)
+    assert np.array_equal(bd.perm, K['example_perm'])
+    assert missing == K['example_missing_list'].tolist()
+    assert np.array_equal(bd.starts, K['example_starts'])
+    for b, m in enumerate(bd.matrices):
+        np.testing.assert_allclose(m.reconstruct(), K['example_recon%d' % b], atol=1e-13)
+
+
+@pytest.mark.parametrize('P,Kc', [(1, 5), (2, 3), (3, 2)])
+def test_mixture_grid_rng_order(P, Kc):
+    """_make_simple reproduces the reference grid AND leaves the legacy RNG in the same state
+    (vi_options.py:301-337); M = K+2 for P=1, 3(K+2)K^(P(P-1)/2) + 3P(K+1) otherwise."""
+    G = golden('mixgrid_kat.npz')
+    tag = 'P%d_K%d' % (P, Kc)
+    np.random.seed(42)
+    covs = vi_options._make_simple(P, Kc, G[tag + '_mins'], G[tag + '_maxes'])
+    assert np.array_equal(np.array(covs), G[tag])
+    assert np.random.uniform() == float(G[tag + '_next_uniform'])
+    want_m = Kc + 2 if P == 1 else 3 * (Kc + 2) * Kc ** (P * (P - 1) // 2) + 3 * P * (Kc + 1)
+    assert len(covs) == want_m

@@ -88,19 +88,21 @@ class HipEngine:
         self._check(self.lib.vilma_set_hyper(self.ctx, _ptr(hyper)))
 
     # ------------------------------------------------------------------ LD store
-    def load_ld(self, cohort, blocks, perm, n_ld):
-        """blocks: list of ('dense', R[n,n]) or ('eig', U[n,r], s[r]) in LD order.  Arrays may
-        be numpy (host) or torch CUDA tensors (device-resident synthetic LD)."""
+    def load_ld(self, cohort, blocks, perm, n_ld, specs=None):
+        """blocks: ('dense', R[n,n]) or ('eig', U[n,r], s[r]) per block in LD order, as a list or
+        -- with `specs` = [(form, n, r), ...] given up front -- any iterable (so large synthetic
+        LD can be produced block by block).  Arrays may be numpy (host) or torch CUDA tensors."""
         lib = self.lib
+        if specs is None:
+            blocks = list(blocks)
+            specs = [(b[0], int(b[1].shape[0]), int(b[1].shape[-1])) for b in blocks]
         total = 0
-        for b in blocks:
-            if b[0] == 'dense':
-                total += lib.vilma_ld_dense_elems(int(b[1].shape[0]))
-            else:
-                total += lib.vilma_ld_lowrank_elems(int(b[1].shape[0]), int(b[1].shape[1]))
+        for form, n, r in specs:
+            total += (lib.vilma_ld_dense_elems(n) if form == 'dense'
+                      else lib.vilma_ld_lowrank_elems(n, r))
         perm = np.ascontiguousarray(perm, dtype=np.int64)
         assert perm.shape == (self.N,)
-        self._check(lib.vilma_ld_begin(self.ctx, cohort, len(blocks), int(n_ld), _ptr(perm), total))
+        self._check(lib.vilma_ld_begin(self.ctx, cohort, len(specs), int(n_ld), _ptr(perm), total))
         for b in blocks:
             if b[0] == 'dense':
                 R = self._as_block(b[1])

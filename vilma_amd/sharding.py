@@ -1,0 +1,154 @@
+"""Data-parallel sharding of the fit problem over GPUs (one process per GPU).
+
+LD blocks are independent and everything else is per-SNP, so the SNP set is split into
+shards that are closed under "shares an LD block in any cohort" (connected components of the
+block structure across cohorts -- cohorts may have different block partitions and different
+`perm`s, reference vi_options.py:161-183).  The only cross-shard quantities are the small sums
+of include/vilma_hip.h (`totals`, `delta_sums`, convergence statistics); `Comm` all-reduces
+them with torch.distributed (backend "nccl" = RCCL over xGMI on MI355X, "gloo" in CPU tests).
+"""
+import numpy as np
+
+
+class Comm:
+    """Thin wrapper over torch.distributed; a no-op for a single process."""
+
+    def __init__(self, group=None):
+        self.rank, self.world = 0, 1
+        self._dist = None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self._dist = dist
+                self.group = group
+                self.rank = dist.get_rank(group)
+                self.world = dist.get_world_size(group)
+                self.backend = dist.get_backend(group)
+        except ImportError:
+            pass
+
+    def allreduce(self, tensor, op='sum'):
+        """All-reduce a small float64 torch tensor (any device) and return it as numpy."""
+        if self.world > 1:
+            dist = self._dist
+            t = tensor
+            if self.backend == 'gloo' and t.is_cuda:
+                t = t.cpu()
+            elif self.backend == 'nccl' and not t.is_cuda:
+                t = t.cuda()
+            rop = dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX
+            dist.all_reduce(t, op=rop, group=self.group)
+            return t.cpu().numpy().copy()
+        return tensor.cpu().numpy().copy()
+
+    def allreduce_np(self, array, op='sum'):
+        if self.world == 1:
+            return np.array(array, dtype=np.float64)
+        import torch
+        return self.allreduce(torch.as_tensor(np.ascontiguousarray(array, dtype=np.float64)), op)
+
+    def gather_snps(self, local, snp_index, n_global):
+        """Assemble an array whose LAST axis is the shard's SNPs into the global SNP order on
+        every rank.  `snp_index` = global indices of the local SNPs."""
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        if self.world == 1:
+            out = np.empty(local.shape[:-1] + (n_global,))
+            out[..., snp_index] = local
+            return out
+        import torch
+        dist = self._dist
+        counts = [None] * self.world
+        dist.all_gather_object(counts, int(local.shape[-1]), group=self.group)
+        width = max(counts)
+        lead = local.shape[:-1]
+
+        def padded(a, dtype):
+            buf = np.zeros(lead + (width,) if a.ndim > 1 else (width,), dtype=dtype)
+            buf[..., :a.shape[-1]] = a
+            t = torch.as_tensor(buf)
+            return t.cuda() if self.backend == 'nccl' else t
+        mine = padded(local, np.float64)
+        idx = padded(np.asarray(snp_index, dtype=np.int64), np.int64)
+        bufs = [torch.empty_like(mine) for _ in range(self.world)]
+        idxs = [torch.empty_like(idx) for _ in range(self.world)]
+        dist.all_gather(bufs, mine, group=self.group)
+        dist.all_gather(idxs, idx, group=self.group)
+        out = np.empty(lead + (n_global,))
+        for r in range(self.world):
+            n = counts[r]
+            out[..., idxs[r].cpu().numpy()[:n]] = bufs[r].cpu().numpy()[..., :n]
+        return out
+
+
+def block_costs(ld):
+    """Bytes one product with each block streams in the form the device will hold it."""
+    out = []
+    for m in ld.matrices:
+        n, r = m.u.shape
+        out.append(8.0 * (n * n if 2 * r > n else 2 * n * r))
+    return np.asarray(out)
+
+
+def plan_shards(ld_mats, num_loci, world, per_snp_cost=0.0):
+    """Split SNPs into `world` shards closed under LD-block membership in every cohort.
+
+    Returns a list (one per rank) of dicts: 'snps' (sorted global SNP indices of the shard) and
+    'blocks' (per cohort, the indices into ld_mats[p].matrices of the blocks it owns).
+    Deterministic, so every rank computes the same plan."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    N = int(num_loci)
+    rows, cols = [], []
+    for ld in ld_mats:
+        n_ld = int(ld.starts[-1])
+        if n_ld == 0:
+            continue
+        sizes = np.diff(ld.starts)
+        first = np.repeat(ld.perm[ld.starts[:-1]], sizes)
+        rows.append(first)
+        cols.append(ld.perm[:n_ld])
+    if rows:
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        graph = coo_matrix((np.ones(len(rows), dtype=np.int8), (rows, cols)), shape=(N, N))
+        n_comp, label = connected_components(graph, directed=False)
+    else:
+        n_comp, label = N, np.arange(N)
+    cost = np.bincount(label, minlength=n_comp).astype(np.float64) * per_snp_cost
+    block_comp = []
+    for ld in ld_mats:
+        comp = label[ld.perm[ld.starts[:-1]]] if len(ld.matrices) else np.zeros(0, dtype=int)
+        block_comp.append(comp)
+        if len(comp):
+            np.add.at(cost, comp, block_costs(ld))
+    # longest-processing-time greedy: heaviest component to the lightest rank; ties by index
+    order = np.lexsort((np.arange(n_comp), -cost))
+    load = np.zeros(world)
+    owner = np.empty(n_comp, dtype=np.int64)
+    for c in order:
+        r = int(np.argmin(load))
+        owner[c] = r
+        load[r] += cost[c]
+    snp_owner = owner[label]
+    plan = []
+    for r in range(world):
+        plan.append({
+            'snps': np.flatnonzero(snp_owner == r),
+            'blocks': [np.flatnonzero(owner[bc] == r) for bc in block_comp],
+            'cost': float(load[r]),
+        })
+    return plan
+
+
+def local_ld(ld, shard_snps, block_ids, num_loci):
+    """(blocks, perm, n_ld) of one cohort restricted to a shard, in local SNP numbering."""
+    g2l = np.full(int(num_loci), -1, dtype=np.int64)
+    g2l[shard_snps] = np.arange(len(shard_snps))
+    mats = [ld.matrices[b] for b in block_ids]
+    members = [ld.perm[ld.starts[b]:ld.starts[b + 1]] for b in block_ids]
+    covered = (np.concatenate(members) if members else np.zeros(0, dtype=np.int64))
+    local_cov = g2l[covered]
+    assert np.all(local_cov >= 0), 'shard is not closed under LD-block membership'
+    is_cov = np.zeros(len(shard_snps), dtype=bool)
+    is_cov[local_cov] = True
+    perm = np.concatenate([local_cov, np.flatnonzero(~is_cov)]).astype(np.int64)
+    return mats, perm, int(len(local_cov))

@@ -1,0 +1,235 @@
+"""Synthetic fit problems of the BASELINE.json shapes (recipe of SURVEY.md section 8d).
+
+Everything random is drawn from numpy Generators seeded per (seed, cohort, block), so the
+global problem is identical however the blocks are sharded over GPUs -- the 1/2/4/8-GPU runs
+of bench.py fit the same data.  LD is AR(1) per (block, cohort), which is positive definite:
+the reference's eigen-decomposition at ldthresh=1 keeps every eigenpair, so the operator is
+the matrix itself, R^+ = R^-1 and rank = n -- the load-time constants of VIScheme.__init__
+(reference variational_inference.py:236-252) are computed here in that closed form, on the
+GPU with torch.linalg for the full-size workloads (no per-block eigh of 3400 blocks on the
+host), on the host with numpy for the small parity cases.
+
+SNP layout: block after block, each block's LD SNPs followed by the LD-missing SNPs attached
+to it (`missing_frac` of all SNPs, multinomially spread), so `perm` is not the identity.
+"""
+import numpy as np
+
+WORKLOADS = {
+    # name: (P, N_ld, B, M, fixed block size or None)
+    'C2': dict(P=1, n_ld=100_000, B=500, M=25, fixed=200, missing_frac=0.0),
+    'C3': dict(P=2, n_ld=1_000_000, B=1700, M=40, fixed=None, missing_frac=0.05),
+    'tiny': dict(P=2, n_ld=6_000, B=12, M=12, fixed=None, missing_frac=0.05),
+}
+
+
+def block_sizes(n_ld, B, fixed=None, seed=0):
+    """LDetect-like block sizes: lognormal(ln 520, 0.5) clipped to [50, 3000],
+    rescaled to sum to n_ld, residual spread +-1 over blocks in descending-size order."""
+    if fixed is not None:
+        assert fixed * B == n_ld
+        return np.full(B, fixed, dtype=np.int64)
+    rng = np.random.default_rng(seed)
+    n = np.clip(np.round(rng.lognormal(np.log(520), 0.5, B)), 50, 3000)
+    n = np.clip(np.round(n * n_ld / n.sum()), 50, 3000).astype(np.int64)
+    resid = int(n_ld - n.sum())
+    order = np.argsort(-n, kind='stable')
+    i = 0
+    while resid != 0:
+        b = order[i % B]
+        step = 1 if resid > 0 else -1
+        if 50 <= n[b] + step <= 3000:
+            n[b] += step
+            resid -= step
+        i += 1
+    return n
+
+
+def missing_counts(sizes, missing_frac, seed=0):
+    """LD-missing SNPs attached after each block; missing_frac is of ALL SNPs."""
+    if missing_frac <= 0:
+        return np.zeros(len(sizes), dtype=np.int64)
+    n_ld = int(sizes.sum())
+    total = int(round(n_ld * missing_frac / (1.0 - missing_frac)))
+    rng = np.random.default_rng([seed, 17])
+    return rng.multinomial(total, sizes / sizes.sum()).astype(np.int64)
+
+
+def mixture_covs(P, M):
+    """sigma_k^2 = geomspace(1e-8, 1e-2, M); cross-cohort correlation cycling 0, 0.5, 0.9."""
+    var = np.geomspace(1e-8, 1e-2, M)
+    covs = []
+    for k in range(M):
+        r = 0.0 if P == 1 else (0.0, 0.5, 0.9)[k % 3]
+        covs.append(var[k] * ((1 - r) * np.eye(P) + r * np.ones((P, P))))
+    return np.array(covs)
+
+
+def shard_ranges(sizes, miss, world, per_snp_cost):
+    """Contiguous runs of blocks per rank, balanced by 8 n_b^2 + per-SNP cost."""
+    cost = 8.0 * sizes.astype(np.float64) ** 2 + per_snp_cost * (sizes + miss)
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(cum, cum[-1] * r / world)))
+    cuts.append(len(sizes))
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+class BlockData:
+    """The random content of one block (all cohorts), reproducible from (seed, block)."""
+
+    def __init__(self, seed, b, n, m, P):
+        rng = np.random.default_rng([seed, 1000 + b])
+        self.n, self.m = int(n), int(m)
+        self.rho = rng.uniform(0.5, 0.95, size=P)
+        self.se = rng.uniform(0.005, 0.02, size=(P, self.n))
+        causal = rng.random(self.n) < 0.05
+        cov = 0.01 ** 2 * (0.2 * np.eye(P) + 0.8 * np.ones((P, P)))
+        self.beta = np.zeros((P, self.n))
+        if causal.any():
+            self.beta[:, causal] = rng.multivariate_normal(np.zeros(P), cov,
+                                                           size=int(causal.sum())).T
+        self.eps = rng.normal(size=(P, self.n))            # sampling noise of beta-hat
+        self.init_noise = rng.normal(size=(P, self.n))     # the 1e-3*se jitter of _initialize
+
+
+def ar1_numpy(n, rho):
+    idx = np.arange(n)
+    return rho ** np.abs(idx[:, None] - idx[None, :])
+
+
+class SyntheticShard:
+    """One rank's part of a synthetic problem: per-SNP arrays in local SNP order, the local
+    perm per cohort, and a generator of LD blocks (numpy or device tensors)."""
+
+    def __init__(self, P, n_ld, B, M, fixed=None, missing_frac=0.0, seed=0, rank=0, world=1,
+                 gwas_N=1e5, init_hg=0.1, block_range=None):
+        self.P, self.M, self.A, self.seed = P, M, 1, seed
+        self.gwas_N = np.full(P, gwas_N, dtype=np.float64)
+        self.init_hg = np.full(P, init_hg, dtype=np.float64)
+        self.sizes_all = block_sizes(n_ld, B, fixed, seed)
+        self.miss_all = missing_counts(self.sizes_all, missing_frac, seed)
+        self.N_global = int(self.sizes_all.sum() + self.miss_all.sum())
+        self.n_ld_global = int(self.sizes_all.sum())
+        if block_range is None:
+            block_range = shard_ranges(self.sizes_all, self.miss_all, world,
+                                       per_snp_cost=8.0 * 3 * M * P)[rank]
+        self.b0, self.b1 = block_range
+        self.sizes = self.sizes_all[self.b0:self.b1]
+        self.miss = self.miss_all[self.b0:self.b1]
+        self.blocks = [BlockData(seed, self.b0 + i, n, m, P)
+                       for i, (n, m) in enumerate(zip(self.sizes, self.miss))]
+        self.N = int(self.sizes.sum() + self.miss.sum())
+        self.n_ld = int(self.sizes.sum())
+        # local SNP index of every LD position (block SNPs first, then that block's missing)
+        snp_start = np.concatenate([[0], np.cumsum(self.sizes + self.miss)])
+        ld_pos, miss_pos = [], []
+        for i, (n, m) in enumerate(zip(self.sizes, self.miss)):
+            ld_pos.append(np.arange(snp_start[i], snp_start[i] + n))
+            miss_pos.append(np.arange(snp_start[i] + n, snp_start[i] + n + m))
+        self.snp_start = snp_start
+        self.ld_snps = np.concatenate(ld_pos).astype(np.int64)
+        self.missing = (np.concatenate(miss_pos).astype(np.int64) if miss_pos
+                        else np.zeros(0, dtype=np.int64))
+        self.perm = np.concatenate([self.ld_snps, self.missing])
+        self.covs = mixture_covs(P, M)
+        self.ld_bytes = 8 * int((self.sizes.astype(np.int64) ** 2).sum()) * P
+
+    # ------------------------------------------------------------------ LD blocks
+    def ld_blocks_numpy(self, p):
+        for blk in self.blocks:
+            yield ('dense', ar1_numpy(blk.n, blk.rho[p]))
+
+    def ld_blocks_torch(self, p, device):
+        import torch
+        for blk in self.blocks:
+            idx = torch.arange(blk.n, device=device, dtype=torch.float64)
+            yield ('dense', torch.pow(torch.tensor(float(blk.rho[p]), device=device,
+                                                   dtype=torch.float64),
+                                      (idx[:, None] - idx[None, :]).abs()))
+
+    def block_specs(self):
+        return [('dense', int(n), int(n)) for n in self.sizes]
+
+    # ------------------------------------------------------------------ sumstats + constants
+    def build(self, device=None):
+        """Sumstats and the load-time constants for this shard.  With `device` (a torch CUDA
+        device) the per-block linear algebra runs on the GPU via torch.linalg; otherwise numpy.
+        Sets: betahat, se, ld_diags, sld, adj, scalings, annot [.., N] local arrays;
+        chi_local [P], rank_local [P], inv_se2_local [P]; call finish_init(inv_se2_global) to
+        get inverse_betas."""
+        P, N = self.P, self.N
+        self.betahat = np.zeros((P, N))
+        self.se = np.ones((P, N))
+        self.ld_diags = np.zeros((P, N))
+        self.ld_diags[:, self.ld_snps] = 1.0
+        self.chi_local = np.zeros(P)
+        self._z = np.zeros((P, N))
+        for i, blk in enumerate(self.blocks):
+            lo = self.snp_start[i]
+            sl = slice(lo, lo + blk.n)
+            self.se[:, sl] = blk.se
+            for p in range(P):
+                zt = blk.beta[p] / blk.se[p]
+                zhat, chi = _block_sumstats(blk.n, blk.rho[p], zt, blk.eps[p], device)
+                self.betahat[p, sl] = blk.se[p] * zhat
+                self._z[p, sl] = zhat
+                self.chi_local[p] += chi
+        self.rank_local = np.full(P, float(self.n_ld))
+        self.sld = self.ld_diags / self.se ** 2
+        self.adj = self._z / self.se            # (R R^-1 z)/se
+        self.scalings = np.ones((P, N))
+        self.annot = np.zeros(N, dtype=np.int32)
+        self.inv_se2_local = (self.se ** -2).sum(axis=1)
+        self._device = device
+        return self
+
+    def finish_init(self, inv_se2_global):
+        """Ridge start inverse_betas (variational_inference.py:246-252) and the jittered
+        fake_mu of _initialize (:649-657), per block."""
+        P, N = self.P, self.N
+        prior = 2 * self.gwas_N * self.init_hg / np.asarray(inv_se2_global)
+        self.inverse_betas = np.zeros((P, N))
+        self.fake_mu = np.zeros((P, N))
+        for i, blk in enumerate(self.blocks):
+            lo = self.snp_start[i]
+            sl = slice(lo, lo + blk.n)
+            for p in range(P):
+                rhs = self.adj[p, sl] * blk.se[p]
+                sol = _block_ridge(blk.n, blk.rho[p], blk.se[p] ** 2 / prior[p], rhs,
+                                   self._device)
+                self.inverse_betas[p, sl] = sol * blk.se[p]
+                self.fake_mu[p, sl] = self.inverse_betas[p, sl] + 1e-3 * blk.se[p] * blk.init_noise[p]
+        # LD-missing SNPs: NaN in every cohort -> cross-cohort nanmean is NaN -> 0 (:653-657)
+        return self
+
+
+def _block_sumstats(n, rho, z_true, eps, device):
+    """z-hat = R z + R^(1/2) eps (recipe of reference sim.py:136-156) and z-hat^T R^-1 z-hat."""
+    if device is None:
+        R = ar1_numpy(n, rho)
+        L = np.linalg.cholesky(R)
+        zhat = R @ z_true + L @ eps
+        w = np.linalg.solve(L, zhat)
+        return zhat, float(w @ w)
+    import torch
+    idx = torch.arange(n, device=device, dtype=torch.float64)
+    R = torch.pow(torch.tensor(float(rho), device=device, dtype=torch.float64),
+                  (idx[:, None] - idx[None, :]).abs())
+    L = torch.linalg.cholesky(R)
+    zt = torch.as_tensor(z_true, device=device)
+    ep = torch.as_tensor(eps, device=device)
+    zhat = R @ zt + L @ ep
+    w = torch.linalg.solve_triangular(L, zhat[:, None], upper=False)[:, 0]
+    return zhat.cpu().numpy(), float((w @ w).item())
+
+
+def _block_ridge(n, rho, reg, rhs, device):
+    if device is None:
+        return np.linalg.solve(ar1_numpy(n, rho) + np.diag(reg), rhs)
+    import torch
+    idx = torch.arange(n, device=device, dtype=torch.float64)
+    R = torch.pow(torch.tensor(float(rho), device=device, dtype=torch.float64),
+                  (idx[:, None] - idx[None, :]).abs())
+    R = R + torch.diag(torch.as_tensor(reg, device=device))
+    return torch.linalg.solve(R, torch.as_tensor(rhs, device=device)).cpu().numpy()

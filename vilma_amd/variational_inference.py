@@ -1,0 +1,660 @@
+"""MultiPopVI for MI355X: the reference's class API over hand-written HIP kernels.
+
+Interface (constructor keywords, `optimize`, `elbo`, `real_posterior_mean/variance`,
+`create_dump_dict`, attributes, error behaviour) follows
+/root/reference/src/vilma/variational_inference.py:96-109, 340-394, 599-630.  What differs is
+where the work happens:
+
+  * the outer loop, the line search on L and every accept/reject decision stay on the host
+    (variational_inference.py:340-450, 762-802) and are reproduced decision for decision;
+  * every objective evaluation is ONE fused per-SNP kernel + ONE block-diagonal LD product per
+    cohort + a fixed-order reduction on the GPU (libvilma_hip.so), returning the 3P+3 sums of
+    include/vilma_hip.h from which the host assembles the objective;
+  * state lives in HBM: vi_mu only.  vi_delta is a pure function of (vi_mu, hyper_delta,
+    error_scaling) (_nat_to_not_vi_delta, variational_inference.py:632-641) and is
+    re-derived inside the kernels; vi_sigma & co. are never materialised on the device;
+  * R z of the accepted point is cached, so a sweep costs one LD product per *distinct*
+    candidate point (the reference recomputes 5-8 per sweep);
+  * with torch.distributed initialised, SNPs are sharded over ranks (one GPU each) and the
+    sums are all-reduced (RCCL) before every decision, so all ranks take the same branch.
+"""
+import logging
+
+import numpy as np
+
+from . import matrix_structures
+from .sharding import Comm, plan_shards, local_ld
+
+L_MAX = 1e12        # reference variational_inference.py:18-24
+REL_TOL = 1e-6
+ABS_TOL = 1e-6
+ELBO_TOL = 0.1
+EM_TOL = 10
+ELBO_MOMENTUM = 0.5
+MAX_NUM_ITERS = 20
+EPSILON = 1e-100    # reference numerics.py:8
+
+_INIT_CHUNK = 1 << 15
+
+
+def _inv_small(mats):
+    """Inverse of [..., P, P] matrices; closed forms for P<=2 as the reference's helpers
+    (numerics.py:216-244)."""
+    P = mats.shape[-1]
+    if P == 1:
+        return 1.0 / mats
+    if P == 2:
+        a, b, c, d = mats[..., 0, 0], mats[..., 0, 1], mats[..., 1, 0], mats[..., 1, 1]
+        r = 1.0 / (a * d - b * c)
+        out = np.empty_like(mats)
+        out[..., 0, 0] = d * r
+        out[..., 1, 1] = a * r
+        out[..., 1, 0] = -c * r
+        out[..., 0, 1] = out[..., 1, 0]
+        return out
+    return np.linalg.inv(mats)
+
+
+def _logdet_small(mats):
+    P = mats.shape[-1]
+    if P == 1:
+        return np.log(mats[..., 0, 0])
+    if P == 2:
+        return np.log(mats[..., 0, 0] * mats[..., 1, 1] - mats[..., 0, 1] * mats[..., 1, 0])
+    return np.linalg.slogdet(mats)[1]
+
+
+def initial_vi_mu(fake_mu, sld, tau, prec, log_det, annot, num_annotations):
+    """The per-SNP part of _initialize (reference variational_inference.py:658-692) for the
+    SNPs given, in chunks so [n,M,P,P] temporaries stay small: heuristic responsibilities from
+    the 1.6x-inflated quadratic form, then vi_mu = Sigma_ki (avg Sigma_i)^-1 fake_mu.
+    Returns (vi_mu [M,P,n], per-annotation sums of the heuristic responsibilities [A,M])."""
+    P, n = fake_mu.shape
+    M = prec.shape[0]
+    vi_mu = np.empty((M, P, n))
+    sums = np.zeros((num_annotations, M))
+    idx = np.arange(P)
+    for lo in range(0, n, _INIT_CHUNK):
+        hi = min(n, lo + _INIT_CHUNK)
+        f = fake_mu[:, lo:hi]
+        lam = np.broadcast_to(prec[None], (hi - lo, M, P, P)).copy()
+        lam[:, :, idx, idx] += (sld[:, lo:hi] / tau[:, None]).T[:, None, :]
+        sigma = _inv_small(lam)                                  # [n,M,P,P]
+        probs = np.einsum('pi,oi,kpo->ik', 1.6 * f, 1.6 * f, prec)
+        probs += np.einsum('kpq,ikqp->ik', prec, sigma)
+        probs -= log_det
+        probs = np.exp(-0.5 * (probs - probs.min(axis=1, keepdims=True)))
+        delta = np.maximum(probs / probs.sum(axis=1, keepdims=True), EPSILON)
+        ann = annot[lo:hi]
+        for a in range(num_annotations):
+            sums[a] += delta[ann == a].sum(axis=0)
+        avg = np.einsum('ikpq,ik->ipq', sigma, delta)
+        nat = np.einsum('pi,iqp->qi', f, np.linalg.inv(avg))
+        vi_mu[:, :, lo:hi] = np.einsum('ikqp,pi->kqi', sigma, nat)
+    return vi_mu, sums
+
+
+def initial_hyper(delta_sums):
+    """hyper_delta of _initialize (variational_inference.py:667-674) from the global sums."""
+    hyper = np.asarray(delta_sums, dtype=np.float64) + 1.
+    hyper /= hyper.sum(axis=1, keepdims=True)
+    return np.maximum(hyper, EPSILON)
+
+
+class DeviceParams:
+    """(vi_mu, vi_delta, hyper_delta) of a state held on the GPU; arrays are downloaded (and
+    gathered across ranks) only when indexed, so sweeps do not pay PCIe traffic."""
+
+    def __init__(self, owner, version, hyper):
+        self._owner, self._version = owner, version
+        self.hyper_delta = np.array(hyper)
+        self._cache = {}
+
+    def _fetch(self, which):
+        if which not in self._cache:
+            if self._owner._version != self._version:
+                raise RuntimeError('these parameters are no longer resident on the device; '
+                                   'index the tuple before taking further steps')
+            self._cache[which] = self._owner._download(which)
+        return self._cache[which]
+
+    def __len__(self):
+        return 3
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[j] for j in range(3))[i]
+        if i < 0:
+            i += 3
+        if i == 0:
+            return self._fetch('vi_mu')
+        if i == 1:
+            return self._fetch('vi_delta')
+        if i == 2:
+            return self.hyper_delta
+        raise IndexError(i)
+
+    def __iter__(self):
+        return iter((self[0], self[1], self[2]))
+
+
+class SweepDriver:
+    """The host side of the sweep loop over an engine holding one shard on one GPU.
+
+    Needs only the shard-independent constants (chi_stat, ld_ranks, annotation_counts, log_det)
+    plus an engine and a Comm; MultiPopVI builds these from the reference's class-API inputs,
+    bench.py builds them from device-resident synthetic data."""
+
+    param_names = ['vi_mu', 'vi_delta', 'hyper_delta']
+
+    def _setup_driver(self, engine, comm, num_pops, num_mix, num_annotations, chi_stat,
+                      ld_ranks, annotation_counts, log_det, scale_se, num_its,
+                      checkpoint=False, checkpoint_freq=-1, checkpoint_path='vilma-checkpoint'):
+        self.engine, self.comm = engine, comm
+        self.num_pops, self.num_mix, self.num_annotations = num_pops, num_mix, num_annotations
+        self.chi_stat = np.asarray(chi_stat, dtype=np.float64)
+        self.ld_ranks = np.asarray(ld_ranks, dtype=np.float64)
+        self.annotation_counts = np.asarray(annotation_counts, dtype=np.float64)
+        self.log_det = np.asarray(log_det, dtype=np.float64)
+        self.scale_se, self.num_its = scale_se, num_its
+        self.checkpoint, self.checkpoint_freq = checkpoint, checkpoint_freq
+        self.checkpoint_path = checkpoint_path
+        if not hasattr(self, 'error_scaling'):
+            self.error_scaling = np.ones(num_pops)
+        self._nat_table = None
+        self._version = 0           # bumped whenever the device state moves
+        self._hyper = None
+        self._totals = None         # all-reduced sums of the current (accepted) state
+        self._objective = None
+        self.n_evaluations = 0      # candidate points evaluated (= LD products per cohort)
+        self.n_trials = 0           # beta line-search trials among them
+        self.num_its_run = 0
+
+    def start_from(self, vi_mu_local, hyper):
+        """Make (vi_mu of this shard, hyper_delta) the current state and evaluate it."""
+        self.engine.set_tau(self.error_scaling)
+        self._set_hyper(hyper)
+        self.engine.set_mu(vi_mu_local)
+        obj, totals = self._evaluate()
+        self._accept(False, obj, totals)
+        return self._params()
+
+    # ------------------------------------------------------------------ device plumbing
+    def _objective_from(self, t):
+        """fast_likelihood (numerics.py:31-46) minus _beta_KL (variational_inference.py:873-885)
+        from the all-reduced sums."""
+        P = self.num_pops
+        lin, var, quad = t[:P], t[P:2 * P], t[2 * P:3 * P]
+        tau = self.error_scaling
+        lik = (-0.5 * (var + quad) + lin - 0.5 * self.chi_stat) / tau \
+            - 0.5 * self.ld_ranks * np.log(tau)
+        return float(lik.sum() - (t[3 * P] + t[3 * P + 1] + t[3 * P + 2]))
+
+    def _evaluate(self, step=None):
+        """Objective of a candidate point: the current vi_mu (step None) or a natural-gradient
+        trial at `step`.  The candidate stays on the device as the trial state."""
+        raw = self.engine.eval() if step is None else self.engine.trial(step)
+        totals = self.comm.allreduce(raw)
+        self.n_evaluations += 1
+        return self._objective_from(totals), totals
+
+    def _accept(self, take_mu, obj, totals):
+        self.engine.accept(take_mu)
+        self._objective, self._totals = obj, totals
+        self._version += 1
+
+    def _set_hyper(self, hyper):
+        self._hyper = np.array(hyper)
+        self.engine.set_hyper(self._hyper)
+        log_h = np.log(self._hyper) - 0.5 * self.log_det[None, :]
+        # fast_vi_delta_grad (numerics.py:149-164) as an [A, M-1] table; the per-SNP array the
+        # reference stores is this table indexed by annotation
+        self._nat_table = log_h[:, :-1] - log_h[:, -1:]
+
+    def _upload(self, params):
+        """Make `params` the current device state and evaluate it."""
+        if isinstance(params, DeviceParams) and params._owner is self \
+                and params._version == self._version:
+            return
+        vi_mu, _, hyper = params[0], params[1], params[2]
+        self.start_from(self._local_part(np.asarray(vi_mu)), hyper)
+
+    def _local_part(self, vi_mu_global):
+        return vi_mu_global
+
+    def _params(self):
+        return DeviceParams(self, self._version, self._hyper)
+
+    def _download(self, which):
+        """This shard's vi_mu / vi_delta (MultiPopVI gathers them across ranks)."""
+        return self.engine.get_mu() if which == 'vi_mu' else self.engine.get_delta()
+
+    # ------------------------------------------------------------------ one sweep
+    def _update_beta(self, L, idx, lsr, orig_obj):
+        """One damped natural-gradient step with backtracking (variational_inference.py:
+        762-802).  Returns (orig_obj, new_obj)."""
+        if self._hyper is None:
+            raise RuntimeError('nat_grad_vi_delta must always be set prior to running '
+                               '_update_beta')
+        while True:
+            new_obj, totals = self._evaluate(1. / L[idx])
+            self.n_trials += 1
+            logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
+            if new_obj >= orig_obj - REL_TOL * np.abs(orig_obj) - ABS_TOL:
+                if L[idx] > L_MAX and not np.isclose(orig_obj, new_obj):
+                    raise RuntimeError('Encountered a numerical error.')
+                self._accept(True, new_obj, totals)
+                return orig_obj, new_obj
+            if L[idx] > L_MAX:
+                if not np.isclose(orig_obj, new_obj):
+                    raise RuntimeError('Encountered a numerical error.')
+                return orig_obj, orig_obj
+            L[idx] *= lsr
+
+    def _update_hyper_delta(self, orig_obj):
+        """Closed-form M-step for the mixture weights (variational_inference.py:825-860)."""
+        sums = self.comm.allreduce(self.engine.delta_sums())
+        new_hyper = sums.reshape(self.num_annotations, self.num_mix)
+        new_hyper = np.maximum(new_hyper / (self.annotation_counts.reshape((-1, 1)) + EPSILON),
+                               EPSILON)
+        new_hyper /= new_hyper.sum(axis=1, keepdims=True)
+        self._set_hyper(new_hyper)
+        new_obj, totals = self._evaluate()
+        self._accept(False, new_obj, totals)
+        logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
+        return orig_obj, new_obj
+
+    def _update_error_scaling(self):
+        """EM update of the SE scaling (variational_inference.py:472-486, 735-738) from the
+        sums of the current state; the sigma-dependent constants follow tau inside the kernels."""
+        P = self.num_pops
+        t = self._totals
+        lin, var, quad = t[:P], t[P:2 * P], t[2 * P:3 * P]
+        self.error_scaling = (self.chi_stat - 2 * lin + quad + var) / self.ld_ranks
+        self.engine.set_tau(self.error_scaling)
+
+    def _nat_grad_step(self, L, line_search_rate, running_elbo_delta=None):
+        """variational_inference.py:419-450 with the redundant re-evaluations removed: the
+        objective of the state a parameter-set update starts from is the one already computed
+        when that state was accepted."""
+        conv_tol = float('inf') if running_elbo_delta is None else 0.1 * running_elbo_delta
+        delta_sum = 0
+        # ---- paramset 0: variational family of beta
+        orig_obj = self._objective
+        for _ in range(MAX_NUM_ITERS):
+            L[0] = max([1., L[0] / 1.25])
+            logging.info('...Updating paramset %d, L=%f', 0, L[0])
+            orig_obj, new_obj = self._update_beta(L, 0, line_search_rate, orig_obj)
+            delta_sum += new_obj - orig_obj
+            if (np.isclose(new_obj - orig_obj, 0, atol=conv_tol, rtol=0)
+                    or L[0] == 1 or L[0] > L_MAX):
+                break
+            orig_obj = new_obj
+        # ---- paramset 1: mixture weights (L[1] stays 1, so exactly one pass)
+        L[1] = max([1., L[1] / 1.25])
+        logging.info('...Updating paramset %d, L=%f', 1, L[1])
+        orig_obj, new_obj = self._update_hyper_delta(self._objective)
+        delta_sum += new_obj - orig_obj
+        # ---- paramset 2: annotations -- nothing to do in this scheme (:862-866)
+        L[2] = max([1., L[2] / 1.25])
+        logging.info('...Updating paramset %d, L=%f', 2, L[2])
+        if self.scale_se and delta_sum < EM_TOL:
+            orig_obj = self._objective
+            self._update_error_scaling()
+            new_obj, totals = self._evaluate()
+            self._accept(False, new_obj, totals)
+            delta_sum += new_obj - orig_obj
+            logging.info('...Updating error_scaling, old ELBo=%f, new ELBo=%f', orig_obj, new_obj)
+        return L, delta_sum
+
+    def _optimize_step(self, params, L, curr_elbo, line_search_rate=1.25,
+                       running_elbo_delta=None):
+        """variational_inference.py:396-410."""
+        self._upload(params)
+        logging.info('Current ELBO = %f and L = %f,%f,%f,%f,%f', curr_elbo, *L[:5])
+        L_new, elbo_change = self._nat_grad_step(L, line_search_rate, running_elbo_delta)
+        elbo = curr_elbo + elbo_change
+        if running_elbo_delta is None:
+            running_elbo_delta = elbo_change
+        running_elbo_delta *= ELBO_MOMENTUM
+        running_elbo_delta += (1 - ELBO_MOMENTUM) * np.maximum(elbo_change, 0)
+        return self._params(), L_new, elbo, running_elbo_delta
+
+    def _diff_stats(self):
+        raw = self.engine.mean_diff()
+        if self.comm.world == 1:
+            return raw.cpu().numpy()
+        s = self.comm.allreduce(raw[:3].clone())
+        m = self.comm.allreduce(raw[3:].clone(), op='max')
+        return np.concatenate([s, m])
+
+    def sweep(self, state=None):
+        """One outer iteration as optimize() runs it: _optimize_step + convergence statistics.
+        `state` carries (L, elbo, running_elbo_delta) between calls; returns (state, stats)."""
+        if state is None:
+            self.engine.snapshot_mean()
+            state = {'L': np.ones(5), 'elbo': self._objective, 'running': None}
+        _, L, elbo, running = self._optimize_step(self._params(), L=state['L'],
+                                                   curr_elbo=state['elbo'], line_search_rate=2.,
+                                                   running_elbo_delta=state['running'])
+        stats = self._diff_stats()
+        return {'L': L, 'elbo': elbo, 'running': running}, stats
+
+    # ------------------------------------------------------------------ driver
+    def optimize(self, loaded_checkpoint=None):
+        """Initialise and run sweeps until convergence (variational_inference.py:340-394)."""
+        if loaded_checkpoint is None:
+            params = self._initialize()
+        else:
+            loaded = [loaded_checkpoint[name] for name in self.param_names]
+            try:
+                self.error_scaling = np.array(loaded_checkpoint['error_scaling'],
+                                              dtype=np.float64)
+            except KeyError:
+                logging.warning('Did not find "error_scaling" in the loaded checkpoint. That '
+                                'is okay, but we will have to assume that the error scalings '
+                                'are 1.')
+            self._upload(loaded)
+            params = self._params()
+        converged = False
+        elbo = self._objective
+        running = None
+        num_its = 0
+        L = np.ones(5)
+        n_total = self.num_pops * self.num_loci
+        self.engine.snapshot_mean()
+        verbose = logging.getLogger().isEnabledFor(logging.INFO)
+        ckp_mean = self.real_posterior_mean(params) if (verbose and self.checkpoint) else None
+        while num_its < self.num_its and not converged:
+            if self.checkpoint and num_its % self.checkpoint_freq == 0:
+                fname = '{}.{}'.format(self.checkpoint_path, num_its)
+                dump = self.create_dump_dict(params)
+                if self.comm.rank == 0:
+                    np.savez(fname, **dump)
+                if verbose:
+                    ckp_mean = self.real_posterior_mean(params)
+            params, L, elbo, running = self._optimize_step(
+                params, L=L, curr_elbo=elbo, line_search_rate=2., running_elbo_delta=running)
+            d = self._diff_stats()
+            converged = d[0] == 0
+            converged = converged or bool(np.isclose(running, 0, atol=ELBO_TOL, rtol=0))
+            if num_its < 10 and loaded_checkpoint is None:
+                converged = False
+            if verbose:
+                self._dump_info(num_its, d, n_total, params, ckp_mean)
+            num_its += 1
+        if num_its == self.num_its:
+            logging.warning('Failed to converge')
+        logging.info('Optimization ran for %d iterations', num_its)
+        self.num_its_run = num_its
+        return params
+
+    def _dump_info(self, num_its, d, n_total, params, ckp_mean):
+        """The reference's per-iteration INFO lines (variational_inference.py:292-331)."""
+        logging.info('Completed iteration %d', num_its + 1)
+        logging.info('Maximum posterior mean beta: %e', d[3])
+        logging.info('SE scaling is: %r', self.error_scaling)
+        logging.info('Max relative difference is: %e', d[5])
+        logging.info('Max absolute difference is: %e', d[4])
+        logging.info('Mean absolute difference is: %e', d[1] / n_total)
+        logging.info('RMSE difference is: %e', np.sqrt(d[2] / n_total))
+        if ckp_mean is not None:
+            new = self.real_posterior_mean(params)
+            logging.info('Max relative difference (checkpoint iterations) is: %e',
+                         np.max(np.abs((new - ckp_mean) / (ckp_mean + EPSILON))))
+            logging.info('Max absolute difference (checkpoint iterations) is: %e',
+                         np.max(np.abs(new - ckp_mean)))
+            logging.info('Mean absolute difference (checkpoint iterations) is: %e',
+                         np.mean(np.abs(new - ckp_mean)))
+            logging.info('RMSE difference (checkpoint iterations) is: %e',
+                         np.sqrt(np.mean((new - ckp_mean) ** 2)))
+
+
+class MultiPopVI(SweepDriver):
+    """Fit the multi-population mixture-of-Gaussians VI scheme on MI355X.
+
+    Keyword arguments are the reference's (variational_inference.py:96-142).  `form` selects
+    the LD storage ('auto' | 'dense' | 'eig'); `_engine_factory` lets tests inject a different
+    engine implementation (the default is the HIP engine and there is no CPU fallback)."""
+
+    def __init__(self, marginal_effects=None, std_errs=None, ld_mats=None, annotations=None,
+                 mixture_covs=None, checkpoint=True, checkpoint_freq=5, scaled=False,
+                 scale_se=False, output='vilma_output', gwas_N=None, init_hg=None,
+                 num_its=None, form='auto', _engine_factory=None, _comm=None):
+        # ---- argument checks, in the reference's order and with its exceptions ----
+        if marginal_effects is not None and mixture_covs is not None:
+            P_ = np.asarray(marginal_effects).shape[0]
+            for mc in mixture_covs:
+                if np.asarray(mc).shape != (P_, P_):
+                    raise ValueError('Mixture component has a covariance matrix of the '
+                                     'wrong shape.')
+            signs, _ = np.linalg.slogdet(mixture_covs)
+            if not np.all(signs == 1):
+                raise ValueError('Mixture component has a non-positive definite covariance '
+                                 'matrix.')
+        required = (('init_hg', init_hg), ('gwas_N', gwas_N),
+                    ('marginal_effects', marginal_effects), ('std_errs', std_errs),
+                    ('ld_mats', ld_mats), ('annotations', annotations),
+                    ('mixture_covs', mixture_covs), ('num_its', num_its))
+        for name, val in required:
+            if val is None:
+                raise ValueError('%s must be specified when calling VIScheme()' % name)
+        marginal_effects = np.asarray(marginal_effects, dtype=np.float64)
+        std_errs = np.asarray(std_errs, dtype=np.float64)
+        annotations = np.asarray(annotations)
+        if not np.all(np.isfinite(marginal_effects)):
+            raise ValueError('Encountered an infinite or NaN value in the GWAS effect size '
+                             'estimates')
+        if not np.all(np.isfinite(std_errs)):
+            raise ValueError('Encountered an infinity or NaN value in the GWAS standard errors')
+
+        self.scaled, self.scale_se = scaled, scale_se
+        self.num_pops, self.num_loci = marginal_effects.shape
+        self.num_mix = len(mixture_covs)
+        P, N, M = self.num_pops, self.num_loci, self.num_mix
+        self.error_scaling = np.ones(P)
+        self.checkpoint, self.checkpoint_freq = checkpoint, checkpoint_freq
+        self.checkpoint_path = '%s-checkpoint' % output
+        if len(ld_mats) != P:
+            raise ValueError('Fewer LD matrices than populations.')
+        for ld in ld_mats:
+            if not isinstance(ld, matrix_structures.BlockDiagonalMatrix):
+                raise ValueError('LD Matrices must be of type BlockDiagonalMatrix.')
+        for ld in ld_mats:
+            if ld.shape != (N, N):
+                raise ValueError('LD matrix shape does not match GWAS marginal effect size '
+                                 'shape.')
+        if not np.allclose(annotations.sum(axis=1), 1):
+            raise ValueError('Some SNPs are either missing annotations or have more than one '
+                             'annotation.')
+        if annotations.shape[0] != N:
+            raise ValueError('annotations dimension does not match GWAS marginal effect size '
+                             'shape.')
+        self.num_annotations = annotations.shape[1]
+        if scaled:                                   # variational_inference.py:205-214
+            self.marginal_effects = marginal_effects / (std_errs + EPSILON)
+            self.std_errs = np.ones_like(std_errs)
+            self.scalings = std_errs + EPSILON
+        else:
+            self.marginal_effects = np.copy(marginal_effects)
+            self.std_errs = np.copy(std_errs)
+            self.scalings = np.ones_like(std_errs)
+        self.ld_mats = ld_mats
+        self.annotations = np.copy(np.where(annotations)[1])
+        self.annotation_counts = annotations.sum(axis=0)
+        self.init_hg = np.asarray(init_hg, dtype=np.float64)
+        self.gwas_N = np.asarray(gwas_N, dtype=np.float64)
+        self.num_its = num_its
+
+        covs = np.array(mixture_covs, dtype=np.float64)            # :621-626
+        prec = _inv_small(covs)
+        self.mixture_prec = prec[:, :, :, None]
+        self.log_det = _logdet_small(covs)
+
+        # ---- shard plan and the device engine for this rank ----
+        self.comm = _comm if _comm is not None else Comm()
+        per_snp = 8.0 * (3 * M * P)
+        self._plan = plan_shards(ld_mats, N, self.comm.world, per_snp_cost=per_snp)
+        mine = self._plan[self.comm.rank]
+        self._snps = mine['snps']
+        n_loc = len(self._snps)
+        if n_loc == 0:
+            raise ValueError('rank %d received no SNPs: fewer LD components than GPUs'
+                             % self.comm.rank)
+        if _engine_factory is None:
+            from .engine import HipEngine
+            _engine_factory = HipEngine
+        self.engine = _engine_factory(P, n_loc, M, self.num_annotations)
+
+        # ---- one-time constants (variational_inference.py:189-252), host numpy per block ----
+        self.ld_diags = np.stack([ld.diag() for ld in ld_mats])
+        self.scaled_ld_diags = self.std_errs ** -2 * self.ld_diags
+        loc = self._snps
+        local_lds = []
+        for p, ld in enumerate(ld_mats):
+            mats, perm, n_ld = local_ld(ld, loc, mine['blocks'][p], N)
+            sub = matrix_structures.BlockDiagonalMatrix(mats, perm=perm,
+                                                        missing=perm[n_ld:])
+            local_lds.append(sub)
+            self.engine.load_ld(p, sub.device_blocks(form), perm, n_ld)
+        self._local_lds = local_lds
+
+        mle = np.zeros((P, n_loc))
+        chi_loc, rank_loc = np.zeros(P), np.zeros(P)
+        z_loc = self.marginal_effects[:, loc] / self.std_errs[:, loc]
+        for p in range(P):
+            mle[p] = local_lds[p].inverse.dot(z_loc[p])
+            chi_loc[p] = z_loc[p].dot(mle[p])
+            rank_loc[p] = local_lds[p].get_rank()
+        # adj = (R R^+ z) / se: the first product of the fit already runs on the GPU
+        adj_loc = self.engine.ld_matvec(mle) / self.std_errs[:, loc]
+        sums = self.comm.allreduce_np(np.concatenate([chi_loc, rank_loc]))
+        self.chi_stat, self.ld_ranks = sums[:P], sums[P:]
+        inv_se2 = self.comm.allreduce_np((self.std_errs[:, loc] ** -2).sum(axis=1)) \
+            if self.comm.world > 1 else (self.std_errs ** -2).sum(axis=1)
+        inverse_loc = np.zeros((P, n_loc))
+        for p in range(P):
+            prior = 2 * self.gwas_N[p] * self.init_hg[p] / inv_se2[p]
+            ridge = local_lds[p].ridge_inverse_dot(adj_loc[p] * self.std_errs[p, loc],
+                                                   self.std_errs[p, loc] ** 2 / prior)
+            inverse_loc[p] = ridge * self.std_errs[p, loc]
+        self.adj_marginal_effects = self.comm.gather_snps(adj_loc, loc, N)
+        self.inverse_betas = self.comm.gather_snps(inverse_loc, loc, N)
+        if not np.allclose(self.adj_marginal_effects[np.isclose(self.ld_diags, 0)], 0):
+            raise ValueError('Some SNPs that are missing in the LD matrix are not being '
+                             'treated as missing.')
+
+        self.engine.set_snp_data(adj_loc, self.std_errs[:, loc], self.scaled_ld_diags[:, loc],
+                                 self.scalings[:, loc], self.annotations[loc])
+        self.engine.set_mixture(prec, self.log_det)
+        self.engine.set_tau(self.error_scaling)
+
+        self._setup_driver(self.engine, self.comm, P, M, self.num_annotations, self.chi_stat,
+                           self.ld_ranks, self.annotation_counts, self.log_det, scale_se, num_its,
+                           checkpoint=checkpoint, checkpoint_freq=checkpoint_freq,
+                           checkpoint_path=self.checkpoint_path)
+
+    @property
+    def nat_grad_vi_delta(self):
+        """[N, M-1] natural parameter of the mixture weights (numerics.py:149-164), expanded
+        from the [A, M-1] table the device uses; None until hyper_delta has been set."""
+        if getattr(self, '_nat_table', None) is None:
+            return None
+        return self._nat_table[self.annotations]
+
+    @nat_grad_vi_delta.setter
+    def nat_grad_vi_delta(self, value):
+        if value is None:
+            self._nat_table = None
+
+    def _local_part(self, vi_mu_global):
+        return vi_mu_global[:, :, self._snps]
+
+    def _download(self, which):
+        if which == 'vi_mu':
+            return self.comm.gather_snps(self.engine.get_mu(), self._snps, self.num_loci)
+        delta = self.engine.get_delta()
+        return np.ascontiguousarray(
+            self.comm.gather_snps(np.ascontiguousarray(delta.T), self._snps, self.num_loci).T)
+
+    # ------------------------------------------------------------------ host-side views
+    def _lam(self):
+        lam = np.zeros((self.num_mix, self.num_pops, self.num_pops, self.num_loci))
+        idx = np.arange(self.num_pops)
+        lam[:, idx, idx, :] = self.scaled_ld_diags / self.error_scaling.reshape((-1, 1))
+        return lam + self.mixture_prec
+
+    @property
+    def vi_sigma(self):
+        """[M,P,P,N], computed on demand for outputs (variational_inference.py:712-724)."""
+        lam = np.transpose(self._lam(), (3, 0, 1, 2))
+        return np.transpose(_inv_small(lam), (1, 2, 3, 0))
+
+    @property
+    def nat_sigma(self):
+        return -0.5 * self._lam()
+
+    @property
+    def vi_sigma_log_det(self):
+        return -np.transpose(_logdet_small(np.transpose(self._lam(), (3, 0, 1, 2))))
+
+    @property
+    def vi_sigma_matches(self):
+        return np.einsum('kpq,kqpi->ik', self.mixture_prec[:, :, :, 0], self.vi_sigma)
+
+    @property
+    def sigma_summary(self):
+        return self.log_det - self.vi_sigma_log_det.T + self.vi_sigma_matches
+
+    # ------------------------------------------------------------------ public API
+    def elbo(self, params):
+        """ELBO of `params` (variational_inference.py:412-417)."""
+        self._upload(params)
+        return self._objective
+
+    def _moments(self, params):
+        self._upload(params)
+        mean, var = self.engine.get_moments()
+        return (self.comm.gather_snps(mean, self._snps, self.num_loci),
+                self.comm.gather_snps(var, self._snps, self.num_loci))
+
+    def real_posterior_mean(self, vi_mu=None, vi_delta=None, hyper_delta=None):
+        params = vi_mu if isinstance(vi_mu, DeviceParams) else (vi_mu, vi_delta, hyper_delta)
+        return self._moments(params)[0] * self.scalings
+
+    def real_posterior_variance(self, vi_mu=None, vi_delta=None, hyper_delta=None):
+        params = vi_mu if isinstance(vi_mu, DeviceParams) else (vi_mu, vi_delta, hyper_delta)
+        return self._moments(params)[1] * self.scalings ** 2
+
+    def create_dump_dict(self, params):
+        dump = dict(zip(self.param_names, (params[0], params[1], params[2])))
+        dump['error_scaling'] = self.error_scaling
+        dump['scalings'] = self.scalings
+        return dump
+
+    # ------------------------------------------------------------------ initialisation
+    def _initialize(self):
+        """Starting point (variational_inference.py:643-700).  The random draw is the
+        reference's single legacy-RNG call over the full [P,N] array, so seeds reproduce."""
+        P, N, M = self.num_pops, self.num_loci, self.num_mix
+        logging.info('Largest inverse_beta is %f', np.max(np.abs(self.inverse_betas)))
+        missing = np.isclose(self.ld_diags, 0)
+        fake_mu = np.random.normal(loc=np.copy(self.inverse_betas),
+                                   scale=1e-3 * self.std_errs, size=(P, N))
+        fake_mu[missing] = np.nan
+        n_obs = (~missing).sum(axis=0)
+        col_mean = np.where(n_obs > 0, np.nansum(fake_mu, axis=0) / np.maximum(n_obs, 1), np.nan)
+        fill = np.tile(col_mean, [P, 1])
+        fake_mu[missing] = fill[missing]
+        fake_mu[np.isnan(fake_mu)] = 0.
+
+        loc = self._snps
+        vi_mu, sums = initial_vi_mu(fake_mu[:, loc], self.scaled_ld_diags[:, loc],
+                                    self.error_scaling, self.mixture_prec[:, :, :, 0],
+                                    self.log_det, self.annotations[loc], self.num_annotations)
+        hyper = initial_hyper(self.comm.allreduce_np(sums))
+        return self.start_from(vi_mu, hyper)
+
+    def _set_state(self, params):
+        self._upload(params)
+
