@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 CSV output (run on the GPU box) to the small summaries kept in profiles/.
+
+    python profiles/summarize_rocprof.py <rocprof_output_dir> <out_prefix>
+
+Writes <out_prefix>_kernel_stats.csv (rocprofv3 --stats table, our kernels + top others),
+<out_prefix>_vilma_kernels.json (per-kernel count / avg / min / max duration from the kernel
+trace) and, when a counter collection is present, <out_prefix>_pmc.json (per-kernel mean counter
+value per dispatch)."""
+import glob
+import json
+import os
+import sys
+
+import pandas as pd
+
+OURS = ('ld_colsum_kernel', 'snp_pass_kernel', 'delta_kernel', 'reduce_cols_kernel',
+        'finalize_kernel', 'mean_diff', 'gather_x_kernel', 'scatter_y_kernel')
+
+
+def short(name):
+    for k in OURS:
+        if k in name:
+            return k
+    return None
+
+
+def main():
+    src, prefix = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+    for f in glob.glob(os.path.join(src, '**', '*kernel_stats.csv'), recursive=True):
+        df = pd.read_csv(f)
+        name_col = [c for c in df.columns if 'Name' in c][0]
+        keep = df[df[name_col].map(lambda n: short(str(n)) is not None)]
+        rest = df[~df.index.isin(keep.index)].head(8)
+        pd.concat([keep, rest]).to_csv(prefix + '_kernel_stats.csv', index=False)
+    for f in glob.glob(os.path.join(src, '**', '*kernel_trace.csv'), recursive=True):
+        df = pd.read_csv(f, usecols=['Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
+        df['k'] = df['Kernel_Name'].map(lambda n: short(str(n)))
+        df = df[df['k'].notna()]
+        df['us'] = (df['End_Timestamp'] - df['Start_Timestamp']) / 1e3
+        out = {}
+        for k, grp in df.groupby('k'):
+            out[k] = {'calls': int(len(grp)), 'avg_us': float(grp.us.mean()),
+                      'min_us': float(grp.us.min()), 'max_us': float(grp.us.max()),
+                      'total_ms': float(grp.us.sum() / 1e3)}
+        # the dominant kernel's launches split by size: the big launches are the full LD product
+        ld = df[df.k == 'ld_colsum_kernel']
+        if len(ld):
+            big = ld[ld.us > 0.5 * ld.us.max()]
+            out['ld_colsum_kernel_full_product'] = {'calls': int(len(big)),
+                                                    'avg_us': float(big.us.mean())}
+        json.dump(out, open(prefix + '_vilma_kernels.json', 'w'), indent=1)
+    for f in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
+        df = pd.read_csv(f, usecols=['Kernel_Name', 'Counter_Name', 'Counter_Value',
+                                     'Start_Timestamp', 'End_Timestamp'])
+        df['k'] = df['Kernel_Name'].map(lambda n: short(str(n)))
+        df = df[df['k'].notna()]
+        df['us'] = (df['End_Timestamp'] - df['Start_Timestamp']) / 1e3
+        out = {}
+        for (k, c), grp in df.groupby(['k', 'Counter_Name']):
+            big = grp[grp.us > 0.5 * grp.us.max()]
+            out.setdefault(k, {})[c] = {'dispatches': int(len(grp)),
+                                        'mean_per_dispatch': float(grp.Counter_Value.mean()),
+                                        'mean_over_large_dispatches': float(big.Counter_Value.mean()),
+                                        'large_dispatches': int(len(big))}
+        json.dump(out, open(prefix + '_pmc.json', 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
