@@ -9,7 +9,7 @@ Workload C3 (BASELINE.json configs[2], the one the metric is quoted on): 2 cohor
 SNPs in 1700 LDetect-sized AR(1) LD blocks (+5% LD-missing SNPs), M=40 mixture components,
 dense-rank LD held in fp64 (11.98 GB), inputs resident in HBM before the timed region.
 With N>1 (launched by torch.distributed.run, one rank per GPU) the same global problem is
-sharded by LD blocks (strong scaling); the 3P+3 sums are all-reduced over RCCL per evaluation.
+sharded by LD blocks (strong scaling); the 3P+2 sums are all-reduced over RCCL per evaluation.
 
 Prints ONE JSON line (rank 0) with the sweep throughput, the roofline object of the dominant
 kernel (ld_colsum_kernel, timed with HIP events on its launch stream inside the library) and,

@@ -37,12 +37,12 @@ typedef struct vilma_ctx vilma_ctx;
  *   [0,P)    lin_p  = sum_i m_pi * adj_pi
  *   [P,2P)   var_p  = sum_i (ld_diag_pi / se_pi^2) * v_pi
  *   [2P,3P)  quad_p = sum_i (R_p z_p)_i * z_pi,  z = m / se
- *   3P       delta_kl  (numerics.py:132-141)
- *   3P+1     ip_comp   (numerics.py:98-115)
- *   3P+2     beta_kl   (numerics.py:144-146)
+ *   3P       kl_mix = delta_kl + beta_kl  (numerics.py:132-146; summed because the
+ *            log-determinant terms of the two cancel and are never computed on the device)
+ *   3P+1     ip_comp  (numerics.py:98-115)
  * These are the per-shard sums from which fast_likelihood (numerics.py:31-46) and _beta_KL
  * (variational_inference.py:873-885) are assembled on the host after the all-reduce. */
-#define VILMA_NTOTALS(P) (3 * (P) + 3)
+#define VILMA_NTOTALS(P) (3 * (P) + 2)
 
 /* number of doubles written by vilma_mean_diff */
 #define VILMA_NDIFF 6
@@ -89,7 +89,8 @@ int vilma_set_hyper(vilma_ctx *ctx, const double *hyper);
 int vilma_ld_begin(vilma_ctx *ctx, int cohort, int n_blocks, int64_t n_ld, const int64_t *perm,
                    int64_t total_elems);
 
-/* Element counts to use in total_elems (row padding to an even leading dimension). */
+/* Element counts to use in total_elems (rows are padded to a multiple of 16 doubles = 128 B so
+ * that every 1-KiB wave load covers whole cache lines). */
 int64_t vilma_ld_dense_elems(int n);
 int64_t vilma_ld_lowrank_elems(int n, int r);
 

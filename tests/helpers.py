@@ -71,7 +71,7 @@ def engine_from_oracle(vi, ld, form='auto'):
 
 
 def oracle_totals(vi, params):
-    """The VILMA_NTOTALS(P) sums (include/vilma_hip.h) computed with the oracle."""
+    """The VILMA_NTOTALS(P) = 3P+2 sums (include/vilma_hip.h) computed with the oracle."""
     from oracle import numerics as nm
     vi_mu, vi_delta, hyper = params
     mean = vi._posterior_mean(vi_mu, vi_delta)
@@ -82,9 +82,9 @@ def oracle_totals(vi, params):
         (mean * vi.adj_marginal_effects).sum(axis=1),
         (vi.scaled_ld_diags * var).sum(axis=1),
         (linked * z).sum(axis=1),
-        [nm.fast_delta_kl(vi_delta, hyper, vi.annotations),
-         nm.fast_inner_product_comp(vi_mu, vi.mixture_prec, vi_delta),
-         nm.fast_beta_kl(vi.sigma_summary, vi_delta)]])
+        [nm.fast_delta_kl(vi_delta, hyper, vi.annotations)
+         + nm.fast_beta_kl(vi.sigma_summary, vi_delta),
+         nm.fast_inner_product_comp(vi_mu, vi.mixture_prec, vi_delta)]])
 
 
 def product_vi_from_traj(g, num_its=None, engine_factory=None, comm=None, form='auto'):

@@ -101,9 +101,8 @@ class OracleEngine:
         totals = np.concatenate([
             (mean * self.adj).sum(axis=1), (self.sld * var).sum(axis=1),
             (linked * z).sum(axis=1),
-            [nm.fast_delta_kl(delta, self.hyper, self.annot),
-             nm.fast_inner_product_comp(mu, self.prec[:, :, :, None], delta),
-             nm.fast_beta_kl(c['summary'], delta)]])
+            [nm.fast_delta_kl(delta, self.hyper, self.annot) + nm.fast_beta_kl(c['summary'], delta),
+             nm.fast_inner_product_comp(mu, self.prec[:, :, :, None], delta)]])
         return st, torch.as_tensor(totals)
 
     # ---- state

@@ -21,9 +21,10 @@ def test_header_symbols_are_exported():
 
 def test_sizes_helpers():
     lib = _lib.load()
-    assert lib.vilma_ld_dense_elems(5) == 5 * 6
-    assert lib.vilma_ld_lowrank_elems(5, 3) == 5 * 4 + 3 * 6
-    assert _lib.ntotals(2) == 9
+    assert lib.vilma_ld_dense_elems(5) == 5 * 16          # rows padded to 128 B
+    assert lib.vilma_ld_lowrank_elems(5, 3) == 5 * 16 + 3 * 16
+    assert lib.vilma_ld_dense_elems(588) == 588 * 592
+    assert _lib.ntotals(2) == 8
 
 
 def test_no_cpu_fallback_in_product():

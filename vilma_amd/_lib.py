@@ -17,7 +17,7 @@ class VilmaHipError(RuntimeError):
 
 
 def ntotals(P):
-    return 3 * P + 3
+    return 3 * P + 2
 
 
 NDIFF = 6

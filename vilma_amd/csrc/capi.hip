@@ -38,7 +38,9 @@ struct CohortLd {
     int n_solo_a = 0, n_solo_b = 0;
 };
 
-inline int even_up(int n) { return (n + 1) & ~1; }
+// leading dimensions are multiples of 16 doubles (128 B): each 128-column slab of a row then
+// starts on a cache-line boundary and no line is shared between two workgroups' slabs
+inline int pad_ld(int n) { return (n + 15) & ~15; }
 
 }  // namespace
 
@@ -120,7 +122,7 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
         if (b.form == 0) {
             for (int c0 = 0; c0 < b.n; c0 += 128) {
                 LdItem it;
-                it.a = co.store + b.off_a; it.rows = b.n; it.ld = even_up(b.n); it.col0 = c0;
+                it.a = co.store + b.off_a; it.rows = b.n; it.ld = pad_ld(b.n); it.col0 = c0;
                 it.ncols = b.n; it.x_off = pN + b.start; it.y_off = PN + pN + b.start;
                 it.dot_off = pN + b.start; it.dot_slot = slot++;
                 A.push_back(it);
@@ -128,14 +130,14 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
         } else {
             for (int c0 = 0; c0 < b.r; c0 += 128) {        // t = U^T x
                 LdItem it;
-                it.a = co.store + b.off_a; it.rows = b.n; it.ld = even_up(b.r); it.col0 = c0;
+                it.a = co.store + b.off_a; it.rows = b.n; it.ld = pad_ld(b.r); it.col0 = c0;
                 it.ncols = b.r; it.x_off = pN + b.start; it.y_off = 2 * PN + t_base + b.t_off;
                 it.dot_off = -1; it.dot_slot = -1;
                 A.push_back(it);
             }
             for (int c0 = 0; c0 < b.n; c0 += 128) {        // y = (diag(s) U^T)^T t
                 LdItem it;
-                it.a = co.store + b.off_v; it.rows = b.r; it.ld = even_up(b.n); it.col0 = c0;
+                it.a = co.store + b.off_v; it.rows = b.r; it.ld = pad_ld(b.n); it.col0 = c0;
                 it.ncols = b.n; it.x_off = 2 * PN + t_base + b.t_off; it.y_off = PN + pN + b.start;
                 it.dot_off = pN + b.start; it.dot_slot = slot++;
                 B.push_back(it);
@@ -319,8 +321,10 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         rc |= dev_alloc(c, &c->lse[s], N);
     }
     rc |= dev_alloc(c, &c->snapshot, PN);
-    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * P + 3));
-    rc |= dev_alloc(c, &c->delta_partials, (int64_t)delta_grid(N) * 4 * A * M);
+    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * P + 2));
+    // per-wave rows plus the scratch rows of the two-stage column reduction (<= rows/256 + 2)
+    rc |= dev_alloc(c, &c->delta_partials,
+                    ((int64_t)delta_grid(N) * 4 + delta_grid(N) / 64 + 8) * A * M);
     rc |= dev_alloc(c, &c->diff_partials, (int64_t)mean_diff_grid(PN) * 6);
     rc |= dev_alloc(c, &c->dot_start, P + 1);
     if (rc) {
@@ -393,9 +397,9 @@ int vilma_set_hyper(vilma_ctx *c, const double *hyper) {
     return 0;
 }
 
-int64_t vilma_ld_dense_elems(int n) { return (int64_t)n * even_up(n); }
+int64_t vilma_ld_dense_elems(int n) { return (int64_t)n * pad_ld(n); }
 int64_t vilma_ld_lowrank_elems(int n, int r) {
-    return (int64_t)n * even_up(r) + (int64_t)r * even_up(n);
+    return (int64_t)n * pad_ld(r) + (int64_t)r * pad_ld(n);
 }
 
 int vilma_ld_begin(vilma_ctx *c, int cohort, int n_blocks, int64_t n_ld, const int64_t *perm,
@@ -434,7 +438,7 @@ int vilma_ld_add_dense(vilma_ctx *c, int cohort, int n, const double *R) {
     const int64_t need = vilma_ld_dense_elems(n);
     if (co.store_used + need > co.store_elems) return fail(c, "LD store overflow (total_elems)");
     double *dst = co.store + co.store_used;
-    HIPCHK(c, hipMemcpy2D(dst, (size_t)even_up(n) * sizeof(double), R, (size_t)n * sizeof(double),
+    HIPCHK(c, hipMemcpy2D(dst, (size_t)pad_ld(n) * sizeof(double), R, (size_t)n * sizeof(double),
                           (size_t)n * sizeof(double), (size_t)n, hipMemcpyDefault));
     BlockRec b{0, n, n, co.store_used, 0, co.next_start, 0};
     co.blocks.push_back(b);
@@ -455,24 +459,24 @@ int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U
     const int64_t need = vilma_ld_lowrank_elems(n, r);
     if (co.store_used + need > co.store_elems) return fail(c, "LD store overflow (total_elems)");
     double *dU = co.store + co.store_used;
-    double *dV = dU + (int64_t)n * even_up(r);
-    HIPCHK(c, hipMemcpy2D(dU, (size_t)even_up(r) * sizeof(double), U, (size_t)r * sizeof(double),
+    double *dV = dU + (int64_t)n * pad_ld(r);
+    HIPCHK(c, hipMemcpy2D(dU, (size_t)pad_ld(r) * sizeof(double), U, (size_t)r * sizeof(double),
                           (size_t)r * sizeof(double), (size_t)n, hipMemcpyDefault));
     double *ds = nullptr;
     HIPCHK(c, hipMalloc((void **)&ds, (size_t)r * sizeof(double)));
     hipError_t e = hipMemcpy(ds, s, (size_t)r * sizeof(double), hipMemcpyDefault);
     if (e == hipSuccess) {
-        launch_scaled_transpose(dU, n, r, even_up(r), ds, dV, even_up(n), nullptr);
+        launch_scaled_transpose(dU, n, r, pad_ld(r), ds, dV, pad_ld(n), nullptr);
         e = hipDeviceSynchronize();
     }
     (void)hipFree(ds);
     if (e != hipSuccess) return fail(c, std::string("eigen-form upload: ") + hipGetErrorString(e));
-    BlockRec b{1, n, r, co.store_used, co.store_used + (int64_t)n * even_up(r), co.next_start,
+    BlockRec b{1, n, r, co.store_used, co.store_used + (int64_t)n * pad_ld(r), co.next_start,
                co.t_used};
     co.blocks.push_back(b);
     co.store_used += need;
     co.next_start += n;
-    co.t_used += even_up(r);
+    co.t_used += pad_ld(r);
     co.alg_bytes += (int64_t)8 * n * r;
     return 0;
 }

@@ -119,72 +119,75 @@ void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *do
 // --------------------------------------------------------------------------------------------
 // small SPD helpers, fully unrolled so everything stays in registers
 // --------------------------------------------------------------------------------------------
+// det(lam)^(-1/2) of a symmetric positive definite matrix
 template <int P>
-static __device__ __forceinline__ double spd_det(const double (&lam)[P][P]) {
+static __device__ __forceinline__ double spd_rsqrt_det(const double (&lam)[P][P]) {
     if constexpr (P == 1) {
-        return lam[0][0];
+        return rsqrt(lam[0][0]);
     } else if constexpr (P == 2) {
-        return lam[0][0] * lam[1][1] - lam[0][1] * lam[1][0];
+        return rsqrt(lam[0][0] * lam[1][1] - lam[0][1] * lam[1][0]);
     } else {
         double G[P][P];
-        double det = 1.0;
+        double w = 1.0;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             double s = lam[j][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= G[j][k] * G[j][k];
-            det *= s;
-            const double gjj = sqrt(s);
-            G[j][j] = gjj;
-            const double inv = 1.0 / gjj;
+            const double rj = rsqrt(s);
+            G[j][j] = s * rj;
+            w *= rj;
 #pragma unroll
             for (int i = j + 1; i < P; ++i) {
                 double t = lam[i][j];
 #pragma unroll
                 for (int k = 0; k < j; ++k) t -= G[i][k] * G[j][k];
-                G[i][j] = t * inv;
+                G[i][j] = t * rj;
             }
         }
-        return det;
+        return w;
     }
 }
 
-// sig = inverse(lam), returns det(lam); lam symmetric positive definite
+// sig = inverse(lam), returns det(lam)^(-1/2); lam symmetric positive definite
 template <int P>
 static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], double (&sig)[P][P]) {
     if constexpr (P == 1) {
-        sig[0][0] = 1.0 / lam[0][0];
-        return lam[0][0];
+        const double w = rsqrt(lam[0][0]);
+        sig[0][0] = w * w;
+        return w;
     } else if constexpr (P == 2) {
-        // closed form of the reference's 2x2 helper (numerics.py:223-232)
+        // closed form of the reference's 2x2 helper (numerics.py:223-232); 1/det = w^2
         const double det = lam[0][0] * lam[1][1] - lam[0][1] * lam[1][0];
-        const double r = 1.0 / det;
+        const double w = rsqrt(det);
+        const double r = w * w;
         sig[0][0] = lam[1][1] * r;
         sig[1][1] = lam[0][0] * r;
         sig[0][1] = -lam[1][0] * r;
         sig[1][0] = sig[0][1];
-        return det;
+        return w;
     } else {
+        // Cholesky lam = G G^T; Gi = G^-1 (its diagonal entries are 1/G_jj, so det^-1/2 is
+        // their product); sig = Gi^T Gi
         double G[P][P], Gi[P][P];
-        double det = 1.0;
+        double w = 1.0;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             double s = lam[j][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= G[j][k] * G[j][k];
-            det *= s;
-            const double gjj = sqrt(s);
-            G[j][j] = gjj;
-            Gi[j][j] = 1.0 / gjj;
+            const double rj = rsqrt(s);
+            G[j][j] = s * rj;
+            Gi[j][j] = rj;
+            w *= rj;
 #pragma unroll
             for (int i = j + 1; i < P; ++i) {
                 double t = lam[i][j];
 #pragma unroll
                 for (int k = 0; k < j; ++k) t -= G[i][k] * G[j][k];
-                G[i][j] = t * Gi[j][j];
+                G[i][j] = t * rj;
             }
         }
-        // Gi = inverse of lower-triangular G
 #pragma unroll
         for (int j = 0; j < P; ++j) {
 #pragma unroll
@@ -206,7 +209,7 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
                 sig[b][a] = t;
             }
         }
-        return det;
+        return w;
     }
 }
 
@@ -218,7 +221,7 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 
 template <int P, bool BLEND, bool ONE_ANNOT>
 __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
-    constexpr int NT = 2 * P + 3;
+    constexpr int NT = 2 * P + 2;
     __shared__ double red[SNP_THREADS / 64][NT];
     const int N = a.N, M = a.M;
     const int64_t N64 = N;
@@ -248,13 +251,17 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
     const double step = a.step;
 
-    double mx = NEG_INF, Z = 0.0, Sdk = 0.0, Sip = 0.0, Sbk = 0.0;
+    // Responsibilities delta_k ~ exp(u_k), u_k = 0.5 (quad_k - log det Lam_k) + lh_k, are
+    // accumulated as w_k exp(a_k - max a) with a_k = 0.5 quad_k + lh_k and w_k = det^-1/2: an
+    // rsqrt instead of a log per (component, SNP).  In the KL terms the log-determinants of
+    // fast_delta_kl and fast_beta_kl cancel, so their sum needs only quad_k and tr(Prec_k Sig_k).
+    double mx = NEG_INF, Z = 0.0, Skl = 0.0, Sip = 0.0;
     double Sm[P], S2[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) { Sm[p] = 0.0; S2[p] = 0.0; }
 
     for (int k0 = 0; k0 < M; k0 += KC) {
-        double u[KC], wk[KC], ipk[KC], ssk[KC], mun[KC][P], sdg[KC][P];
+        double av[KC], wv[KC], klk[KC], ipk[KC], mun[KC][P], sdg[KC][P];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
             const int k = k0 + kk;
@@ -268,8 +275,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                     lam[p][p] += d[p];
                     mu[p] = a.mu_in[((int64_t)k * P + p) * N64 + ii];
                 }
-                const double det = spd_inverse<P>(lam, sig);
-                const double logdet = log(det);
+                wv[kk] = spd_inverse<P>(lam, sig);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     double t = 0.0;
@@ -299,33 +305,30 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                         ip += mun[kk][p] * mun[kk][q] * pr[q][p];
                         tr += pr[p][q] * sig[q][p];
                     }
-                const double ldk = a.log_det[k];
-                u[kk] = 0.5 * (quad - logdet) + lh[k];
-                wk[kk] = 0.5 * (quad - logdet - ldk);
-                ssk[kk] = ldk + logdet + tr;
+                av[kk] = 0.5 * quad + lh[k];
+                klk[kk] = 0.5 * (quad + tr);
                 ipk[kk] = ip;
             } else {
-                u[kk] = NEG_INF; wk[kk] = 0.0; ssk[kk] = 0.0; ipk[kk] = 0.0;
+                av[kk] = NEG_INF; wv[kk] = 0.0; klk[kk] = 0.0; ipk[kk] = 0.0;
 #pragma unroll
                 for (int p = 0; p < P; ++p) { mun[kk][p] = 0.0; sdg[kk][p] = 0.0; }
             }
         }
-        double cmax = u[0];
+        double cmax = av[0];
 #pragma unroll
-        for (int kk = 1; kk < KC; ++kk) cmax = fmax(cmax, u[kk]);
+        for (int kk = 1; kk < KC; ++kk) cmax = fmax(cmax, av[kk]);
         const double nmx = fmax(mx, cmax);
         const double sc = exp(mx - nmx);
         mx = nmx;
-        Z *= sc; Sdk *= sc; Sip *= sc; Sbk *= sc;
+        Z *= sc; Skl *= sc; Sip *= sc;
 #pragma unroll
         for (int p = 0; p < P; ++p) { Sm[p] *= sc; S2[p] *= sc; }
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-            const double e = exp(u[kk] - mx);
+            const double e = wv[kk] * exp(av[kk] - mx);
             Z += e;
-            Sdk = fma(e, wk[kk], Sdk);
+            Skl = fma(e, klk[kk], Skl);
             Sip = fma(e, ipk[kk], Sip);
-            Sbk = fma(e, ssk[kk], Sbk);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 Sm[p] = fma(e, mun[kk][p], Sm[p]);
@@ -349,9 +352,8 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
         part[P + p] = live ? sld[p] * v : 0.0;
     }
     if (live) a.lse_out[i] = lse;
-    part[2 * P] = live ? (Sdk * invZ - lse) : 0.0;
+    part[2 * P] = live ? (Skl * invZ - lse) : 0.0;
     part[2 * P + 1] = live ? 0.5 * Sip * invZ : 0.0;
-    part[2 * P + 2] = live ? 0.5 * Sbk * invZ : 0.0;
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
             lam[p][p] += d[p];
             mu[p] = a.mu[((int64_t)k * P + p) * N64 + ii];
         }
-        const double logdet = log(spd_det<P>(lam));
+        const double wdet = spd_rsqrt_det<P>(lam);
         double quad = 0.0;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -431,8 +433,7 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
             for (int q = 0; q < P; ++q) t += lam[p][q] * mu[q];
             quad += mu[p] * t;
         }
-        const double u = 0.5 * (quad - logdet) + lh[k];
-        const double delta = fmax(exp(u - lse), 1e-100);
+        const double delta = fmax(wdet * exp(0.5 * quad + lh[k] - lse), 1e-100);
         if (WRITE) {
             if (live) a.out[(int64_t)k * N64 + i] = delta;
         } else if (ONE_ANNOT) {
@@ -449,25 +450,47 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
 
 int delta_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
 
-// out[c] = sum over rows of partials[r][c]; lanes along columns, 16 waves over interleaved rows,
-// fixed combination order
-__global__ __launch_bounds__(1024) void reduce_cols_kernel(const double *__restrict__ partials,
-                                                            int rows, int ncols,
-                                                            double *__restrict__ out) {
-    __shared__ double red[16][64];
+// out[chunk][c] = sum over the chunk's rows of in[r][c]: lanes along columns, the 4 waves take
+// interleaved rows with 4 independent accumulators each, fixed combination order.  Launched
+// twice (rows -> RC_CHUNKS partial rows -> 1 row) so the long reduction is spread over the chip.
+#define RC_CHUNK_ROWS 256
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const double *__restrict__ in, int rows,
+                                                           int ncols, double *__restrict__ out) {
+    __shared__ double red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    double s = 0.0;
-    if (c < ncols)
-        for (int r = w; r < rows; r += 16) s += partials[(int64_t)r * ncols + c];
-    red[w][lane] = s;
-    __syncthreads();
-    if (w == 0 && c < ncols) {
-        double t = red[0][lane];
-#pragma unroll
-        for (int ww = 1; ww < 16; ++ww) t += red[ww][lane];
-        out[c] = t;
+    const int r0 = blockIdx.y * RC_CHUNK_ROWS;
+    const int r1 = min(rows, r0 + RC_CHUNK_ROWS);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < ncols) {
+        int r = r0 + w;
+        for (; r + 12 < r1; r += 16) {
+            s0 += in[(int64_t)r * ncols + c];
+            s1 += in[(int64_t)(r + 4) * ncols + c];
+            s2 += in[(int64_t)(r + 8) * ncols + c];
+            s3 += in[(int64_t)(r + 12) * ncols + c];
+        }
+        for (; r < r1; r += 4) s0 += in[(int64_t)r * ncols + c];
     }
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && c < ncols)
+        out[(int64_t)blockIdx.y * ncols + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+static void reduce_cols(const double *in, int rows, int ncols, double *scratch, double *out,
+                        hipStream_t s) {
+    // scratch must hold ceil(rows / RC_CHUNK_ROWS) * ncols doubles
+    const int colblocks = (ncols + 63) / 64;
+    while (rows > RC_CHUNK_ROWS) {
+        const int chunks = (rows + RC_CHUNK_ROWS - 1) / RC_CHUNK_ROWS;
+        hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, chunks), dim3(256), 0, s, in, rows,
+                           ncols, scratch);
+        in = scratch;
+        scratch = scratch + (int64_t)chunks * ncols;
+        rows = chunks;
+    }
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, 1), dim3(256), 0, s, in, rows, ncols, out);
 }
 
 template <int P, bool WRITE>
@@ -492,8 +515,7 @@ void launch_delta_sums(const DeltaArgs &a, double *sums_out, hipStream_t s) {
     launch_delta_any<false>(a, s);
     const int ncols = a.A * a.M;
     const int rows = delta_grid(a.N) * (SNP_THREADS / 64);
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, s, a.out, rows,
-                       ncols, sums_out);
+    reduce_cols(a.out, rows, ncols, a.out + (int64_t)rows * ncols, sums_out, s);
 }
 
 void launch_delta_write(const DeltaArgs &a, hipStream_t s) { launch_delta_any<true>(a, s); }
@@ -530,7 +552,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict
                                                          const int32_t *__restrict__ dot_start,
                                                          double *__restrict__ totals) {
     __shared__ double sh[16];
-    const int NT = 2 * P + 3;
+    const int NT = 2 * P + 2;
     for (int c = 0; c < NT; ++c) {
         double s = 0.0;
         for (int r = threadIdx.x; r < snp_rows; r += 1024) s += snp_partials[(int64_t)r * NT + c];

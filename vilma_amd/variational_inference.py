@@ -8,7 +8,7 @@ where the work happens:
   * the outer loop, the line search on L and every accept/reject decision stay on the host
     (variational_inference.py:340-450, 762-802) and are reproduced decision for decision;
   * every objective evaluation is ONE fused per-SNP kernel + ONE block-diagonal LD product per
-    cohort + a fixed-order reduction on the GPU (libvilma_hip.so), returning the 3P+3 sums of
+    cohort + a fixed-order reduction on the GPU (libvilma_hip.so), returning the 3P+2 sums of
     include/vilma_hip.h from which the host assembles the objective;
   * state lives in HBM: vi_mu only.  vi_delta is a pure function of (vi_mu, hyper_delta,
     error_scaling) (_nat_to_not_vi_delta, variational_inference.py:632-641) and is
@@ -188,7 +188,7 @@ class SweepDriver:
         tau = self.error_scaling
         lik = (-0.5 * (var + quad) + lin - 0.5 * self.chi_stat) / tau \
             - 0.5 * self.ld_ranks * np.log(tau)
-        return float(lik.sum() - (t[3 * P] + t[3 * P + 1] + t[3 * P + 2]))
+        return float(lik.sum() - (t[3 * P] + t[3 * P + 1]))
 
     def _evaluate(self, step=None):
         """Objective of a candidate point: the current vi_mu (step None) or a natural-gradient
