@@ -162,8 +162,11 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = engine.prof_read(reset=True)
+    prof = engine.prof_read(reset=True)
     engine.prof_enable(False)
+    # the dominant kernel = the LD-streaming kernel with the most accumulated time
+    dom = max(('ld_sym_kernel', 'ld_colsum_kernel'), key=lambda k: prof[k][0])
+    kernel_ms, launches = prof[dom]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -179,7 +182,7 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('ld_colsum_kernel_bytes_per_launch')
+            traffic = json.load(open(tpath)).get(dom + '_bytes_per_launch')
         except Exception:
             traffic = None
 
@@ -204,10 +207,12 @@ def main():
             'setup_seconds': setup_s,
         },
         'roofline': {
-            'bound': 'hbm', 'kernel': 'ld_colsum_kernel', 'achieved': achieved,
+            'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'algorithmic_bytes_per_launch': alg_launch,
             'avg_launch_ms': avg_ms, 'launches': int(launches),
+            'stored_bytes_per_launch': float(engine.ld_bytes()[1]),
+            'other_ld_kernels_ms': {k: v[0] / max(v[1], 1) for k, v in prof.items() if k != dom and v[1]},
             'sweep_algorithmic_GBps': (n_eval * (alg_launch + state_bytes)) / elapsed / 1e9,
         },
     }

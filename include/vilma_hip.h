@@ -80,6 +80,10 @@ int vilma_set_tau(vilma_ctx *ctx, const double *tau);
  * (numerics.py:149-164, variational_inference.py:844-848) as an [A,M] table on device. */
 int vilma_set_hyper(vilma_ctx *ctx, const double *hyper);
 
+/* annotation_counts [A] = number of SNPs (of the WHOLE problem, not the shard) per annotation
+ * (variational_inference.py:218); used by vilma_mstep. */
+int vilma_set_annotation_counts(vilma_ctx *ctx, const double *counts);
+
 /* ---- LD operator: BlockDiagonalMatrix (matrix_structures.py:237-447) -------------------- */
 
 /* Start cohort `cohort`.  perm [N] int64: perm[t] = SNP index at LD position t; the first
@@ -90,11 +94,12 @@ int vilma_ld_begin(vilma_ctx *ctx, int cohort, int n_blocks, int64_t n_ld, const
                    int64_t total_elems);
 
 /* Element counts to use in total_elems (rows are padded to a multiple of 16 doubles = 128 B so
- * that every 1-KiB wave load covers whole cache lines). */
+ * that every 1-KiB wave load covers whole cache lines; dense blocks keep the lower triangle). */
 int64_t vilma_ld_dense_elems(int n);
 int64_t vilma_ld_lowrank_elems(int n, int r);
 
-/* Add the next block as a dense symmetric n x n matrix R (row-major, host or device).  For the
+/* Add the next block as a dense SYMMETRIC n x n matrix R (row-major, host or device).  Only its
+ * lower triangle is stored (by 128-column slabs) and read -- once -- per product.  For the
  * reference's blocks R must be the reconstruction U diag(s) U^T of the kept eigenpairs
  * (LowRankMatrix, matrix_structures.py:95-152), NOT the raw .npy matrix. */
 int vilma_ld_add_dense(vilma_ctx *ctx, int cohort, int n, const double *R);
@@ -113,7 +118,8 @@ int vilma_ld_matvec(vilma_ctx *ctx, void *stream, int cohort, const double *x, d
 
 /* Algorithmic bytes one vilma_eval/vilma_trial_beta streams from the LD store (all cohorts):
  * 8 * sum_b n_b^2 (dense) or 8 * sum_b n_b r_b (eigen form, U counted once) -- SURVEY.md 8(d).
- * stored_bytes = bytes actually resident (eigen form stores U and diag(s)U^T). */
+ * stored_bytes = bytes actually resident and streamed per product (dense symmetric blocks keep
+ * ~n^2/2 + 64 n elements; eigen form stores U and diag(s)U^T). */
 int vilma_ld_bytes(const vilma_ctx *ctx, int64_t *algorithmic_bytes, int64_t *stored_bytes);
 
 /* ---- variational state ---------------------------------------------------------------- */
@@ -152,6 +158,12 @@ int vilma_accept(vilma_ctx *ctx, int take_mu);
  * M-step statistic and the payload of the cross-GPU all-reduce. */
 int vilma_delta_sums(vilma_ctx *ctx, void *stream, double *sums_dev);
 
+/* The M-step of _update_hyper_delta on the device, without a host round trip: from the
+ * (all-reduced) sums_dev [A*M] of vilma_delta_sums compute
+ * hyper = normalise(max(sums / (annotation_counts + 1e-100), 1e-100)) (variational_inference.py:
+ * 837-842), install it exactly as vilma_set_hyper would, and write it to hyper_dev [A*M]. */
+int vilma_mstep(vilma_ctx *ctx, void *stream, const double *sums_dev, double *hyper_dev);
+
 /* Convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
  * between the current state and the snapshot taken by the previous call (or by
  * vilma_snapshot_mean): out_dev[0] = #entries violating |new-old| <= 1e-6 + 1e-6|old|,
@@ -160,11 +172,19 @@ int vilma_delta_sums(vilma_ctx *ctx, void *stream, double *sums_dev);
 int vilma_mean_diff(vilma_ctx *ctx, void *stream, double *out_dev);
 int vilma_snapshot_mean(vilma_ctx *ctx, void *stream);
 
+/* Copy n doubles of a device result buffer to the host behind everything queued on `stream`
+ * (pinned staging + stream synchronise): the one blocking point of a decision. */
+int vilma_fetch(vilma_ctx *ctx, void *stream, const double *src_dev, double *dst_host, int64_t n);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 
-/* When enabled, every LD-matvec kernel launch is bracketed by HIP events on its stream.
- * vilma_prof_read synchronises the device and returns accumulated kernel milliseconds and the
- * number of launches since the last reset. */
+/* When enabled, every LD-product kernel launch is bracketed by HIP events on its stream.
+ * vilma_prof_read synchronises the device and returns, per kernel kind, the accumulated kernel
+ * milliseconds and number of launches since the last reset (arrays of VILMA_PROF_KINDS). */
+#define VILMA_PROF_LD_SYM 0      /* ld_sym_kernel: symmetric dense blocks, lower triangle read once */
+#define VILMA_PROF_LD_COLSUM 1   /* ld_colsum_kernel: both passes of eigen-form blocks */
+#define VILMA_PROF_LD_COMBINE 2  /* ld_sym_combine_kernel */
+#define VILMA_PROF_KINDS 3
 int vilma_prof_enable(vilma_ctx *ctx, int enable);
 int vilma_prof_read(vilma_ctx *ctx, double *ms_total, int64_t *launches, int reset);
 

@@ -14,7 +14,7 @@ import sys
 
 import pandas as pd
 
-OURS = ('ld_colsum_kernel', 'snp_pass_kernel', 'delta_kernel', 'reduce_cols_kernel',
+OURS = ("ld_sym_combine_kernel", "ld_sym_kernel", "ld_colsum_kernel", 'snp_pass_kernel', 'delta_kernel', 'reduce_cols_kernel',
         'finalize_kernel', 'mean_diff', 'gather_x_kernel', 'scatter_y_kernel')
 
 
@@ -45,10 +45,10 @@ def main():
                       'min_us': float(grp.us.min()), 'max_us': float(grp.us.max()),
                       'total_ms': float(grp.us.sum() / 1e3)}
         # the dominant kernel's launches split by size: the big launches are the full LD product
-        ld = df[df.k == 'ld_colsum_kernel']
+        ld = df[df.k == 'ld_sym_kernel']
         if len(ld):
             big = ld[ld.us > 0.5 * ld.us.max()]
-            out['ld_colsum_kernel_full_product'] = {'calls': int(len(big)),
+            out['ld_sym_kernel_full_product'] = {'calls': int(len(big)),
                                                     'avg_us': float(big.us.mean())}
         json.dump(out, open(prefix + '_vilma_kernels.json', 'w'), indent=1)
     for f in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):

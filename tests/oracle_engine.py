@@ -35,6 +35,13 @@ class OracleEngine:
         self.mu_trial = None
         self.snap = None
         self._c = None
+        self.n_totals = 3 * P + 2
+        am = A * M
+        self.results = torch.zeros(self.n_totals + 6 + 2 * am, dtype=torch.float64)
+        self._totals = self.results[:self.n_totals]
+        self._diff = self.results[self.n_totals:self.n_totals + 6]
+        self._hyper_t = self.results[self.n_totals + 6:self.n_totals + 6 + am]
+        self._sums = self.results[self.n_totals + 6 + am:]
 
     # ---- static data
     def set_snp_data(self, adj, se, sld, scalings, annot):
@@ -53,6 +60,18 @@ class OracleEngine:
 
     def set_hyper(self, hyper):
         self.hyper = np.array(hyper).reshape(self.A, self.M)
+
+    def set_annotation_counts(self, counts):
+        self.counts = np.array(counts, dtype=float)
+
+    def mstep(self, sums=None):
+        sums = self._sums if sums is None else sums
+        h = np.maximum(sums.numpy().reshape(self.A, self.M)
+                       / (self.counts.reshape((-1, 1)) + 1e-100), 1e-100)
+        h /= h.sum(axis=1, keepdims=True)
+        self.hyper = h
+        self._hyper_t.copy_(torch.as_tensor(h.ravel()))
+        return self._hyper_t
 
     def load_ld(self, cohort, blocks, perm, n_ld):
         perm = np.asarray(perm)
@@ -103,7 +122,8 @@ class OracleEngine:
             (linked * z).sum(axis=1),
             [nm.fast_delta_kl(delta, self.hyper, self.annot) + nm.fast_beta_kl(c['summary'], delta),
              nm.fast_inner_product_comp(mu, self.prec[:, :, :, None], delta)]])
-        return st, torch.as_tensor(totals)
+        self._totals.copy_(torch.as_tensor(totals))
+        return st, self._totals
 
     # ---- state
     def set_mu(self, vi_mu):
@@ -143,7 +163,9 @@ class OracleEngine:
         self.cur = self.trial_state
 
     def delta_sums(self):
-        return torch.as_tensor(nm.sum_annotations(self.cur['delta'], self.annot, self.A).ravel())
+        self._sums.copy_(torch.as_tensor(nm.sum_annotations(self.cur['delta'], self.annot,
+                                                            self.A).ravel()))
+        return self._sums
 
     def snapshot_mean(self):
         self.snap = self.cur['mean'] * self.scal
@@ -156,7 +178,11 @@ class OracleEngine:
                         np.abs(new).max(), df.max(), np.abs((new - old) / (old + 1e-100)).max()],
                        dtype=float)
         self.snap = new
-        return torch.as_tensor(out)
+        self._diff.copy_(torch.as_tensor(out))
+        return self._diff
+
+    def fetch(self, n):
+        return self.results[:n].numpy().copy()
 
     def close(self):
         pass

@@ -132,3 +132,69 @@ def test_errors_are_loud():
     with pytest.raises(_lib.VilmaHipError):
         eng.load_ld(0, [('dense', np.eye(4))], np.array([0, 1, 2, 3, 3, 5, 6, 7, 8, 9]), 4)
     eng.close()
+
+
+@pytest.mark.parametrize('sizes', [[1, 2, 3], [127, 128, 129], [255, 256, 257], [300, 64, 700],
+                                   [1000, 17]])
+def test_ld_matvec_block_sizes(sizes):
+    """The symmetric (lower-triangle) dense kernel and the eigen-form kernel across slab
+    boundaries: block sizes around multiples of 128, odd sizes, ragged mixes, perm + missing."""
+    from vilma_amd.engine import HipEngine
+    rng = np.random.default_rng(sum(sizes))
+    n_ld = sum(sizes)
+    N = n_ld + 7
+    perm = rng.permutation(N).astype(np.int64)
+    mats, eigs = [], []
+    for n in sizes:
+        r = max(1, n // 3)
+        U = np.linalg.qr(rng.normal(size=(n, r)))[0]
+        s = rng.uniform(0.1, 2.0, size=r)
+        mats.append((U * s) @ U.T + np.diag(rng.uniform(0.1, 1.0, size=n)))   # full-rank SPD
+        eigs.append((U, s))
+    x = rng.normal(size=(2, N))
+    eng = HipEngine(2, N, 3, 1)
+    eng.load_ld(0, [('dense', R) for R in mats], perm, n_ld)
+    eng.load_ld(1, [('eig', U, s) for U, s in eigs], perm, n_ld)
+    got = eng.ld_matvec(x)
+    want = np.zeros((2, N))
+    lo = 0
+    for n, R, (U, s) in zip(sizes, mats, eigs):
+        idx = perm[lo:lo + n]
+        want[0, idx] = R @ x[0, idx]
+        want[1, idx] = U @ (s * (U.T @ x[1, idx]))
+        lo += n
+    _close(got, want, rtol=1e-11, atol=1e-11)
+    assert np.all(got[:, perm[n_ld:]] == 0.0)
+    # symmetry property of the operator: x^T (R y) == y^T (R x)
+    y = rng.normal(size=(2, N))
+    ry = eng.ld_matvec(y)
+    _close((x * ry).sum(axis=1), (y * got).sum(axis=1), rtol=1e-10)
+    alg, stored = eng.ld_bytes()
+    assert alg == 8 * sum(n * n + n * max(1, n // 3) for n in sizes)
+    eng.close()
+
+
+def test_device_mstep_matches_host_formula():
+    """vilma_mstep == the M-step of _update_hyper_delta (variational_inference.py:832-848)."""
+    from oracle import numerics as nm
+    g = golden('traj_p2_scale_se.npz')            # A = 2 annotations
+    vi, ld = oracle_from_traj(g)
+    eng = engine_from_oracle(vi, ld)
+    eng.set_annotation_counts(vi.annotation_counts)
+    np.random.seed(int(g['seed']))
+    vi_mu, vi_delta, hyper = vi._initialize()
+    eng.set_hyper(hyper)
+    eng.set_mu(vi_mu)
+    eng.eval(); eng.accept(False)
+    sums = eng.delta_sums()
+    hyper_dev = eng.mstep(sums).cpu().numpy().reshape(vi.num_annotations, vi.num_mix)
+    want = nm.sum_annotations(vi_delta, vi.annotations, vi.num_annotations)
+    want = np.maximum(want / (vi.annotation_counts.reshape((-1, 1)) + 1e-100), 1e-100)
+    want /= want.sum(axis=1, keepdims=True)
+    _close(hyper_dev, want, rtol=1e-12, atol=1e-300)
+    # the table installed by mstep is the one set_hyper(want) would install
+    t1 = eng.eval().cpu().numpy().copy()
+    eng.set_hyper(want)
+    t2 = eng.eval().cpu().numpy().copy()
+    _close(t1, t2, rtol=1e-12, atol=1e-10)
+    eng.close()

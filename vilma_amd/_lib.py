@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvilma_hip.so')
+# VILMA_HIP_LIB selects an alternative build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get('VILMA_HIP_LIB') or os.path.join(_HERE, 'libvilma_hip.so')
 
 _lib = None
 
@@ -48,6 +49,8 @@ def load():
         'vilma_set_mixture': (C.c_int, [vp, vp, vp]),
         'vilma_set_tau': (C.c_int, [vp, vp]),
         'vilma_set_hyper': (C.c_int, [vp, vp]),
+        'vilma_set_annotation_counts': (C.c_int, [vp, vp]),
+        'vilma_mstep': (C.c_int, [vp, vp, vp, vp]),
         'vilma_ld_begin': (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, vp, C.c_int64]),
         'vilma_ld_dense_elems': (C.c_int64, [C.c_int]),
         'vilma_ld_lowrank_elems': (C.c_int64, [C.c_int, C.c_int]),
@@ -66,6 +69,7 @@ def load():
         'vilma_delta_sums': (C.c_int, [vp, vp, vp]),
         'vilma_mean_diff': (C.c_int, [vp, vp, vp]),
         'vilma_snapshot_mean': (C.c_int, [vp, vp]),
+        'vilma_fetch': (C.c_int, [vp, vp, vp, vp, C.c_int64]),
         'vilma_prof_enable': (C.c_int, [vp, C.c_int]),
         'vilma_prof_read': (C.c_int, [vp, _c_double_p, _c_i64_p, C.c_int]),
     }

@@ -25,17 +25,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
-    """hipcc --offload-arch=gfx950 -O3 -shared; cross-compiles without a GPU."""
-    if not force and not needs_build():
+def build_library(force=False, verbose=True, extra_flags=(), out=None):
+    """hipcc --offload-arch=gfx950 -O3 -shared; cross-compiles without a GPU.  `extra_flags` /
+    `out` build a variant next to the default library (see VILMA_HIP_LIB in _lib.py)."""
+    if out is None and not force and not needs_build():
         return LIB
     cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-ffp-contract=on', '-Wall', '-Wno-unused-function',
-           '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           '-ffp-contract=on', '-Wall', '-Wno-unused-function'] + list(extra_flags) + [
+           '-o', out or LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == '__main__':

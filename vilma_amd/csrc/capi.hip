@@ -34,13 +34,29 @@ struct CohortLd {
     int32_t next_start = 0, t_used = 0;
     std::vector<BlockRec> blocks;
     int64_t alg_bytes = 0;
-    LdItem *solo_a = nullptr, *solo_b = nullptr;   // per-cohort item lists (vilma_ld_matvec)
-    int n_solo_a = 0, n_solo_b = 0;
+    int32_t s_used = 0;                            // scratch entries of the symmetric product
 };
+
+// device-resident work lists of one LD product (all cohorts, or one cohort)
+struct ItemSet {
+    SymItem *sym = nullptr;
+    SymCombItem *comb = nullptr;
+    LdItem *a = nullptr, *b = nullptr;
+    int n_sym = 0, n_comb = 0, n_a = 0, n_b = 0;
+};
+
+// number of doubles a dense block occupies: per 128-column slab J the panel of rows >= 128 J
+inline int64_t sym_panel_elems(int n, int J);
+
 
 // leading dimensions are multiples of 16 doubles (128 B): each 128-column slab of a row then
 // starts on a cache-line boundary and no line is shared between two workgroups' slabs
 inline int pad_ld(int n) { return (n + 15) & ~15; }
+inline int slab_width(int n, int J) { return std::min(128, n - 128 * J); }
+inline int64_t sym_panel_elems(int n, int J) {
+    return (int64_t)(n - 128 * J) * pad_ld(slab_width(n, J));
+}
+inline int n_slabs(int n) { return (n + 127) / 128; }
 
 }  // namespace
 
@@ -51,7 +67,7 @@ struct vilma_ctx {
 
     double *adj = nullptr, *se = nullptr, *sld = nullptr, *scal = nullptr;
     int32_t *annot = nullptr, *invperm = nullptr;
-    double *prec = nullptr, *log_det = nullptr, *lh = nullptr;
+    double *prec = nullptr, *log_det = nullptr, *lh = nullptr, *counts = nullptr;
     std::vector<double> log_det_host;
     double tau[VILMA_MAX_P];
 
@@ -68,14 +84,18 @@ struct vilma_ctx {
     int32_t *dot_start = nullptr;
 
     std::vector<CohortLd> ld;
-    LdItem *items_a = nullptr, *items_b = nullptr;
-    int n_a = 0, n_b = 0;
+    ItemSet all;
+    std::vector<ItemSet> solo;      // per cohort (vilma_ld_matvec with cohort >= 0)
+    double *sym_scratch = nullptr;
+    double *pinned = nullptr;       // host staging for vilma_fetch
+    int64_t pinned_elems = 0;
     bool ready = false;
 
     bool prof = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    double prof_ms = 0.0;
-    int64_t prof_launches = 0;
+    struct Pending { hipEvent_t e0, e1; int kind; };
+    std::vector<Pending> pending;
+    double prof_ms[VILMA_PROF_KINDS] = {0, 0, 0};
+    int64_t prof_launches[VILMA_PROF_KINDS] = {0, 0, 0};
 };
 
 namespace {
@@ -102,65 +122,97 @@ int dev_alloc(vilma_ctx *c, T **p, int64_t count, bool zero = true) {
 
 void dev_free(void *p) { if (p) (void)hipFree(p); }
 
+void free_items(ItemSet &it) {
+    dev_free(it.sym); dev_free(it.comb); dev_free(it.a); dev_free(it.b);
+    it = ItemSet();
+}
+
 void free_ready(vilma_ctx *c) {
     for (int s = 0; s < 2; ++s) { dev_free(c->pool[s]); c->pool[s] = nullptr; }
-    dev_free(c->items_a); dev_free(c->items_b); dev_free(c->dot_partials);
-    c->items_a = c->items_b = nullptr; c->dot_partials = nullptr;
-    c->n_a = c->n_b = 0;
-    for (auto &co : c->ld) {
-        dev_free(co.solo_a); dev_free(co.solo_b);
-        co.solo_a = co.solo_b = nullptr; co.n_solo_a = co.n_solo_b = 0;
-    }
+    dev_free(c->dot_partials); c->dot_partials = nullptr;
+    dev_free(c->sym_scratch); c->sym_scratch = nullptr;
+    free_items(c->all);
+    for (auto &it : c->solo) free_items(it);
+    c->solo.clear();
     c->ready = false;
     c->have_moments = false;
 }
 
-void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, int32_t &slot,
-                std::vector<LdItem> &A, std::vector<LdItem> &B) {
+struct HostItems {
+    std::vector<SymItem> sym;
+    std::vector<SymCombItem> comb;
+    std::vector<LdItem> a, b;
+};
+
+void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, int32_t s_base,
+                int32_t &slot, HostItems &H) {
     const int32_t PN = (int32_t)(c->P * c->N), pN = (int32_t)(p * c->N);
+    int32_t s_off = s_base;
     for (const BlockRec &b : co.blocks) {
         if (b.form == 0) {
-            for (int c0 = 0; c0 < b.n; c0 += 128) {
-                LdItem it;
-                it.a = co.store + b.off_a; it.rows = b.n; it.ld = pad_ld(b.n); it.col0 = c0;
-                it.ncols = b.n; it.x_off = pN + b.start; it.y_off = PN + pN + b.start;
-                it.dot_off = pN + b.start; it.dot_slot = slot++;
-                A.push_back(it);
+            int64_t off = b.off_a;
+            const int ns = n_slabs(b.n);
+            for (int J = 0; J < ns; ++J) {
+                SymItem it;
+                it.a = co.store + off; it.rows = b.n - 128 * J; it.w = slab_width(b.n, J);
+                it.ld = pad_ld(it.w); it.j0 = 128 * J; it.x_off = pN + b.start;
+                it.s_off = s_off + J * b.n; it.n = b.n; it.pad = 0;
+                H.sym.push_back(it);
+                SymCombItem cb;
+                cb.n = b.n; cb.j0 = 128 * J; cb.w = it.w; cb.slab = J; cb.s_base = s_off;
+                cb.y_off = PN + pN + b.start; cb.dot_off = pN + b.start; cb.dot_slot = slot++;
+                H.comb.push_back(cb);
+                off += sym_panel_elems(b.n, J);
             }
+            s_off += ns * b.n;
         } else {
             for (int c0 = 0; c0 < b.r; c0 += 128) {        // t = U^T x
                 LdItem it;
                 it.a = co.store + b.off_a; it.rows = b.n; it.ld = pad_ld(b.r); it.col0 = c0;
                 it.ncols = b.r; it.x_off = pN + b.start; it.y_off = 2 * PN + t_base + b.t_off;
                 it.dot_off = -1; it.dot_slot = -1;
-                A.push_back(it);
+                H.a.push_back(it);
             }
             for (int c0 = 0; c0 < b.n; c0 += 128) {        // y = (diag(s) U^T)^T t
                 LdItem it;
                 it.a = co.store + b.off_v; it.rows = b.r; it.ld = pad_ld(b.n); it.col0 = c0;
                 it.ncols = b.n; it.x_off = 2 * PN + t_base + b.t_off; it.y_off = PN + pN + b.start;
                 it.dot_off = pN + b.start; it.dot_slot = slot++;
-                B.push_back(it);
+                H.b.push_back(it);
             }
         }
     }
 }
 
-void sort_items(std::vector<LdItem> &v) {
-    // longest first: workgroup run time ~ rows * slab width
-    std::stable_sort(v.begin(), v.end(), [](const LdItem &x, const LdItem &y) {
-        const int64_t cx = (int64_t)x.rows * std::min(128, x.ncols - x.col0);
-        const int64_t cy = (int64_t)y.rows * std::min(128, y.ncols - y.col0);
-        return cx > cy;
+void sort_items(HostItems &H) {
+    // longest first: workgroup run time ~ rows streamed
+    std::stable_sort(H.a.begin(), H.a.end(), [](const LdItem &x, const LdItem &y) {
+        return (int64_t)x.rows * std::min(128, x.ncols - x.col0) >
+               (int64_t)y.rows * std::min(128, y.ncols - y.col0);
+    });
+    std::stable_sort(H.b.begin(), H.b.end(), [](const LdItem &x, const LdItem &y) {
+        return (int64_t)x.rows * std::min(128, x.ncols - x.col0) >
+               (int64_t)y.rows * std::min(128, y.ncols - y.col0);
+    });
+    std::stable_sort(H.sym.begin(), H.sym.end(), [](const SymItem &x, const SymItem &y) {
+        return (int64_t)x.rows * x.w > (int64_t)y.rows * y.w;
     });
 }
 
-int upload_items(vilma_ctx *c, const std::vector<LdItem> &v, LdItem **dev) {
+template <typename T>
+int upload_vec(vilma_ctx *c, const std::vector<T> &v, T **dev, int *count) {
     *dev = nullptr;
+    *count = (int)v.size();
     if (v.empty()) return 0;
-    HIPCHK(c, hipMalloc((void **)dev, v.size() * sizeof(LdItem)));
-    HIPCHK(c, hipMemcpy(*dev, v.data(), v.size() * sizeof(LdItem), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void **)dev, v.size() * sizeof(T)));
+    HIPCHK(c, hipMemcpy(*dev, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return 0;
+}
+
+int upload_items(vilma_ctx *c, HostItems &H, ItemSet &out) {
+    sort_items(H);
+    return upload_vec(c, H.sym, &out.sym, &out.n_sym) || upload_vec(c, H.comb, &out.comb, &out.n_comb) ||
+           upload_vec(c, H.a, &out.a, &out.n_a) || upload_vec(c, H.b, &out.b, &out.n_b);
 }
 
 int ensure_ready(vilma_ctx *c) {
@@ -168,31 +220,29 @@ int ensure_ready(vilma_ctx *c) {
     for (int p = 0; p < c->P; ++p)
         if (!c->ld[p].ended) return fail(c, "LD for cohort " + std::to_string(p) + " not loaded");
     free_ready(c);
-    std::vector<LdItem> A, B;
+    HostItems all;
     std::vector<int32_t> dstart(c->P + 1, 0);
-    int32_t slot = 0, t_base = 0;
+    int32_t slot = 0, t_base = 0, s_base = 0;
+    c->solo.resize(c->P);
     for (int p = 0; p < c->P; ++p) {
         dstart[p] = slot;
-        std::vector<LdItem> sa, sb;
+        HostItems one;
         int32_t s0 = slot;
-        make_items(c, p, c->ld[p], t_base, s0, sa, sb);
-        // same items, same slots, for the whole-problem lists
-        make_items(c, p, c->ld[p], t_base, slot, A, B);
-        sort_items(sa); sort_items(sb);
-        if (upload_items(c, sa, &c->ld[p].solo_a) || upload_items(c, sb, &c->ld[p].solo_b)) return 1;
-        c->ld[p].n_solo_a = (int)sa.size(); c->ld[p].n_solo_b = (int)sb.size();
+        make_items(c, p, c->ld[p], t_base, s_base, s0, one);
+        make_items(c, p, c->ld[p], t_base, s_base, slot, all);     // same items, same slots
+        if (upload_items(c, one, c->solo[p])) return 1;
         t_base += c->ld[p].t_used;
+        s_base += c->ld[p].s_used;
     }
     dstart[c->P] = slot;
-    sort_items(A); sort_items(B);
-    if (upload_items(c, A, &c->items_a) || upload_items(c, B, &c->items_b)) return 1;
-    c->n_a = (int)A.size(); c->n_b = (int)B.size();
+    if (upload_items(c, all, c->all)) return 1;
     const int64_t pool_elems = 2 * (int64_t)c->P * c->N + t_base + 2;
     if (pool_elems >= (int64_t)1 << 31) return fail(c, "shard too large for 32-bit vector offsets");
     c->pool_elems = pool_elems;
     for (int s = 0; s < 2; ++s)
         if (dev_alloc(c, &c->pool[s], pool_elems)) return 1;
     if (dev_alloc(c, &c->dot_partials, slot)) return 1;
+    if (dev_alloc(c, &c->sym_scratch, s_base)) return 1;
     HIPCHK(c, hipMemcpy(c->dot_start, dstart.data(), (c->P + 1) * sizeof(int32_t),
                         hipMemcpyHostToDevice));
     c->ready = true;
@@ -204,44 +254,50 @@ void prof_begin(vilma_ctx *c, hipStream_t s, hipEvent_t &e0) {
     (void)hipEventCreate(&e0);
     (void)hipEventRecord(e0, s);
 }
-void prof_end(vilma_ctx *c, hipStream_t s, hipEvent_t e0) {
+void prof_end(vilma_ctx *c, hipStream_t s, hipEvent_t e0, int kind) {
     if (!c->prof) return;
     hipEvent_t e1;
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e1, s);
-    c->pending.emplace_back(e0, e1);
+    c->pending.push_back({e0, e1, kind});
 }
 void prof_resolve(vilma_ctx *c) {
     for (auto &pr : c->pending) {
         float ms = 0.f;
-        (void)hipEventSynchronize(pr.second);
-        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-            c->prof_ms += ms;
-            c->prof_launches += 1;
+        (void)hipEventSynchronize(pr.e1);
+        if (hipEventElapsedTime(&ms, pr.e0, pr.e1) == hipSuccess) {
+            c->prof_ms[pr.kind] += ms;
+            c->prof_launches[pr.kind] += 1;
         }
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.e0);
+        (void)hipEventDestroy(pr.e1);
     }
     c->pending.clear();
 }
 
 // the LD product on pool `pl` (x_ld section -> y_ld section), all cohorts or one
 void run_ld(vilma_ctx *c, hipStream_t s, double *pl, int cohort) {
-    const LdItem *ia = cohort < 0 ? c->items_a : c->ld[cohort].solo_a;
-    const LdItem *ib = cohort < 0 ? c->items_b : c->ld[cohort].solo_b;
-    const int na = cohort < 0 ? c->n_a : c->ld[cohort].n_solo_a;
-    const int nb = cohort < 0 ? c->n_b : c->ld[cohort].n_solo_b;
-    if (na > 0) {
-        hipEvent_t e0;
+    const ItemSet &it = cohort < 0 ? c->all : c->solo[cohort];
+    hipEvent_t e0;
+    if (it.n_sym > 0) {
         prof_begin(c, s, e0);
-        launch_ld_colsum(ia, na, pl, c->dot_partials, s);
-        prof_end(c, s, e0);
+        launch_ld_sym(it.sym, it.n_sym, pl, c->sym_scratch, s);
+        prof_end(c, s, e0, VILMA_PROF_LD_SYM);
     }
-    if (nb > 0) {
-        hipEvent_t e0;
+    if (it.n_a > 0) {
         prof_begin(c, s, e0);
-        launch_ld_colsum(ib, nb, pl, c->dot_partials, s);
-        prof_end(c, s, e0);
+        launch_ld_colsum(it.a, it.n_a, pl, c->dot_partials, s);
+        prof_end(c, s, e0, VILMA_PROF_LD_COLSUM);
+    }
+    if (it.n_b > 0) {
+        prof_begin(c, s, e0);
+        launch_ld_colsum(it.b, it.n_b, pl, c->dot_partials, s);
+        prof_end(c, s, e0, VILMA_PROF_LD_COLSUM);
+    }
+    if (it.n_comb > 0) {
+        prof_begin(c, s, e0);
+        launch_ld_sym_combine(it.comb, it.n_comb, pl, c->sym_scratch, c->dot_partials, s);
+        prof_end(c, s, e0, VILMA_PROF_LD_COMBINE);
     }
     if (c->pending.size() > 8192) prof_resolve(c);
 }
@@ -315,6 +371,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     rc |= dev_alloc(c, &c->annot, N); rc |= dev_alloc(c, &c->invperm, PN);
     rc |= dev_alloc(c, &c->prec, (int64_t)M * P * P); rc |= dev_alloc(c, &c->log_det, M);
     rc |= dev_alloc(c, &c->lh, (int64_t)A * M);
+    rc |= dev_alloc(c, &c->counts, A);
     for (int s = 0; s < 2 && !rc; ++s) {
         rc |= dev_alloc(c, &c->mu[s], (int64_t)M * PN);
         rc |= dev_alloc(c, &c->m[s], PN); rc |= dev_alloc(c, &c->v[s], PN);
@@ -343,8 +400,9 @@ void vilma_destroy(vilma_ctx *c) {
     prof_resolve(c);
     free_ready(c);
     for (auto &co : c->ld) dev_free(co.store);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
-                    c->lh, c->mu[0], c->mu[1], c->m[0], c->m[1], c->v[0], c->v[1], c->lse[0],
+                    c->lh, c->counts, c->mu[0], c->mu[1], c->m[0], c->m[1], c->v[0], c->v[1], c->lse[0],
                     c->lse[1], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials,
                     c->dot_start};
     for (void *p : ptrs) dev_free(p);
@@ -397,7 +455,24 @@ int vilma_set_hyper(vilma_ctx *c, const double *hyper) {
     return 0;
 }
 
-int64_t vilma_ld_dense_elems(int n) { return (int64_t)n * pad_ld(n); }
+int vilma_set_annotation_counts(vilma_ctx *c, const double *counts) {
+    if (!c) return 1;
+    HIPCHK(c, hipMemcpy(c->counts, counts, (size_t)c->A * sizeof(double), hipMemcpyDefault));
+    return 0;
+}
+
+int vilma_mstep(vilma_ctx *c, void *stream, const double *sums_dev, double *hyper_dev) {
+    if (!c) return 1;
+    launch_mstep(sums_dev, c->counts, c->log_det, c->A, c->M, hyper_dev, c->lh, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int64_t vilma_ld_dense_elems(int n) {
+    int64_t e = 0;
+    for (int J = 0; J < n_slabs(n); ++J) e += sym_panel_elems(n, J);
+    return e;
+}
 int64_t vilma_ld_lowrank_elems(int n, int r) {
     return (int64_t)n * pad_ld(r) + (int64_t)r * pad_ld(n);
 }
@@ -437,14 +512,21 @@ int vilma_ld_add_dense(vilma_ctx *c, int cohort, int n, const double *R) {
     if (co.next_start + (int64_t)n > co.n_ld) return fail(c, "blocks exceed n_ld");
     const int64_t need = vilma_ld_dense_elems(n);
     if (co.store_used + need > co.store_elems) return fail(c, "LD store overflow (total_elems)");
+    // only the lower triangle is kept, slab by slab: rows 128J.. of columns [128J, 128J+w)
     double *dst = co.store + co.store_used;
-    HIPCHK(c, hipMemcpy2D(dst, (size_t)pad_ld(n) * sizeof(double), R, (size_t)n * sizeof(double),
-                          (size_t)n * sizeof(double), (size_t)n, hipMemcpyDefault));
+    for (int J = 0; J < n_slabs(n); ++J) {
+        const int w = slab_width(n, J), j0 = 128 * J;
+        HIPCHK(c, hipMemcpy2D(dst, (size_t)pad_ld(w) * sizeof(double), R + (size_t)j0 * n + j0,
+                              (size_t)n * sizeof(double), (size_t)w * sizeof(double),
+                              (size_t)(n - j0), hipMemcpyDefault));
+        dst += sym_panel_elems(n, J);
+    }
     BlockRec b{0, n, n, co.store_used, 0, co.next_start, 0};
     co.blocks.push_back(b);
     co.store_used += need;
     co.next_start += n;
     co.alg_bytes += (int64_t)8 * n * n;
+    co.s_used += n_slabs(n) * n;
     return 0;
 }
 
@@ -605,6 +687,23 @@ int vilma_snapshot_mean(vilma_ctx *c, void *stream) {
     return 0;
 }
 
+int vilma_fetch(vilma_ctx *c, void *stream, const double *src_dev, double *dst_host, int64_t n) {
+    if (!c) return 1;
+    if (n <= 0) return 0;
+    if (n > c->pinned_elems) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinned_elems = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->pinned, (size_t)n * sizeof(double), hipHostMallocDefault));
+        c->pinned_elems = n;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipMemcpyAsync(c->pinned, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::memcpy(dst_host, c->pinned, (size_t)n * sizeof(double));
+    return 0;
+}
+
 int vilma_prof_enable(vilma_ctx *c, int enable) {
     if (!c) return 1;
     c->prof = enable != 0;
@@ -615,9 +714,11 @@ int vilma_prof_read(vilma_ctx *c, double *ms_total, int64_t *launches, int reset
     if (!c) return 1;
     HIPCHK(c, hipDeviceSynchronize());
     prof_resolve(c);
-    if (ms_total) *ms_total = c->prof_ms;
-    if (launches) *launches = c->prof_launches;
-    if (reset) { c->prof_ms = 0.0; c->prof_launches = 0; }
+    for (int k = 0; k < VILMA_PROF_KINDS; ++k) {
+        if (ms_total) ms_total[k] = c->prof_ms[k];
+        if (launches) launches[k] = c->prof_launches[k];
+        if (reset) { c->prof_ms[k] = 0.0; c->prof_launches[k] = 0; }
+    }
     return 0;
 }
 

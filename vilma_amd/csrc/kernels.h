@@ -19,6 +19,27 @@ struct LdItem {
     int32_t dot_slot;    // where to store this item's partial of that dot product
 };
 
+// One work item of the SYMMETRIC dense product: the panel of one block below (and including)
+// the diagonal tile of a 128-column slab, stored contiguously: rows j0..n-1, `ld` doubles each.
+struct SymItem {
+    const double *a;     // panel base (row j0, first column of the slab), 128-byte aligned
+    int32_t rows;        // n - j0
+    int32_t ld;          // panel leading dimension (multiple of 16 doubles)
+    int32_t w;           // columns in this slab (<= 128)
+    int32_t j0;          // first row/column of the slab inside the block
+    int32_t x_off;       // pool offset of x[0] of the block
+    int32_t s_off;       // scratch offset of S[slab][0] (n entries per slab)
+    int32_t n;           // block size
+    int32_t pad;
+};
+
+// combine step of the symmetric product for one slab of one block
+struct SymCombItem {
+    int32_t n, j0, w, slab;   // slab index J: y[j] = sum_{J' <= J} S[J'][j]
+    int32_t s_base;           // scratch offset of S[0][0] of the block
+    int32_t y_off, dot_off, dot_slot;
+};
+
 struct TauArg { double v[VILMA_MAX_P]; };
 
 struct SnpKernelArgs {
@@ -46,6 +67,10 @@ int snp_pass_grid(int64_t N);
 
 void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *dot_partials,
                       hipStream_t s);
+void launch_ld_sym(const SymItem *items, int n_items, const double *pool, double *scratch,
+                   hipStream_t s);
+void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
+                           const double *scratch, double *dot_partials, hipStream_t s);
 
 // totals[0..2P) and [3P..3P+3) from the per-SNP partials, totals[2P..3P) from the matvec dots
 void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
@@ -73,6 +98,9 @@ void launch_scatter_y(const double *pool_y, const int32_t *invperm, double *y_sn
 // V[c][i] = s[c] * U[i][c]  (U: n x ldu, V: r x ldv)
 void launch_scaled_transpose(const double *U, int n, int r, int ldu, const double *s, double *V,
                              int ldv, hipStream_t st);
+
+void launch_mstep(const double *sums, const double *counts, const double *log_det, int A, int M,
+                  double *hyper, double *lh, hipStream_t s);
 
 void launch_mean_diff(const double *m_cur, const double *scalings, double *snapshot, int64_t PN,
                       double *partials, double *out6, bool compare, hipStream_t s);

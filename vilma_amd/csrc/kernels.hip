@@ -117,6 +117,143 @@ void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *do
 }
 
 // --------------------------------------------------------------------------------------------
+// Symmetric dense LD product reading only the lower triangle (by 128-column slabs): for slab J the
+// panel P = R[j0.., slab] (rows from the diagonal tile down) is streamed ONCE and used twice,
+//   column sums  cs[c] = sum_j P[j][c] x[j]        -> y[slab]  (R symmetric: = R[slab, j0..] x)
+//   row sums     rs[j] = sum_c P[j][c] x[slab c]    -> y[j] for the rows below the diagonal tile
+// so a block costs ~n^2/2 + 64 n elements instead of n^2.  Row sums need a cross-lane reduction:
+// 8 rows at a time with a halving butterfly (4+2+1 exchanges, then 3 full steps = 10 shuffles per
+// 8 KiB streamed).  Both kinds of partial go to a scratch S[slab][j]; ld_sym_combine_kernel adds
+// them in slab order (fixed order => deterministic) and forms the y.z partials.
+// --------------------------------------------------------------------------------------------
+// one group of 8 panel rows: column-sum FMAs, row-sum partials, butterfly, scratch write
+template <bool FULL>
+static __device__ __forceinline__ void sym_group(const v2d (&v)[CS_ROWS], const double *__restrict__ xrow,
+                                                 int r0, int rows, double xs0, double xs1,
+                                                 double &acc0, double &acc1, int lane, int slab_w,
+                                                 double *__restrict__ srow) {
+    double p[CS_ROWS];
+#pragma unroll
+    for (int u = 0; u < CS_ROWS; ++u) {
+        const double xv = (FULL || r0 + u < rows) ? xrow[FULL ? r0 + u : min(r0 + u, rows - 1)] : 0.0;
+        const double xz = (FULL || r0 + u < rows) ? xv : 0.0;
+        acc0 = fma(v[u].x, xz, acc0);
+        acc1 = fma(v[u].y, xz, acc1);
+        p[u] = fma(v[u].x, xs0, v[u].y * xs1);
+    }
+    // halving butterfly: after the three steps lane l holds row (bit5*4 + bit4*2 + bit3) summed
+    // over the 8 lanes that differ from it in bits 5,4,3; three plain steps finish bits 2..0
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+    double q[4], r2[2], t1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const double send = h5 ? p[u] : p[u + 4];
+        const double keep = h5 ? p[u + 4] : p[u];
+        q[u] = keep + __shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double send = h4 ? q[u] : q[u + 2];
+        const double keep = h4 ? q[u + 2] : q[u];
+        r2[u] = keep + __shfl_xor(send, 16);
+    }
+    {
+        const double send = h3 ? r2[0] : r2[1];
+        const double keep = h3 ? r2[1] : r2[0];
+        t1 = keep + __shfl_xor(send, 8);
+    }
+    t1 += __shfl_xor(t1, 4);
+    t1 += __shfl_xor(t1, 2);
+    t1 += __shfl_xor(t1, 1);
+    const int rr = r0 + ((h5 ? 4 : 0) | (h4 ? 2 : 0) | (h3 ? 1 : 0));
+    if ((lane & 7) == 0 && (FULL || rr < rows) && rr >= slab_w)   // strictly below the diagonal tile
+        srow[rr] = t1;
+}
+
+__global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
+    const SymItem *__restrict__ items, const double *__restrict__ xpool,
+    double *__restrict__ scratch) {
+    __shared__ double red[CS_WAVES][128];
+    const SymItem it = items[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cl = 2 * lane;
+    const bool active = cl < it.w;
+    const int rows = it.rows;
+    const int64_t ld = it.ld;
+    const double *__restrict__ xrow = xpool + it.x_off + it.j0;     // x of the panel's rows
+    // x of this lane's two columns (the slab's columns are rows j0.. of the same vector)
+    const double xs0 = active ? xrow[cl] : 0.0;
+    const double xs1 = (cl + 1 < it.w) ? xrow[cl + 1] : 0.0;
+    // loads are unconditional (a select around a load makes hipcc branch and wait per element):
+    // lanes beyond the slab read column 0 and are neutralised by xs = 0
+    const double *ap = it.a + (active ? cl : 0);
+    double *__restrict__ srow = scratch + it.s_off + it.j0;
+    double acc0 = 0.0, acc1 = 0.0;
+    const int nfull = rows / CS_ROWS;              // full 8-row groups; group g belongs to wave g % 4
+    const int64_t gstride = (int64_t)CS_WAVES * CS_ROWS * ld;
+    v2d v[CS_ROWS];
+    const double *rp = ap + (int64_t)w * CS_ROWS * ld;
+    // plain loop: 8 x 1 KiB loads in flight per wave, latency hidden by occupancy (a manually
+    // software-pipelined version with two register sets measured the same, 1.20 ms @C3)
+    for (int g = w; g < nfull; g += CS_WAVES, rp += gstride) {
+#pragma unroll
+        for (int u = 0; u < CS_ROWS; ++u) v[u] = *(gd2_ptr)(rp + (int64_t)u * ld);
+        sym_group<true>(v, xrow, g * CS_ROWS, rows, xs0, xs1, acc0, acc1, lane, it.w, srow);
+    }
+    if ((rows % CS_ROWS) != 0 && (nfull % CS_WAVES) == w) {     // the one partial group
+        const int r0 = nfull * CS_ROWS;
+#pragma unroll
+        for (int u = 0; u < CS_ROWS; ++u)     // rows past the end re-read the last row
+            v[u] = *(gd2_ptr)(ap + (int64_t)min(r0 + u, rows - 1) * ld);
+        sym_group<false>(v, xrow, r0, rows, xs0, xs1, acc0, acc1, lane, it.w, srow);
+    }
+    red[w][2 * lane] = acc0;
+    red[w][2 * lane + 1] = acc1;
+    __syncthreads();
+    if ((int)threadIdx.x < it.w) {
+        double s = red[0][threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < CS_WAVES; ++ww) s += red[ww][threadIdx.x];
+        srow[threadIdx.x] = s;                                  // the slab's own (diagonal) entry
+    }
+}
+
+__global__ __launch_bounds__(128) void ld_sym_combine_kernel(
+    const SymCombItem *__restrict__ items, const double *__restrict__ xpool,
+    double *__restrict__ ypool, const double *__restrict__ scratch,
+    double *__restrict__ dot_partials) {
+    __shared__ double dred[2];
+    const SymCombItem it = items[blockIdx.x];
+    const int t = threadIdx.x;
+    double dv = 0.0;
+    if (t < it.w) {
+        const int j = it.j0 + t;
+        double s = 0.0;
+        for (int J = 0; J <= it.slab; ++J) s += scratch[it.s_base + J * it.n + j];
+        ypool[it.y_off + j] = s;
+        dv = s * xpool[it.dot_off + j];
+    }
+    dv = wave_sum(dv);
+    if ((t & 63) == 0) dred[t >> 6] = dv;
+    __syncthreads();
+    if (t == 0) dot_partials[it.dot_slot] = dred[0] + dred[1];
+}
+
+void launch_ld_sym(const SymItem *items, int n_items, const double *pool, double *scratch,
+                   hipStream_t s) {
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(ld_sym_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pool, scratch);
+}
+
+void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
+                           const double *scratch, double *dot_partials, hipStream_t s) {
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items), dim3(128), 0, s, items,
+                       (const double *)pool, pool, scratch, dot_partials);
+}
+
+// --------------------------------------------------------------------------------------------
 // small SPD helpers, fully unrolled so everything stays in registers
 // --------------------------------------------------------------------------------------------
 // det(lam)^(-1/2) of a symmetric positive definite matrix
@@ -217,7 +354,9 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 // fused per-SNP pass (one thread per SNP, coalesced along the SNP axis of vi_mu [M][P][N])
 // --------------------------------------------------------------------------------------------
 #define SNP_THREADS 256
-#define KC 4
+#ifndef KU
+#define KU 4
+#endif
 
 template <int P, bool BLEND, bool ONE_ANNOT>
 __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
@@ -255,84 +394,78 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     // accumulated as w_k exp(a_k - max a) with a_k = 0.5 quad_k + lh_k and w_k = det^-1/2: an
     // rsqrt instead of a log per (component, SNP).  In the KL terms the log-determinants of
     // fast_delta_kl and fast_beta_kl cancel, so their sum needs only quad_k and tr(Prec_k Sig_k).
+    // Online softmax with ONE exp per component: with d = a_k - max, t = exp(-|d|) is the weight
+    // of the new term when d <= 0 and the rescale factor of the running sums when d > 0.
     double mx = NEG_INF, Z = 0.0, Skl = 0.0, Sip = 0.0;
     double Sm[P], S2[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) { Sm[p] = 0.0; S2[p] = 0.0; }
 
-    for (int k0 = 0; k0 < M; k0 += KC) {
-        double av[KC], wv[KC], klk[KC], ipk[KC], mun[KC][P], sdg[KC][P];
+    // vi_mu of KU components is loaded up front (KU*P independent 512-B wave loads in flight),
+    // then the components are folded in one at a time
+    for (int k0 = 0; k0 < M; k0 += KU) {
+        double mul[KU][P];
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-            const int k = k0 + kk;
-            if (k < M) {
-                double pr[P][P], lam[P][P], sig[P][P], mu[P], nat[P];
-                const double *pk = a.prec + (int64_t)k * P * P;
+        for (int kk = 0; kk < KU; ++kk) {
+            const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-#pragma unroll
-                    for (int q = 0; q < P; ++q) { pr[p][q] = pk[p * P + q]; lam[p][q] = pr[p][q]; }
-                    lam[p][p] += d[p];
-                    mu[p] = a.mu_in[((int64_t)k * P + p) * N64 + ii];
-                }
-                wv[kk] = spd_inverse<P>(lam, sig);
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int q = 0; q < P; ++q) t += lam[p][q] * mu[q];
-                    nat[p] = BLEND ? (step * g[p] + (1.0 - step) * t) : t;
-                }
-                double quad = 0.0;
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    double t = mu[p];
-                    if (BLEND) {
-                        t = 0.0;
-#pragma unroll
-                        for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
-                        if (live) a.mu_out[((int64_t)k * P + p) * N64 + i] = t;
-                    }
-                    mun[kk][p] = t;
-                    sdg[kk][p] = sig[p][p];
-                    quad += t * nat[p];
-                }
-                double ip = 0.0, tr = 0.0;
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-#pragma unroll
-                    for (int q = 0; q < P; ++q) {
-                        ip += mun[kk][p] * mun[kk][q] * pr[q][p];
-                        tr += pr[p][q] * sig[q][p];
-                    }
-                av[kk] = 0.5 * quad + lh[k];
-                klk[kk] = 0.5 * (quad + tr);
-                ipk[kk] = ip;
-            } else {
-                av[kk] = NEG_INF; wv[kk] = 0.0; klk[kk] = 0.0; ipk[kk] = 0.0;
-#pragma unroll
-                for (int p = 0; p < P; ++p) { mun[kk][p] = 0.0; sdg[kk][p] = 0.0; }
-            }
+            for (int p = 0; p < P; ++p) mul[kk][p] = a.mu_in[((int64_t)kc * P + p) * N64 + ii];
         }
-        double cmax = av[0];
 #pragma unroll
-        for (int kk = 1; kk < KC; ++kk) cmax = fmax(cmax, av[kk]);
-        const double nmx = fmax(mx, cmax);
-        const double sc = exp(mx - nmx);
-        mx = nmx;
-        Z *= sc; Skl *= sc; Sip *= sc;
-#pragma unroll
-        for (int p = 0; p < P; ++p) { Sm[p] *= sc; S2[p] *= sc; }
-#pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-            const double e = wv[kk] * exp(av[kk] - mx);
-            Z += e;
-            Skl = fma(e, klk[kk], Skl);
-            Sip = fma(e, ipk[kk], Sip);
+        for (int kk = 0; kk < KU; ++kk) {
+            const int k = k0 + kk;
+            if (k >= M) break;
+            double pr[P][P], lam[P][P], sig[P][P], nat[P], mun[P];
+            const double *pk = a.prec + (int64_t)k * P * P;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                Sm[p] = fma(e, mun[kk][p], Sm[p]);
-                S2[p] = fma(e, sdg[kk][p] + mun[kk][p] * mun[kk][p], S2[p]);
+#pragma unroll
+                for (int q = 0; q < P; ++q) { pr[p][q] = pk[p * P + q]; lam[p][q] = pr[p][q]; }
+                lam[p][p] += d[p];
+            }
+            const double wk = spd_inverse<P>(lam, sig);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < P; ++q) t += lam[p][q] * mul[kk][q];
+                nat[p] = BLEND ? (step * g[p] + (1.0 - step) * t) : t;
+            }
+            double quad = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double t = mul[kk][p];
+                if (BLEND) {
+                    t = 0.0;
+#pragma unroll
+                    for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+                    if (live) a.mu_out[((int64_t)k * P + p) * N64 + i] = t;
+                }
+                mun[p] = t;
+                quad += t * nat[p];
+            }
+            double ip = 0.0, tr = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    ip += mun[p] * mun[q] * pr[q][p];
+                    tr += pr[p][q] * sig[q][p];
+                }
+            const double ak = 0.5 * quad + lh[k];
+            const double dk = ak - mx;
+            const double t = exp(-fabs(dk));
+            const bool up = dk > 0.0;
+            const double sc = up ? t : 1.0;
+            const double e = wk * (up ? 1.0 : t);
+            mx = up ? ak : mx;
+            Z = fma(Z, sc, e);
+            Skl = fma(Skl, sc, e * (0.5 * (quad + tr)));
+            Sip = fma(Sip, sc, e * ip);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                Sm[p] = fma(Sm[p], sc, e * mun[p]);
+                S2[p] = fma(S2[p], sc, e * (sig[p][p] + mun[p] * mun[p]));
             }
         }
     }
@@ -546,6 +679,25 @@ static __device__ double block_max_1024(double v, double *sh) {
     return t;
 }
 
+// sum of v[0..n) with stride `stride`, by a 1024-thread workgroup: every thread issues up to 8
+// independent loads per pass (clamped index + select, so no branch sits around a load and the
+// loads pipeline), then a fixed-order wave / LDS combination.
+static __device__ double block_strided_sum_1024(const double *__restrict__ v, int n, int stride,
+                                                double *sh) {
+    double acc = 0.0;
+    for (int r0 = threadIdx.x; r0 < n; r0 += 8 * 1024) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u * 1024;
+            const double x = v[(int64_t)min(r, n - 1) * stride];
+            t[u] = r < n ? x : 0.0;
+        }
+        acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    return block_sum_1024(acc, sh);
+}
+
 __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict__ snp_partials,
                                                          int snp_rows, int P,
                                                          const double *__restrict__ dot_partials,
@@ -554,15 +706,12 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict
     __shared__ double sh[16];
     const int NT = 2 * P + 2;
     for (int c = 0; c < NT; ++c) {
-        double s = 0.0;
-        for (int r = threadIdx.x; r < snp_rows; r += 1024) s += snp_partials[(int64_t)r * NT + c];
-        s = block_sum_1024(s, sh);
+        const double s = block_strided_sum_1024(snp_partials + c, snp_rows, NT, sh);
         if (threadIdx.x == 0) totals[c < 2 * P ? c : (3 * P + (c - 2 * P))] = s;
     }
     for (int p = 0; p < P; ++p) {
-        double s = 0.0;
-        for (int r = dot_start[p] + threadIdx.x; r < dot_start[p + 1]; r += 1024) s += dot_partials[r];
-        s = block_sum_1024(s, sh);
+        const int lo = dot_start[p], hi = dot_start[p + 1];
+        const double s = hi > lo ? block_strided_sum_1024(dot_partials + lo, hi - lo, 1, sh) : 0.0;
         if (threadIdx.x == 0) totals[2 * P + p] = s;
     }
 }
@@ -647,13 +796,23 @@ __global__ __launch_bounds__(256) void mean_diff_kernel(const double *__restrict
 __global__ __launch_bounds__(1024) void mean_diff_final_kernel(const double *__restrict__ partials,
                                                                 int rows, double *__restrict__ out) {
     __shared__ double sh[16];
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < 3; ++c) {
+        const double s = block_strided_sum_1024(partials + c, rows, 6, sh);
+        if (threadIdx.x == 0) out[c] = s;
+    }
+    for (int c = 3; c < 6; ++c) {
         double s = 0.0;
-        for (int r = threadIdx.x; r < rows; r += 1024) {
-            const double x = partials[(int64_t)r * 6 + c];
-            s = c < 3 ? s + x : fmax(s, x);
+        for (int r0 = threadIdx.x; r0 < rows; r0 += 4 * 1024) {
+            double t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * 1024;
+                const double x = partials[(int64_t)min(r, rows - 1) * 6 + c];
+                t[u] = r < rows ? x : 0.0;
+            }
+            s = fmax(s, fmax(fmax(t[0], t[1]), fmax(t[2], t[3])));
         }
-        s = c < 3 ? block_sum_1024(s, sh) : block_max_1024(s, sh);
+        s = block_max_1024(s, sh);
         if (threadIdx.x == 0) out[c] = s;
     }
 }
@@ -691,4 +850,35 @@ void launch_scaled_transpose(const double *U, int n, int r, int ldu, const doubl
                              int ldv, hipStream_t st) {
     hipLaunchKernelGGL(scaled_transpose_kernel, dim3((n + 31) / 32, (r + 31) / 32), dim3(32, 8), 0,
                        st, U, n, r, ldu, s, V, ldv);
+}
+
+// --------------------------------------------------------------------------------------------
+// device M-step: hyper = normalise(max(S / (count + 1e-100), 1e-100)) per annotation
+// (variational_inference.py:832-842) and lh = log hyper - 0.5 log_det (numerics.py:149-164).
+// One workgroup per annotation row; fixed-order sum.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mstep_kernel(const double *__restrict__ sums,
+                                                     const double *__restrict__ counts,
+                                                     const double *__restrict__ log_det, int M,
+                                                     double *__restrict__ hyper,
+                                                     double *__restrict__ lh) {
+    __shared__ double red[4];
+    const int a = blockIdx.x;
+    const double inv = 1.0 / (counts[a] + 1e-100);
+    double part = 0.0;
+    for (int k = threadIdx.x; k < M; k += 256) part += fmax(sums[(int64_t)a * M + k] * inv, 1e-100);
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const double total = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int k = threadIdx.x; k < M; k += 256) {
+        const double h = fmax(sums[(int64_t)a * M + k] * inv, 1e-100) / total;
+        hyper[(int64_t)a * M + k] = h;
+        lh[(int64_t)a * M + k] = log(h) - 0.5 * log_det[k];
+    }
+}
+
+void launch_mstep(const double *sums, const double *counts, const double *log_det, int A, int M,
+                  double *hyper, double *lh, hipStream_t s) {
+    hipLaunchKernelGGL(mstep_kernel, dim3(A), dim3(256), 0, s, sums, counts, log_det, M, hyper, lh);
 }

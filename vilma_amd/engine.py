@@ -37,10 +37,17 @@ class HipEngine:
         if self.lib.vilma_create(self.P, self.N, self.M, self.A, C.byref(ctx)):
             raise _lib.VilmaHipError(self.lib.vilma_last_error(None).decode())
         self.ctx = ctx
-        f64 = dict(dtype=torch.float64, device=self.device)
-        self._totals = torch.zeros(_lib.ntotals(self.P), **f64)
-        self._sums = torch.zeros(self.A * self.M, **f64)
-        self._diff = torch.zeros(_lib.NDIFF, **f64)
+        # one device tensor for every small result, so a decision needs a single D2H copy:
+        # [totals (3P+2) | convergence stats (6) | hyper_delta (A*M) | delta sums (A*M)]
+        nt, am = _lib.ntotals(self.P), self.A * self.M
+        self.results = torch.zeros(nt + _lib.NDIFF + 2 * am, dtype=torch.float64,
+                                   device=self.device)
+        self._totals = self.results[:nt]
+        self._diff = self.results[nt:nt + _lib.NDIFF]
+        self._hyper = self.results[nt + _lib.NDIFF:nt + _lib.NDIFF + am]
+        self._sums = self.results[nt + _lib.NDIFF + am:]
+        self.n_totals = nt
+        self._host = np.zeros(self.results.numel())
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -82,6 +89,18 @@ class HipEngine:
     def set_tau(self, tau):
         tau = _f64(tau)
         self._check(self.lib.vilma_set_tau(self.ctx, _ptr(tau)))
+
+    def set_annotation_counts(self, counts):
+        counts = _f64(counts)
+        assert counts.shape == (self.A,)
+        self._check(self.lib.vilma_set_annotation_counts(self.ctx, _ptr(counts)))
+
+    def mstep(self, sums=None):
+        """Device M-step from (all-reduced) delta sums; returns the device view of hyper_delta."""
+        sums = self._sums if sums is None else sums
+        self._check(self.lib.vilma_mstep(self.ctx, self._stream(), C.c_void_p(sums.data_ptr()),
+                                         C.c_void_p(self._hyper.data_ptr())))
+        return self._hyper
 
     def set_hyper(self, hyper):
         hyper = _f64(hyper).reshape(self.A, self.M)
@@ -174,6 +193,12 @@ class HipEngine:
     def accept(self, take_mu):
         self._check(self.lib.vilma_accept(self.ctx, 1 if take_mu else 0))
 
+    def fetch(self, n):
+        """results[:n] on the host (one pinned D2H copy behind the current stream)."""
+        self._check(self.lib.vilma_fetch(self.ctx, self._stream(),
+                                         C.c_void_p(self.results.data_ptr()), _ptr(self._host), n))
+        return self._host[:n].copy()
+
     def delta_sums(self):
         self._check(self.lib.vilma_delta_sums(self.ctx, self._stream(),
                                               C.c_void_p(self._sums.data_ptr())))
@@ -191,7 +216,11 @@ class HipEngine:
     def prof_enable(self, on=True):
         self._check(self.lib.vilma_prof_enable(self.ctx, 1 if on else 0))
 
+    PROF_KINDS = ('ld_sym_kernel', 'ld_colsum_kernel', 'ld_sym_combine_kernel')
+
     def prof_read(self, reset=True):
-        ms, n = C.c_double(), C.c_int64()
-        self._check(self.lib.vilma_prof_read(self.ctx, C.byref(ms), C.byref(n), 1 if reset else 0))
-        return ms.value, n.value
+        """{kernel: (milliseconds, launches)} accumulated by the library's HIP events."""
+        ms = (C.c_double * len(self.PROF_KINDS))()
+        n = (C.c_int64 * len(self.PROF_KINDS))()
+        self._check(self.lib.vilma_prof_read(self.ctx, ms, n, 1 if reset else 0))
+        return {k: (ms[i], n[i]) for i, k in enumerate(self.PROF_KINDS)}

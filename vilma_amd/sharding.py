@@ -41,6 +41,21 @@ class Comm:
             return t.cpu().numpy().copy()
         return tensor.cpu().numpy().copy()
 
+    def allreduce_inplace(self, tensor, op='sum'):
+        """All-reduce a (view of a) torch tensor in place, without a host copy when the backend
+        can work on its device (nccl/RCCL on GPU tensors, gloo on CPU tensors)."""
+        if self.world == 1:
+            return tensor
+        dist = self._dist
+        rop = dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX
+        if (self.backend == 'gloo' and tensor.is_cuda) or (self.backend == 'nccl' and not tensor.is_cuda):
+            t = tensor.cpu() if tensor.is_cuda else tensor.cuda()
+            dist.all_reduce(t, op=rop, group=self.group)
+            tensor.copy_(t)
+        else:
+            dist.all_reduce(tensor, op=rop, group=self.group)
+        return tensor
+
     def allreduce_np(self, array, op='sum'):
         if self.world == 1:
             return np.array(array, dtype=np.float64)

@@ -162,6 +162,10 @@ class SweepDriver:
         if not hasattr(self, 'error_scaling'):
             self.error_scaling = np.ones(num_pops)
         self._nat_table = None
+        self._want_diff = False
+        self.engine.set_annotation_counts(self.annotation_counts)
+        self._last_diff = None      # convergence statistics fetched together with an evaluation
+        self._verbose = False
         self._version = 0           # bumped whenever the device state moves
         self._hyper = None
         self._totals = None         # all-reduced sums of the current (accepted) state
@@ -190,11 +194,27 @@ class SweepDriver:
             - 0.5 * self.ld_ranks * np.log(tau)
         return float(lik.sum() - (t[3 * P] + t[3 * P + 1]))
 
+    def _fetch(self, with_diff=False, with_hyper=False):
+        """All-reduce and download the engine's result vector in ONE device->host copy:
+        [totals | convergence statistics | hyper_delta].  Sums are all-reduced over the ranks
+        (RCCL); the maxima of the statistics only when INFO logging wants them."""
+        eng = self.engine
+        nt, am = eng.n_totals, self.num_annotations * self.num_mix
+        if self.comm.world > 1:
+            self.comm.allreduce_inplace(eng.results[:nt + (3 if with_diff else 0)])
+            if with_diff and self._verbose:
+                self.comm.allreduce_inplace(eng.results[nt + 3:nt + 6], op='max')
+        upto = nt + 6 + am if with_hyper else (nt + 6 if with_diff else nt)
+        return eng.fetch(upto)
+
     def _evaluate(self, step=None):
         """Objective of a candidate point: the current vi_mu (step None) or a natural-gradient
         trial at `step`.  The candidate stays on the device as the trial state."""
-        raw = self.engine.eval() if step is None else self.engine.trial(step)
-        totals = self.comm.allreduce(raw)
+        if step is None:
+            self.engine.eval()
+        else:
+            self.engine.trial(step)
+        totals = self._fetch()
         self.n_evaluations += 1
         return self._objective_from(totals), totals
 
@@ -203,13 +223,17 @@ class SweepDriver:
         self._objective, self._totals = obj, totals
         self._version += 1
 
-    def _set_hyper(self, hyper):
+    def _install_hyper(self, hyper):
+        """Host-side bookkeeping of a hyper_delta that is already installed on the device."""
         self._hyper = np.array(hyper)
-        self.engine.set_hyper(self._hyper)
         log_h = np.log(self._hyper) - 0.5 * self.log_det[None, :]
         # fast_vi_delta_grad (numerics.py:149-164) as an [A, M-1] table; the per-SNP array the
         # reference stores is this table indexed by annotation
         self._nat_table = log_h[:, :-1] - log_h[:, -1:]
+
+    def _set_hyper(self, hyper):
+        self.engine.set_hyper(np.asarray(hyper, dtype=np.float64))
+        self._install_hyper(hyper)
 
     def _upload(self, params):
         """Make `params` the current device state and evaluate it."""
@@ -251,16 +275,29 @@ class SweepDriver:
                 return orig_obj, orig_obj
             L[idx] *= lsr
 
-    def _update_hyper_delta(self, orig_obj):
-        """Closed-form M-step for the mixture weights (variational_inference.py:825-860)."""
-        sums = self.comm.allreduce(self.engine.delta_sums())
-        new_hyper = sums.reshape(self.num_annotations, self.num_mix)
-        new_hyper = np.maximum(new_hyper / (self.annotation_counts.reshape((-1, 1)) + EPSILON),
-                               EPSILON)
-        new_hyper /= new_hyper.sum(axis=1, keepdims=True)
-        self._set_hyper(new_hyper)
-        new_obj, totals = self._evaluate()
-        self._accept(False, new_obj, totals)
+    def _update_hyper_delta(self, orig_obj, with_diff=False):
+        """Closed-form M-step for the mixture weights (variational_inference.py:825-860), all on
+        the device: responsibility sums -> (all-reduce) -> new hyper_delta and its table ->
+        re-evaluation, then ONE download of [sums of the new state | statistics | hyper_delta].
+        The update is unconditional in the reference, so it is accepted before the download."""
+        eng = self.engine
+        sums = eng.delta_sums()
+        if self.comm.world > 1:
+            self.comm.allreduce_inplace(sums)
+        eng.mstep(sums)
+        eng.eval()
+        eng.accept(False)
+        if with_diff:
+            eng.mean_diff()
+        host = self._fetch(with_diff=with_diff, with_hyper=True)
+        nt = eng.n_totals
+        totals = host[:nt]
+        self._install_hyper(host[nt + 6:].reshape(self.num_annotations, self.num_mix))
+        self._last_diff = host[nt:nt + 6] if with_diff else None
+        new_obj = self._objective_from(totals)
+        self.n_evaluations += 1
+        self._objective, self._totals = new_obj, totals
+        self._version += 1
         logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
         return orig_obj, new_obj
 
@@ -293,7 +330,10 @@ class SweepDriver:
         # ---- paramset 1: mixture weights (L[1] stays 1, so exactly one pass)
         L[1] = max([1., L[1] / 1.25])
         logging.info('...Updating paramset %d, L=%f', 1, L[1])
-        orig_obj, new_obj = self._update_hyper_delta(self._objective)
+        # without --learn-scaling this is the last evaluation of the sweep: piggy-back the
+        # convergence statistics on its download
+        orig_obj, new_obj = self._update_hyper_delta(self._objective,
+                                                     with_diff=self._want_diff and not self.scale_se)
         delta_sum += new_obj - orig_obj
         # ---- paramset 2: annotations -- nothing to do in this scheme (:862-866)
         L[2] = max([1., L[2] / 1.25])
@@ -321,12 +361,18 @@ class SweepDriver:
         return self._params(), L_new, elbo, running_elbo_delta
 
     def _diff_stats(self):
-        raw = self.engine.mean_diff()
-        if self.comm.world == 1:
-            return raw.cpu().numpy()
-        s = self.comm.allreduce(raw[:3].clone())
-        m = self.comm.allreduce(raw[3:].clone(), op='max')
-        return np.concatenate([s, m])
+        """Statistics of the posterior-mean change over the sweep just finished (fetched with
+        its last evaluation when possible, otherwise computed and fetched now)."""
+        if self._last_diff is not None:
+            d, self._last_diff = self._last_diff, None
+            return d
+        self.engine.mean_diff()
+        nt = self.engine.n_totals
+        if self.comm.world > 1:
+            self.comm.allreduce_inplace(self.engine.results[nt:nt + 3])
+            if self._verbose:
+                self.comm.allreduce_inplace(self.engine.results[nt + 3:nt + 6], op='max')
+        return self.engine.fetch(nt + 6)[nt:]
 
     def sweep(self, state=None):
         """One outer iteration as optimize() runs it: _optimize_step + convergence statistics.
@@ -334,6 +380,7 @@ class SweepDriver:
         if state is None:
             self.engine.snapshot_mean()
             state = {'L': np.ones(5), 'elbo': self._objective, 'running': None}
+        self._want_diff, self._last_diff = True, None
         _, L, elbo, running = self._optimize_step(self._params(), L=state['L'],
                                                    curr_elbo=state['elbo'], line_search_rate=2.,
                                                    running_elbo_delta=state['running'])
@@ -364,6 +411,7 @@ class SweepDriver:
         n_total = self.num_pops * self.num_loci
         self.engine.snapshot_mean()
         verbose = logging.getLogger().isEnabledFor(logging.INFO)
+        self._verbose, self._want_diff, self._last_diff = verbose, True, None
         ckp_mean = self.real_posterior_mean(params) if (verbose and self.checkpoint) else None
         while num_its < self.num_its and not converged:
             if self.checkpoint and num_its % self.checkpoint_freq == 0:
