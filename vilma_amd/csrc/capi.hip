@@ -158,12 +158,12 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
                 it.ld = pad_ld(it.w); it.j0 = 128 * J; it.x_off = pN + b.start;
                 it.s_off = s_off + J * b.n; it.n = b.n; it.pad = 0;
                 H.sym.push_back(it);
-                SymCombItem cb;
-                cb.n = b.n; cb.j0 = 128 * J; cb.w = it.w; cb.slab = J; cb.s_base = s_off;
-                cb.y_off = PN + pN + b.start; cb.dot_off = pN + b.start; cb.dot_slot = slot++;
-                H.comb.push_back(cb);
                 off += sym_panel_elems(b.n, J);
             }
+            SymCombItem cb;
+            cb.n = b.n; cb.s_base = s_off; cb.y_off = PN + pN + b.start;
+            cb.dot_off = pN + b.start; cb.dot_slot = slot++; cb.pad = 0;
+            H.comb.push_back(cb);
             s_off += ns * b.n;
         } else {
             for (int c0 = 0; c0 < b.r; c0 += 128) {        // t = U^T x

@@ -33,11 +33,12 @@ struct SymItem {
     int32_t pad;
 };
 
-// combine step of the symmetric product for one slab of one block
+// combine step of the symmetric product for one block: y[j] = sum_{J <= j/128} S[J][j]
 struct SymCombItem {
-    int32_t n, j0, w, slab;   // slab index J: y[j] = sum_{J' <= J} S[J'][j]
+    int32_t n;                // block size
     int32_t s_base;           // scratch offset of S[0][0] of the block
     int32_t y_off, dot_off, dot_slot;
+    int32_t pad;
 };
 
 struct TauArg { double v[VILMA_MAX_P]; };

@@ -219,25 +219,33 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     }
 }
 
-__global__ __launch_bounds__(128) void ld_sym_combine_kernel(
+// y[j] = sum_{J <= slab(j)} S[J][j] for one whole block per workgroup (slab order = fixed order),
+// with the block's y.z partial.
+__global__ __launch_bounds__(256) void ld_sym_combine_kernel(
     const SymCombItem *__restrict__ items, const double *__restrict__ xpool,
     double *__restrict__ ypool, const double *__restrict__ scratch,
     double *__restrict__ dot_partials) {
-    __shared__ double dred[2];
+    __shared__ double dred[4];
     const SymCombItem it = items[blockIdx.x];
-    const int t = threadIdx.x;
     double dv = 0.0;
-    if (t < it.w) {
-        const int j = it.j0 + t;
+    for (int j = threadIdx.x; j < it.n; j += 256) {
+        const int slab = j >> 7;
+        const double *sj = scratch + it.s_base + j;
         double s = 0.0;
-        for (int J = 0; J <= it.slab; ++J) s += scratch[it.s_base + J * it.n + j];
+        int J = 0;
+        for (; J + 3 <= slab; J += 4) {          // four independent loads in flight, fixed order
+            const double t0 = sj[(int64_t)J * it.n], t1 = sj[(int64_t)(J + 1) * it.n];
+            const double t2 = sj[(int64_t)(J + 2) * it.n], t3 = sj[(int64_t)(J + 3) * it.n];
+            s += (t0 + t1) + (t2 + t3);
+        }
+        for (; J <= slab; ++J) s += sj[(int64_t)J * it.n];
         ypool[it.y_off + j] = s;
-        dv = s * xpool[it.dot_off + j];
+        dv = fma(s, xpool[it.dot_off + j], dv);
     }
     dv = wave_sum(dv);
-    if ((t & 63) == 0) dred[t >> 6] = dv;
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = dv;
     __syncthreads();
-    if (t == 0) dot_partials[it.dot_slot] = dred[0] + dred[1];
+    if (threadIdx.x == 0) dot_partials[it.dot_slot] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
 void launch_ld_sym(const SymItem *items, int n_items, const double *pool, double *scratch,
@@ -249,7 +257,7 @@ void launch_ld_sym(const SymItem *items, int n_items, const double *pool, double
 void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
                            const double *scratch, double *dot_partials, hipStream_t s) {
     if (n_items <= 0) return;
-    hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items), dim3(128), 0, s, items,
+    hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items), dim3(256), 0, s, items,
                        (const double *)pool, pool, scratch, dot_partials);
 }
 
@@ -698,21 +706,59 @@ static __device__ double block_strided_sum_1024(const double *__restrict__ v, in
     return block_sum_1024(acc, sh);
 }
 
+// One workgroup, ONE memory latency: every thread first accumulates all 2P+2 columns of its rows
+// (and its share of each cohort's y.z partials), then the columns are reduced across the
+// workgroup together (wave shuffles, one barrier, fixed order).
+#define FIN_MAXC (2 * VILMA_MAX_P + 2 + VILMA_MAX_P)
 __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict__ snp_partials,
                                                          int snp_rows, int P,
                                                          const double *__restrict__ dot_partials,
                                                          const int32_t *__restrict__ dot_start,
                                                          double *__restrict__ totals) {
-    __shared__ double sh[16];
+    __shared__ double sh[16][FIN_MAXC];
     const int NT = 2 * P + 2;
-    for (int c = 0; c < NT; ++c) {
-        const double s = block_strided_sum_1024(snp_partials + c, snp_rows, NT, sh);
-        if (threadIdx.x == 0) totals[c < 2 * P ? c : (3 * P + (c - 2 * P))] = s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double acc[FIN_MAXC];
+#pragma unroll
+    for (int c = 0; c < FIN_MAXC; ++c) acc[c] = 0.0;
+    for (int r = threadIdx.x; r < snp_rows; r += 1024) {
+        const double *row = snp_partials + (int64_t)r * NT;
+        double t[2 * VILMA_MAX_P + 2];
+#pragma unroll
+        for (int c = 0; c < 2 * VILMA_MAX_P + 2; ++c) t[c] = row[min(c, NT - 1)];   // no branch
+#pragma unroll
+        for (int c = 0; c < 2 * VILMA_MAX_P + 2; ++c) acc[c] += c < NT ? t[c] : 0.0;
     }
-    for (int p = 0; p < P; ++p) {
-        const int lo = dot_start[p], hi = dot_start[p + 1];
-        const double s = hi > lo ? block_strided_sum_1024(dot_partials + lo, hi - lo, 1, sh) : 0.0;
-        if (threadIdx.x == 0) totals[2 * P + p] = s;
+#pragma unroll
+    for (int p = 0; p < VILMA_MAX_P; ++p) {
+        if (p < P) {
+            const int lo = dot_start[p], hi = dot_start[p + 1];
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int r = lo + threadIdx.x;
+            for (; r + 3 * 1024 < hi; r += 4 * 1024) {
+                a0 += dot_partials[r];
+                a1 += dot_partials[r + 1024];
+                a2 += dot_partials[r + 2 * 1024];
+                a3 += dot_partials[r + 3 * 1024];
+            }
+            for (; r < hi; r += 1024) a0 += dot_partials[r];
+            acc[2 * VILMA_MAX_P + 2 + p] = (a0 + a1) + (a2 + a3);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < FIN_MAXC; ++c) {
+        const double s = wave_sum(acc[c]);
+        if (lane == 0) sh[w][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < FIN_MAXC) {
+        const int c = threadIdx.x;
+        double s = sh[0][c];
+#pragma unroll
+        for (int ww = 1; ww < 16; ++ww) s += sh[ww][c];
+        if (c < NT) totals[c < 2 * P ? c : (3 * P + (c - 2 * P))] = s;
+        else if (c >= 2 * VILMA_MAX_P + 2 && c - (2 * VILMA_MAX_P + 2) < P)
+            totals[2 * P + (c - (2 * VILMA_MAX_P + 2))] = s;
     }
 }
 
@@ -757,26 +803,31 @@ void launch_scatter_y(const double *pool_y, const int32_t *invperm, double *y_sn
 // --------------------------------------------------------------------------------------------
 // convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
 // --------------------------------------------------------------------------------------------
+#define MD_PER_THREAD 4
 __global__ __launch_bounds__(256) void mean_diff_kernel(const double *__restrict__ m_cur,
                                                          const double *__restrict__ scalings,
                                                          double *__restrict__ snapshot, int64_t PN,
                                                          double *__restrict__ partials, int compare) {
     __shared__ double red[4][6];
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double v[6] = {0, 0, 0, 0, 0, 0};
-    if (t < PN) {
-        const double nw = m_cur[t] * scalings[t];
-        if (compare) {
-            const double od = snapshot[t];
-            const double df = fabs(nw - od);
-            v[0] = (df <= 1e-6 + 1e-6 * fabs(od)) ? 0.0 : 1.0;
-            v[1] = df;
-            v[2] = df * df;
-            v[3] = fabs(nw);
-            v[4] = df;
-            v[5] = fabs((nw - od) / (od + 1e-100));
+    const int64_t base = (int64_t)blockIdx.x * 256 * MD_PER_THREAD + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < MD_PER_THREAD; ++u) {
+        const int64_t t = base + (int64_t)u * 256;
+        if (t < PN) {
+            const double nw = m_cur[t] * scalings[t];
+            if (compare) {
+                const double od = snapshot[t];
+                const double df = fabs(nw - od);
+                v[0] += (df <= 1e-6 + 1e-6 * fabs(od)) ? 0.0 : 1.0;
+                v[1] += df;
+                v[2] += df * df;
+                v[3] = fmax(v[3], fabs(nw));
+                v[4] = fmax(v[4], df);
+                v[5] = fmax(v[5], fabs((nw - od) / (od + 1e-100)));
+            }
+            snapshot[t] = nw;
         }
-        snapshot[t] = nw;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -795,29 +846,33 @@ __global__ __launch_bounds__(256) void mean_diff_kernel(const double *__restrict
 
 __global__ __launch_bounds__(1024) void mean_diff_final_kernel(const double *__restrict__ partials,
                                                                 int rows, double *__restrict__ out) {
-    __shared__ double sh[16];
-    for (int c = 0; c < 3; ++c) {
-        const double s = block_strided_sum_1024(partials + c, rows, 6, sh);
-        if (threadIdx.x == 0) out[c] = s;
-    }
-    for (int c = 3; c < 6; ++c) {
-        double s = 0.0;
-        for (int r0 = threadIdx.x; r0 < rows; r0 += 4 * 1024) {
-            double t[4];
+    __shared__ double sh[16][6];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = threadIdx.x; r < rows; r += 1024) {
+        const double *row = partials + (int64_t)r * 6;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * 1024;
-                const double x = partials[(int64_t)min(r, rows - 1) * 6 + c];
-                t[u] = r < rows ? x : 0.0;
-            }
-            s = fmax(s, fmax(fmax(t[0], t[1]), fmax(t[2], t[3])));
-        }
-        s = block_max_1024(s, sh);
-        if (threadIdx.x == 0) out[c] = s;
+        for (int c = 0; c < 3; ++c) acc[c] += row[c];
+#pragma unroll
+        for (int c = 3; c < 6; ++c) acc[c] = fmax(acc[c], row[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double s = c < 3 ? wave_sum(acc[c]) : wave_max(acc[c]);
+        if (lane == 0) sh[w][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        double s = sh[0][c];
+        for (int ww = 1; ww < 16; ++ww) s = c < 3 ? s + sh[ww][c] : fmax(s, sh[ww][c]);
+        out[c] = s;
     }
 }
 
-int mean_diff_grid(int64_t PN) { return (int)((PN + 255) / 256); }
+int mean_diff_grid(int64_t PN) {
+    return (int)((PN + 256 * MD_PER_THREAD - 1) / (256 * MD_PER_THREAD));
+}
 
 void launch_mean_diff(const double *m_cur, const double *scalings, double *snapshot, int64_t PN,
                       double *partials, double *out6, bool compare, hipStream_t s) {
