@@ -44,8 +44,6 @@ typedef struct vilma_ctx vilma_ctx;
  * (variational_inference.py:873-885) are assembled on the host after the all-reduce. */
 #define VILMA_NTOTALS(P) (3 * (P) + 2)
 
-/* number of doubles written by vilma_mean_diff */
-#define VILMA_NDIFF 6
 
 const char *vilma_version(void);
 
@@ -154,9 +152,14 @@ int vilma_trial_beta(vilma_ctx *ctx, void *stream, double step, double *totals_d
  * vilma_eval (vi_mu unchanged, only the moments / LD product move). */
 int vilma_accept(vilma_ctx *ctx, int take_mu);
 
-/* sums [A*M] = sum_annotations(vi_delta) of the current state (numerics.py:118-129), the
- * M-step statistic and the payload of the cross-GPU all-reduce. */
-int vilma_delta_sums(vilma_ctx *ctx, void *stream, double *sums_dev);
+/* sums [A*M] = sum_annotations(vi_delta) (numerics.py:118-129), the M-step statistic and the
+ * payload of the cross-GPU all-reduce, of the state `which`: the current state, or the trial
+ * state left by the last vilma_trial_beta / vilma_eval (so the statistic can be queued right
+ * behind a line-search trial and fetched with its objective, saving a host round trip). */
+#define VILMA_STATE_CURRENT 0
+#define VILMA_STATE_TRIAL_BETA 1   /* trial of vilma_trial_beta (its own vi_mu) */
+#define VILMA_STATE_TRIAL_EVAL 2   /* trial of vilma_eval (shares the current vi_mu) */
+int vilma_delta_sums(vilma_ctx *ctx, void *stream, double *sums_dev, int which);
 
 /* The M-step of _update_hyper_delta on the device, without a host round trip: from the
  * (all-reduced) sums_dev [A*M] of vilma_delta_sums compute
@@ -166,10 +169,10 @@ int vilma_mstep(vilma_ctx *ctx, void *stream, const double *sums_dev, double *hy
 
 /* Convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
  * between the current state and the snapshot taken by the previous call (or by
- * vilma_snapshot_mean): out_dev[0] = #entries violating |new-old| <= 1e-6 + 1e-6|old|,
- * [1] = sum |new-old|, [2] = sum (new-old)^2, [3] = max |new|, [4] = max |new-old|,
- * [5] = max |(new-old)/(old+1e-100)|.  Then the snapshot is replaced by the current mean. */
-int vilma_mean_diff(vilma_ctx *ctx, void *stream, double *out_dev);
+ * vilma_snapshot_mean): out_sum3_dev = {#entries violating |new-old| <= 1e-6 + 1e-6|old|,
+ * sum |new-old|, sum (new-old)^2} (additive over shards), out_max3_dev = {max |new|,
+ * max |new-old|, max |(new-old)/(old+1e-100)|}.  Then the snapshot becomes the current mean. */
+int vilma_mean_diff(vilma_ctx *ctx, void *stream, double *out_sum3_dev, double *out_max3_dev);
 int vilma_snapshot_mean(vilma_ctx *ctx, void *stream);
 
 /* Copy n doubles of a device result buffer to the host behind everything queued on `stream`

@@ -47,7 +47,7 @@ def engine_blocks(ld, form):
         n, r = b.u.shape
         f = form
         if form == 'auto':
-            f = 'dense' if 2 * r > n else 'eig'
+            f = 'dense' if 0.5 * n * n + 64.0 * n <= 2.0 * n * r else 'eig'
         if f == 'dense':
             out.append(('dense', (b.u * b.s) @ b.u.T))
         else:

@@ -35,13 +35,15 @@ class OracleEngine:
         self.mu_trial = None
         self.snap = None
         self._c = None
+        from vilma_amd.engine import ResultLayout
         self.n_totals = 3 * P + 2
-        am = A * M
-        self.results = torch.zeros(self.n_totals + 6 + 2 * am, dtype=torch.float64)
-        self._totals = self.results[:self.n_totals]
-        self._diff = self.results[self.n_totals:self.n_totals + 6]
-        self._hyper_t = self.results[self.n_totals + 6:self.n_totals + 6 + am]
-        self._sums = self.results[self.n_totals + 6 + am:]
+        self.layout = ResultLayout(self.n_totals, A * M)
+        L = self.layout
+        self.results = torch.zeros(L.size, dtype=torch.float64)
+        self._dsum, self._totals = self.results[L.dsum], self.results[L.totals]
+        self._sums, self._dmax = self.results[L.sums], self.results[L.dmax]
+        self._hyper_t = self.results[L.hyper]
+        self._last_trial_kind = None
 
     # ---- static data
     def set_snp_data(self, adj, se, sld, scalings, annot):
@@ -162,8 +164,9 @@ class OracleEngine:
             self.mu = self.mu_trial
         self.cur = self.trial_state
 
-    def delta_sums(self):
-        self._sums.copy_(torch.as_tensor(nm.sum_annotations(self.cur['delta'], self.annot,
+    def delta_sums(self, which=0):
+        st = self.cur if which == 0 else self.trial_state
+        self._sums.copy_(torch.as_tensor(nm.sum_annotations(st['delta'], self.annot,
                                                             self.A).ravel()))
         return self._sums
 
@@ -178,11 +181,12 @@ class OracleEngine:
                         np.abs(new).max(), df.max(), np.abs((new - old) / (old + 1e-100)).max()],
                        dtype=float)
         self.snap = new
-        self._diff.copy_(torch.as_tensor(out))
-        return self._diff
+        self._dsum.copy_(torch.as_tensor(out[:3]))
+        self._dmax.copy_(torch.as_tensor(out[3:]))
+        return torch.as_tensor(out)
 
-    def fetch(self, n):
-        return self.results[:n].numpy().copy()
+    def fetch(self):
+        return self.results.numpy().copy()
 
     def close(self):
         pass

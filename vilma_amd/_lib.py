@@ -21,7 +21,7 @@ def ntotals(P):
     return 3 * P + 2
 
 
-NDIFF = 6
+STATE_CURRENT, STATE_TRIAL_BETA, STATE_TRIAL_EVAL = 0, 1, 2
 
 _c_double_p = C.POINTER(C.c_double)
 _c_i32_p = C.POINTER(C.c_int32)
@@ -66,8 +66,8 @@ def load():
         'vilma_eval': (C.c_int, [vp, vp, vp]),
         'vilma_trial_beta': (C.c_int, [vp, vp, C.c_double, vp]),
         'vilma_accept': (C.c_int, [vp, C.c_int]),
-        'vilma_delta_sums': (C.c_int, [vp, vp, vp]),
-        'vilma_mean_diff': (C.c_int, [vp, vp, vp]),
+        'vilma_delta_sums': (C.c_int, [vp, vp, vp, C.c_int]),
+        'vilma_mean_diff': (C.c_int, [vp, vp, vp, vp]),
         'vilma_snapshot_mean': (C.c_int, [vp, vp]),
         'vilma_fetch': (C.c_int, [vp, vp, vp, vp, C.c_int64]),
         'vilma_prof_enable': (C.c_int, [vp, C.c_int]),

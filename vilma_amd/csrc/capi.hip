@@ -316,11 +316,12 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
 }
 
-void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out) {
+void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out, bool trial_mu = false,
+                     bool trial_mom = false) {
     a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
-    a.mu = c->mu[c->mu_cur]; a.sld = c->sld; a.annot = c->annot;
+    a.mu = c->mu[trial_mu ? 1 - c->mu_cur : c->mu_cur]; a.sld = c->sld; a.annot = c->annot;
     a.prec = c->prec; a.log_det = c->log_det; a.lh = c->lh;
-    a.lse = c->lse[c->mom_cur];
+    a.lse = c->lse[trial_mom ? 1 - c->mom_cur : c->mom_cur];
     a.out = out;
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
 }
@@ -659,21 +660,25 @@ int vilma_accept(vilma_ctx *c, int take_mu) {
     return 0;
 }
 
-int vilma_delta_sums(vilma_ctx *c, void *stream, double *sums_dev) {
+int vilma_delta_sums(vilma_ctx *c, void *stream, double *sums_dev, int which) {
     if (!c) return 1;
-    if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    if (which == VILMA_STATE_CURRENT && !c->have_moments)
+        return fail(c, "no accepted evaluation of the current state");
+    if (which != VILMA_STATE_CURRENT && !c->ready) return fail(c, "no trial state");
     DeltaArgs a;
-    fill_delta_args(c, a, c->delta_partials);
+    // the trial of a beta step has its own vi_mu; the trial of a plain evaluation shares it
+    fill_delta_args(c, a, c->delta_partials, which == VILMA_STATE_TRIAL_BETA,
+                    which != VILMA_STATE_CURRENT);
     launch_delta_sums(a, sums_dev, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
-int vilma_mean_diff(vilma_ctx *c, void *stream, double *out_dev) {
+int vilma_mean_diff(vilma_ctx *c, void *stream, double *out_sum3_dev, double *out_max3_dev) {
     if (!c) return 1;
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,
-                     c->diff_partials, out_dev, true, (hipStream_t)stream);
+                     c->diff_partials, out_sum3_dev, out_max3_dev, true, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -682,7 +687,7 @@ int vilma_snapshot_mean(vilma_ctx *c, void *stream) {
     if (!c) return 1;
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,
-                     c->diff_partials, nullptr, false, (hipStream_t)stream);
+                     c->diff_partials, nullptr, nullptr, false, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

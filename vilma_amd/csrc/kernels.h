@@ -104,5 +104,6 @@ void launch_mstep(const double *sums, const double *counts, const double *log_de
                   double *hyper, double *lh, hipStream_t s);
 
 void launch_mean_diff(const double *m_cur, const double *scalings, double *snapshot, int64_t PN,
-                      double *partials, double *out6, bool compare, hipStream_t s);
+                      double *partials, double *out_sum3, double *out_max3, bool compare,
+                      hipStream_t s);
 int mean_diff_grid(int64_t PN);

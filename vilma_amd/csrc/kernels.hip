@@ -845,7 +845,8 @@ __global__ __launch_bounds__(256) void mean_diff_kernel(const double *__restrict
 }
 
 __global__ __launch_bounds__(1024) void mean_diff_final_kernel(const double *__restrict__ partials,
-                                                                int rows, double *__restrict__ out) {
+                                                                int rows, double *__restrict__ out_sum,
+                                                                double *__restrict__ out_max) {
     __shared__ double sh[16][6];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(1024) void mean_diff_final_kernel(const double *__r
         const int c = threadIdx.x;
         double s = sh[0][c];
         for (int ww = 1; ww < 16; ++ww) s = c < 3 ? s + sh[ww][c] : fmax(s, sh[ww][c]);
-        out[c] = s;
+        if (c < 3) out_sum[c] = s; else out_max[c - 3] = s;
     }
 }
 
@@ -875,12 +876,14 @@ int mean_diff_grid(int64_t PN) {
 }
 
 void launch_mean_diff(const double *m_cur, const double *scalings, double *snapshot, int64_t PN,
-                      double *partials, double *out6, bool compare, hipStream_t s) {
+                      double *partials, double *out_sum3, double *out_max3, bool compare,
+                      hipStream_t s) {
     const int grid = mean_diff_grid(PN);
     hipLaunchKernelGGL(mean_diff_kernel, dim3(grid), dim3(256), 0, s, m_cur, scalings, snapshot, PN,
                        partials, compare ? 1 : 0);
     if (compare)
-        hipLaunchKernelGGL(mean_diff_final_kernel, dim3(1), dim3(1024), 0, s, partials, grid, out6);
+        hipLaunchKernelGGL(mean_diff_final_kernel, dim3(1), dim3(1024), 0, s, partials, grid,
+                           out_sum3, out_max3);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -19,6 +19,19 @@ def _ptr(a):
     return C.c_void_p(a.ctypes.data)
 
 
+class ResultLayout:
+    """Slices of an engine's result vector (shared by the HIP engine and the test engine)."""
+
+    def __init__(self, nt, am):
+        self.nt, self.am = nt, am
+        self.dsum = slice(0, 3)
+        self.totals = slice(3, 3 + nt)
+        self.sums = slice(3 + nt, 3 + nt + am)
+        self.dmax = slice(3 + nt + am, 6 + nt + am)
+        self.hyper = slice(6 + nt + am, 6 + nt + 2 * am)
+        self.size = 6 + nt + 2 * am
+
+
 class HipEngine:
     """One GPU, one shard: P cohorts x N SNPs x M mixture components, A annotations."""
 
@@ -37,17 +50,20 @@ class HipEngine:
         if self.lib.vilma_create(self.P, self.N, self.M, self.A, C.byref(ctx)):
             raise _lib.VilmaHipError(self.lib.vilma_last_error(None).decode())
         self.ctx = ctx
-        # one device tensor for every small result, so a decision needs a single D2H copy:
-        # [totals (3P+2) | convergence stats (6) | hyper_delta (A*M) | delta sums (A*M)]
+        # One device tensor for every small result, so a decision needs a single D2H copy and the
+        # parts that are summed over ranks are contiguous:
+        #   [diff sums (3) | totals (3P+2) | delta sums (A*M) | diff maxima (3) | hyper (A*M)]
         nt, am = _lib.ntotals(self.P), self.A * self.M
-        self.results = torch.zeros(nt + _lib.NDIFF + 2 * am, dtype=torch.float64,
-                                   device=self.device)
-        self._totals = self.results[:nt]
-        self._diff = self.results[nt:nt + _lib.NDIFF]
-        self._hyper = self.results[nt + _lib.NDIFF:nt + _lib.NDIFF + am]
-        self._sums = self.results[nt + _lib.NDIFF + am:]
+        self.layout = ResultLayout(nt, am)
+        self.results = torch.zeros(self.layout.size, dtype=torch.float64, device=self.device)
+        L = self.layout
+        self._dsum = self.results[L.dsum]
+        self._totals = self.results[L.totals]
+        self._sums = self.results[L.sums]
+        self._dmax = self.results[L.dmax]
+        self._hyper = self.results[L.hyper]
         self.n_totals = nt
-        self._host = np.zeros(self.results.numel())
+        self._host = np.zeros(L.size)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -193,21 +209,23 @@ class HipEngine:
     def accept(self, take_mu):
         self._check(self.lib.vilma_accept(self.ctx, 1 if take_mu else 0))
 
-    def fetch(self, n):
-        """results[:n] on the host (one pinned D2H copy behind the current stream)."""
+    def fetch(self):
+        """The whole result vector on the host (one pinned D2H copy behind the current stream)."""
         self._check(self.lib.vilma_fetch(self.ctx, self._stream(),
-                                         C.c_void_p(self.results.data_ptr()), _ptr(self._host), n))
-        return self._host[:n].copy()
+                                         C.c_void_p(self.results.data_ptr()), _ptr(self._host),
+                                         self.layout.size))
+        return self._host.copy()
 
-    def delta_sums(self):
+    def delta_sums(self, which=_lib.STATE_CURRENT):
         self._check(self.lib.vilma_delta_sums(self.ctx, self._stream(),
-                                              C.c_void_p(self._sums.data_ptr())))
+                                              C.c_void_p(self._sums.data_ptr()), which))
         return self._sums
 
     def mean_diff(self):
         self._check(self.lib.vilma_mean_diff(self.ctx, self._stream(),
-                                             C.c_void_p(self._diff.data_ptr())))
-        return self._diff
+                                             C.c_void_p(self._dsum.data_ptr()),
+                                             C.c_void_p(self._dmax.data_ptr())))
+        return self.torch.cat([self._dsum, self._dmax])
 
     def snapshot_mean(self):
         self._check(self.lib.vilma_snapshot_mean(self.ctx, self._stream()))

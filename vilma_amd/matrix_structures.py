@@ -27,6 +27,11 @@ def _svd_threshold(matrix, ld_thresh):
     return u, np.array(w[sel]), np.array(u.T)
 
 
+def dense_is_cheaper(n, r):
+    """Bytes per product: dense symmetric (lower triangle by 128-column slabs) vs eigen form."""
+    return 0.5 * n * n + 64.0 * n <= 2.0 * n * r
+
+
 class LowRankMatrix:
     """Symmetric block stored as u diag(s) v + diag(D), v = u^T
     (reference matrix_structures.py:38-234)."""
@@ -143,14 +148,15 @@ class BlockDiagonalMatrix:
 
     # -- device operator -------------------------------------------------------------------
     def device_blocks(self, form='auto'):
-        """Blocks in the form the HIP LD store takes: dense reconstruction when the kept rank
-        exceeds n/2 (n^2 <= 2 n r bytes), eigen form otherwise."""
+        """Blocks in the form the HIP LD store takes, chosen by bytes streamed per product: the
+        dense symmetric form reads the lower triangle once (~n^2/2 + 64 n elements), the eigen
+        form reads U and diag(s)U^T (2 n r) -- so eigen form only when r < n/4 + 32."""
         out = []
         for m in self.matrices:
             n, r = m.u.shape
             if not np.allclose(m.D, 0):
                 raise NotImplementedError('device LD blocks must have a zero diagonal part')
-            dense = form == 'dense' or (form == 'auto' and 2 * r > n)
+            dense = form == 'dense' or (form == 'auto' and dense_is_cheaper(n, r))
             out.append(('dense', m.reconstruct()) if dense else ('eig', m.u, m.s))
         return out
 

@@ -97,10 +97,11 @@ class Comm:
 
 def block_costs(ld):
     """Bytes one product with each block streams in the form the device will hold it."""
+    from .matrix_structures import dense_is_cheaper
     out = []
     for m in ld.matrices:
         n, r = m.u.shape
-        out.append(8.0 * (n * n if 2 * r > n else 2 * n * r))
+        out.append(8.0 * (0.5 * n * n + 64.0 * n if dense_is_cheaper(n, r) else 2.0 * n * r))
     return np.asarray(out)
 
 

@@ -165,6 +165,8 @@ class SweepDriver:
         self._want_diff = False
         self.engine.set_annotation_counts(self.annotation_counts)
         self._last_diff = None      # convergence statistics fetched together with an evaluation
+        self._cur_sums = None       # all-reduced responsibility sums of the current state, if known
+        self._trial_sums = None
         self._verbose = False
         self._version = 0           # bumped whenever the device state moves
         self._hyper = None
@@ -194,33 +196,49 @@ class SweepDriver:
             - 0.5 * self.ld_ranks * np.log(tau)
         return float(lik.sum() - (t[3 * P] + t[3 * P + 1]))
 
-    def _fetch(self, with_diff=False, with_hyper=False):
-        """All-reduce and download the engine's result vector in ONE device->host copy:
-        [totals | convergence statistics | hyper_delta].  Sums are all-reduced over the ranks
-        (RCCL); the maxima of the statistics only when INFO logging wants them."""
+    def _fetch(self, with_sums=False, with_diff=False):
+        """All-reduce what has to be summed over ranks (ONE RCCL all-reduce on a contiguous part
+        of the engine's result vector) and download the whole vector in ONE device->host copy.
+        Returns the host copy; slices are in engine.layout."""
         eng = self.engine
-        nt, am = eng.n_totals, self.num_annotations * self.num_mix
+        L = eng.layout
         if self.comm.world > 1:
-            self.comm.allreduce_inplace(eng.results[:nt + (3 if with_diff else 0)])
+            lo = L.dsum.start if with_diff else L.totals.start
+            hi = L.sums.stop if with_sums else L.totals.stop
+            self.comm.allreduce_inplace(eng.results[lo:hi])
             if with_diff and self._verbose:
-                self.comm.allreduce_inplace(eng.results[nt + 3:nt + 6], op='max')
-        upto = nt + 6 + am if with_hyper else (nt + 6 if with_diff else nt)
-        return eng.fetch(upto)
+                self.comm.allreduce_inplace(eng.results[L.dmax], op='max')
+        return eng.fetch()
 
-    def _evaluate(self, step=None):
+    def _evaluate(self, step=None, with_sums=False):
         """Objective of a candidate point: the current vi_mu (step None) or a natural-gradient
-        trial at `step`.  The candidate stays on the device as the trial state."""
+        trial at `step`.  The candidate stays on the device as the trial state.  with_sums also
+        queues the responsibility sums of the candidate (the M-step statistic) so that an
+        accepted candidate needs no second round trip."""
+        from . import _lib
         if step is None:
             self.engine.eval()
+            which = _lib.STATE_TRIAL_EVAL
         else:
             self.engine.trial(step)
-        totals = self._fetch()
+            which = _lib.STATE_TRIAL_BETA
+        if with_sums:
+            # this overwrites the device copy of the sums: whatever was there (the current
+            # state's, from the accepted trial before) is gone until this candidate is accepted
+            self._cur_sums = None
+            self.engine.delta_sums(which)
+        host = self._fetch(with_sums=with_sums)
+        L = self.engine.layout
+        totals = host[L.totals]
+        self._trial_sums = host[L.sums] if with_sums else None
         self.n_evaluations += 1
         return self._objective_from(totals), totals
 
     def _accept(self, take_mu, obj, totals):
         self.engine.accept(take_mu)
         self._objective, self._totals = obj, totals
+        # responsibility sums fetched with the candidate now describe the current state
+        self._cur_sums, self._trial_sums = self._trial_sums, None
         self._version += 1
 
     def _install_hyper(self, hyper):
@@ -261,7 +279,7 @@ class SweepDriver:
             raise RuntimeError('nat_grad_vi_delta must always be set prior to running '
                                '_update_beta')
         while True:
-            new_obj, totals = self._evaluate(1. / L[idx])
+            new_obj, totals = self._evaluate(1. / L[idx], with_sums=True)
             self.n_trials += 1
             logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
             if new_obj >= orig_obj - REL_TOL * np.abs(orig_obj) - ABS_TOL:
@@ -277,26 +295,31 @@ class SweepDriver:
 
     def _update_hyper_delta(self, orig_obj, with_diff=False):
         """Closed-form M-step for the mixture weights (variational_inference.py:825-860), all on
-        the device: responsibility sums -> (all-reduce) -> new hyper_delta and its table ->
-        re-evaluation, then ONE download of [sums of the new state | statistics | hyper_delta].
+        the device: responsibility sums (already all-reduced if they came with the accepted beta
+        trial) -> new hyper_delta and its table -> re-evaluation, then ONE download.
         The update is unconditional in the reference, so it is accepted before the download."""
         eng = self.engine
-        sums = eng.delta_sums()
-        if self.comm.world > 1:
-            self.comm.allreduce_inplace(sums)
-        eng.mstep(sums)
+        L = eng.layout
+        if self._cur_sums is None:
+            # no accepted beta step since the last evaluation (line search gave up or resumed
+            # state): compute the statistic of the current state now
+            sums = eng.delta_sums()
+            if self.comm.world > 1:
+                self.comm.allreduce_inplace(sums)
+        # the sums of the accepted trial are still in the result vector (all-reduced in place)
+        eng.mstep()
         eng.eval()
         eng.accept(False)
         if with_diff:
             eng.mean_diff()
-        host = self._fetch(with_diff=with_diff, with_hyper=True)
-        nt = eng.n_totals
-        totals = host[:nt]
-        self._install_hyper(host[nt + 6:].reshape(self.num_annotations, self.num_mix))
-        self._last_diff = host[nt:nt + 6] if with_diff else None
+        host = self._fetch(with_diff=with_diff)
+        totals = host[L.totals]
+        self._install_hyper(host[L.hyper].reshape(self.num_annotations, self.num_mix))
+        self._last_diff = np.concatenate([host[L.dsum], host[L.dmax]]) if with_diff else None
         new_obj = self._objective_from(totals)
         self.n_evaluations += 1
         self._objective, self._totals = new_obj, totals
+        self._cur_sums = self._trial_sums = None
         self._version += 1
         logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
         return orig_obj, new_obj
@@ -367,12 +390,13 @@ class SweepDriver:
             d, self._last_diff = self._last_diff, None
             return d
         self.engine.mean_diff()
-        nt = self.engine.n_totals
+        L = self.engine.layout
         if self.comm.world > 1:
-            self.comm.allreduce_inplace(self.engine.results[nt:nt + 3])
+            self.comm.allreduce_inplace(self.engine.results[L.dsum])
             if self._verbose:
-                self.comm.allreduce_inplace(self.engine.results[nt + 3:nt + 6], op='max')
-        return self.engine.fetch(nt + 6)[nt:]
+                self.comm.allreduce_inplace(self.engine.results[L.dmax], op='max')
+        host = self.engine.fetch()
+        return np.concatenate([host[L.dsum], host[L.dmax]])
 
     def sweep(self, state=None):
         """One outer iteration as optimize() runs it: _optimize_step + convergence statistics.
