@@ -106,11 +106,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    # rehearsal knobs (tests only): several ranks on one GPU over gloo
+    if os.environ.get('VILMA_BENCH_SAME_DEVICE') == '1':
+        local_rank = 0
+    backend = os.environ.get('VILMA_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
     comm = Comm()
 
     cfg = dict(WORKLOADS[args.workload])
@@ -168,9 +175,7 @@ def main():
     dom = max(('ld_sym_kernel', 'ld_colsum_kernel'), key=lambda k: prof[k][0])
     kernel_ms, launches = prof[dom]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(comm.allreduce_np(np.array([elapsed]), op='max')[0])
 
     n_eval = driver.n_evaluations - ev0
     alg_launch = float(engine.ld_bytes()[0])            # this rank's LD bytes per launch

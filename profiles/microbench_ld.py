@@ -17,12 +17,14 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--rank-frac', type=float, default=0.28)
     ap.add_argument('--workload', default='C3')
+    ap.add_argument('--shard', type=int, default=1, help='use blocks [0, B/shard) only')
     args = ap.parse_args()
     import torch
     from vilma_amd.engine import HipEngine
     from vilma_amd.synthetic import WORKLOADS, block_sizes
     cfg = WORKLOADS[args.workload]
     sizes = block_sizes(cfg['n_ld'], cfg['B'], cfg['fixed'], 0)
+    sizes = sizes[:len(sizes) // args.shard]
     P, N = cfg['P'], int(sizes.sum())
     dev = torch.device('cuda', 0)
     nmax = int(sizes.max())
