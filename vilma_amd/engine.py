@@ -50,6 +50,7 @@ class HipEngine:
         if self.lib.vilma_create(self.P, self.N, self.M, self.A, C.byref(ctx)):
             raise _lib.VilmaHipError(self.lib.vilma_last_error(None).decode())
         self.ctx = ctx
+        self.refresh_stream()
         # One device tensor for every small result, so a decision needs a single D2H copy and the
         # parts that are summed over ranks are contiguous:
         #   [diff sums (3) | totals (3P+2) | delta sums (A*M) | diff maxima (3) | hyper (A*M)]
@@ -71,7 +72,13 @@ class HipEngine:
             raise _lib.VilmaHipError(self.lib.vilma_last_error(self.ctx).decode())
 
     def _stream(self):
-        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        return self._stream_handle
+
+    def refresh_stream(self):
+        """Bind the engine to torch's current HIP stream (kernels, RCCL all-reduces issued through
+        torch and the fetch then share one ordering).  Called at construction and by the driver
+        at the start of every sweep; looking the stream up per launch costs microseconds."""
+        self._stream_handle = C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
 
     def close(self):
         if getattr(self, 'ctx', None):

@@ -19,6 +19,7 @@ where the work happens:
     sums are all-reduced (RCCL) before every decision, so all ranks take the same branch.
 """
 import logging
+import math
 
 import numpy as np
 
@@ -190,11 +191,13 @@ class SweepDriver:
         """fast_likelihood (numerics.py:31-46) minus _beta_KL (variational_inference.py:873-885)
         from the all-reduced sums."""
         P = self.num_pops
-        lin, var, quad = t[:P], t[P:2 * P], t[2 * P:3 * P]
-        tau = self.error_scaling
-        lik = (-0.5 * (var + quad) + lin - 0.5 * self.chi_stat) / tau \
-            - 0.5 * self.ld_ranks * np.log(tau)
-        return float(lik.sum() - (t[3 * P] + t[3 * P + 1]))
+        t = t.tolist()
+        tau, chi, rk = self.error_scaling, self.chi_stat, self.ld_ranks
+        lik = 0.0
+        for p in range(P):          # P <= 4: plain floats beat small-array numpy here
+            lik += ((-0.5 * (t[P + p] + t[2 * P + p]) + t[p] - 0.5 * chi[p]) / tau[p]
+                    - 0.5 * rk[p] * math.log(tau[p]))
+        return lik - (t[3 * P] + t[3 * P + 1])
 
     def _fetch(self, with_sums=False, with_diff=False):
         """All-reduce what has to be summed over ranks (ONE RCCL all-reduce on a contiguous part
@@ -282,7 +285,9 @@ class SweepDriver:
             new_obj, totals = self._evaluate(1. / L[idx], with_sums=True)
             self.n_trials += 1
             logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
-            if new_obj >= orig_obj - REL_TOL * np.abs(orig_obj) - ABS_TOL:
+            # scalar arithmetic on Python floats: np.isclose & co cost ~20 us per call, which is
+            # visible next to a 150 us evaluation on an 8-GPU shard
+            if new_obj >= orig_obj - REL_TOL * abs(orig_obj) - ABS_TOL:
                 if L[idx] > L_MAX and not np.isclose(orig_obj, new_obj):
                     raise RuntimeError('Encountered a numerical error.')
                 self._accept(True, new_obj, totals)
@@ -346,8 +351,8 @@ class SweepDriver:
             logging.info('...Updating paramset %d, L=%f', 0, L[0])
             orig_obj, new_obj = self._update_beta(L, 0, line_search_rate, orig_obj)
             delta_sum += new_obj - orig_obj
-            if (np.isclose(new_obj - orig_obj, 0, atol=conv_tol, rtol=0)
-                    or L[0] == 1 or L[0] > L_MAX):
+            # == np.isclose(new_obj - orig_obj, 0, atol=conv_tol, rtol=0) for finite objectives
+            if abs(new_obj - orig_obj) <= conv_tol or L[0] == 1 or L[0] > L_MAX:
                 break
             orig_obj = new_obj
         # ---- paramset 1: mixture weights (L[1] stays 1, so exactly one pass)
@@ -373,6 +378,8 @@ class SweepDriver:
     def _optimize_step(self, params, L, curr_elbo, line_search_rate=1.25,
                        running_elbo_delta=None):
         """variational_inference.py:396-410."""
+        if hasattr(self.engine, 'refresh_stream'):
+            self.engine.refresh_stream()
         self._upload(params)
         logging.info('Current ELBO = %f and L = %f,%f,%f,%f,%f', curr_elbo, *L[:5])
         L_new, elbo_change = self._nat_grad_step(L, line_search_rate, running_elbo_delta)
@@ -380,7 +387,7 @@ class SweepDriver:
         if running_elbo_delta is None:
             running_elbo_delta = elbo_change
         running_elbo_delta *= ELBO_MOMENTUM
-        running_elbo_delta += (1 - ELBO_MOMENTUM) * np.maximum(elbo_change, 0)
+        running_elbo_delta += (1 - ELBO_MOMENTUM) * max(elbo_change, 0)
         return self._params(), L_new, elbo, running_elbo_delta
 
     def _diff_stats(self):
@@ -449,7 +456,7 @@ class SweepDriver:
                 params, L=L, curr_elbo=elbo, line_search_rate=2., running_elbo_delta=running)
             d = self._diff_stats()
             converged = d[0] == 0
-            converged = converged or bool(np.isclose(running, 0, atol=ELBO_TOL, rtol=0))
+            converged = converged or abs(running) <= ELBO_TOL
             if num_its < 10 and loaded_checkpoint is None:
                 converged = False
             if verbose:
