@@ -37,10 +37,14 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='C3')
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--ld-form', default='auto', choices=['auto', 'dense', 'eig'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-blocks', type=int, default=96,
                     help='blocks of the workload in the CPU-baseline sample')
     ap.add_argument('--cpu-sweeps', type=int, default=5)
+    ap.add_argument('--emulate-shard', type=int, default=0,
+                    help='diagnostic: time rank 0 of a K-way sharding alone on one GPU '
+                         '(no collectives; NOT a valid bench line)')
     return ap.parse_args()
 
 
@@ -122,7 +126,10 @@ def main():
 
     cfg = dict(WORKLOADS[args.workload])
     t_setup = time.perf_counter()
-    shard = SyntheticShard(seed=args.seed, rank=rank, world=world, **cfg).build(device)
+    if args.emulate_shard > 1:
+        shard = SyntheticShard(seed=args.seed, rank=0, world=args.emulate_shard, **cfg).build(device)
+    else:
+        shard = SyntheticShard(seed=args.seed, rank=rank, world=world, **cfg).build(device)
     P, M = shard.P, shard.M
     g = comm.allreduce_np(np.concatenate([shard.chi_local, shard.rank_local, shard.inv_se2_local]))
     chi, ranks, inv_se2 = g[:P], g[P:2 * P], g[2 * P:]
@@ -134,8 +141,12 @@ def main():
     log_det = np.linalg.slogdet(shard.covs)[1]
     engine.set_mixture(prec, log_det)
     for p in range(P):
-        engine.load_ld(p, shard.ld_blocks_torch(p, device), shard.perm, shard.n_ld,
-                       specs=shard.block_specs())
+        if shard.kind == 'lowrank':
+            engine.load_ld(p, shard.ld_blocks_torch(p, device, args.ld_form), shard.perm,
+                           shard.n_ld, specs=shard.block_specs(args.ld_form))
+        else:
+            engine.load_ld(p, shard.ld_blocks_torch(p, device), shard.perm, shard.n_ld,
+                           specs=shard.block_specs())
     torch.cuda.synchronize()
 
     driver = SweepDriver()
@@ -174,11 +185,15 @@ def main():
     # the dominant kernel = the LD-streaming kernel with the most accumulated time
     dom = max(('ld_sym_kernel', 'ld_colsum_kernel'), key=lambda k: prof[k][0])
     kernel_ms, launches = prof[dom]
+    if dom == 'ld_colsum_kernel':
+        # the eigen form takes two launches (U^T x, then diag(s)U^T transposed) per product:
+        # quote the pair as one launch of the product
+        launches //= 2
     if world > 1:
         elapsed = float(comm.allreduce_np(np.array([elapsed]), op='max')[0])
 
     n_eval = driver.n_evaluations - ev0
-    alg_launch = float(engine.ld_bytes()[0])            # this rank's LD bytes per launch
+    alg_launch = float(shard.ld_bytes)                   # this rank's algorithmic LD bytes per product
     avg_ms = kernel_ms / max(launches, 1)
     achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     state_bytes = 8.0 * shard.N * (2 * M * P)            # per-SNP pass: read mu, write mu'
@@ -192,19 +207,22 @@ def main():
             traffic = None
 
     out = {
-        'metric': 'full VI sweeps/sec (1M SNPs, 2 cohorts)' if args.workload == 'C3'
-                  else 'full VI sweeps/sec',
+        'metric': ('DIAGNOSTIC shard emulation' if args.emulate_shard > 1 else
+                   'full VI sweeps/sec (1M SNPs, 2 cohorts)' if args.workload == 'C3'
+                   else 'full VI sweeps/sec'),
         'value': args.steps / elapsed, 'unit': 'sweeps/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
         'data': 'synthetic',
         'config': {
-            'workload': '%s: %d cohorts, %d SNPs (%d in %d AR(1) LD blocks + %d LD-missing), '
-                        'M=%d mixture components, dense-rank fp64 LD %.2f GB, A=1, no '
+            'workload': '%s: %d cohorts, %d SNPs (%d in %d %s LD blocks + %d LD-missing), '
+                        'M=%d mixture components, fp64 LD %.2f GB algorithmic (%s), A=1, no '
                         '--learn-scaling' % (args.workload, P, shard.N_global, shard.n_ld_global,
                                              len(shard.sizes_all),
+                                             'AR(1)' if shard.kind == 'ar1' else 'eigen-form (rank %.2f n)' % shard.rank_frac,
                                              shard.N_global - shard.n_ld_global, M,
-                                             8e-9 * P * float((shard.sizes_all.astype(np.float64) ** 2).sum())),
+                                             8e-9 * P * float((shard.sizes_all.astype(np.float64) * (shard.sizes_all if shard.kind == 'ar1' else np.maximum(1, np.round(shard.rank_frac * shard.sizes_all)))).sum()),
+                                             'dense rank, 8 n^2' if shard.kind == 'ar1' else '8 n r, U counted once'),
             'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
             'points_evaluated_per_sweep': n_eval / args.steps,
             'beta_trials_per_sweep': (driver.n_trials - tr0) / args.steps,

@@ -135,3 +135,36 @@ def test_synthetic_closed_form_constants_match_class_api():
     np.testing.assert_allclose(vi.ld_ranks, sh.rank_local)
     np.testing.assert_allclose(vi.inverse_betas, sh.inverse_betas, rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(vi.ld_diags, sh.ld_diags, atol=1e-12)
+
+
+def test_synthetic_eigen_form_constants_match_class_api():
+    """The C4-style workload gives LD directly as (U, s); its closed-form constants equal what the
+    class API derives from LowRankMatrix(u, s, v, D=0), and both LD storage forms fit alike."""
+    import torch
+    from vilma_amd.synthetic import SyntheticShard, WORKLOADS
+    from vilma_amd.matrix_structures import LowRankMatrix, BlockDiagonalMatrix
+    from vilma_amd.variational_inference import MultiPopVI
+    dev = torch.device('cuda', 0)
+    sh = SyntheticShard(seed=4, **WORKLOADS['tiny4']).build(dev)
+    sh.finish_init(sh.inv_se2_local)
+    ld = []
+    for p in range(sh.P):
+        mats = []
+        for U, sv in sh._eig[p]:
+            u = U.cpu().numpy()
+            mats.append(LowRankMatrix(u=u, s=sv.cpu().numpy(), v=u.T.copy(), D=np.zeros(u.shape[0])))
+        ld.append(BlockDiagonalMatrix(mats, perm=sh.perm, missing=sh.missing))
+    elbos = {}
+    for form in ('eig', 'dense'):
+        vi = MultiPopVI(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
+                        mixture_covs=list(sh.covs), annotations=np.ones((sh.N, 1)),
+                        checkpoint=False, gwas_N=sh.gwas_N, init_hg=sh.init_hg, num_its=3, form=form)
+        np.testing.assert_allclose(vi.adj_marginal_effects, sh.adj, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(vi.chi_stat, sh.chi_local, rtol=1e-8)
+        np.testing.assert_allclose(vi.ld_ranks, sh.rank_local)
+        np.testing.assert_allclose(vi.ld_diags, sh.ld_diags, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(vi.inverse_betas, sh.inverse_betas, rtol=1e-6, atol=1e-10)
+        np.random.seed(1)
+        vi.optimize()
+        elbos[form] = vi._objective
+    assert abs(elbos['eig'] - elbos['dense']) < 1e-9 * abs(elbos['eig'])

@@ -19,6 +19,11 @@ WORKLOADS = {
     'C2': dict(P=1, n_ld=100_000, B=500, M=25, fixed=200, missing_frac=0.0),
     'C3': dict(P=2, n_ld=1_000_000, B=1700, M=40, fixed=None, missing_frac=0.05),
     'tiny': dict(P=2, n_ld=6_000, B=12, M=12, fixed=None, missing_frac=0.05),
+    # C4: as C3 but eigen-truncated LD (what --ldthresh 0.8 leaves: kept rank ~0.28 n)
+    'C4': dict(P=2, n_ld=1_000_000, B=1700, M=40, fixed=None, missing_frac=0.05,
+               kind='lowrank', rank_frac=0.28),
+    'tiny4': dict(P=2, n_ld=6_000, B=12, M=12, fixed=None, missing_frac=0.05,
+                  kind='lowrank', rank_frac=0.28),
 }
 
 
@@ -103,8 +108,9 @@ class SyntheticShard:
     perm per cohort, and a generator of LD blocks (numpy or device tensors)."""
 
     def __init__(self, P, n_ld, B, M, fixed=None, missing_frac=0.0, seed=0, rank=0, world=1,
-                 gwas_N=1e5, init_hg=0.1, block_range=None):
+                 gwas_N=1e5, init_hg=0.1, block_range=None, kind='ar1', rank_frac=0.28):
         self.P, self.M, self.A, self.seed = P, M, 1, seed
+        self.kind, self.rank_frac = kind, rank_frac
         self.gwas_N = np.full(P, gwas_N, dtype=np.float64)
         self.init_hg = np.full(P, init_hg, dtype=np.float64)
         self.sizes_all = block_sizes(n_ld, B, fixed, seed)
@@ -133,22 +139,42 @@ class SyntheticShard:
                         else np.zeros(0, dtype=np.int64))
         self.perm = np.concatenate([self.ld_snps, self.missing])
         self.covs = mixture_covs(P, M)
-        self.ld_bytes = 8 * int((self.sizes.astype(np.int64) ** 2).sum()) * P
+        self.ranks = (self.sizes if kind == 'ar1' else
+                      np.maximum(1, np.round(rank_frac * self.sizes)).astype(np.int64))
+        # algorithmic bytes of one product: 8 n^2 dense, 8 n r eigen form
+        self.ld_bytes = 8 * int((self.sizes.astype(np.int64) * self.ranks).sum()) * P
+        self._eig = None          # per (cohort, block): (U, s) device tensors, lowrank kind
 
     # ------------------------------------------------------------------ LD blocks
     def ld_blocks_numpy(self, p):
         for blk in self.blocks:
             yield ('dense', ar1_numpy(blk.n, blk.rho[p]))
 
-    def ld_blocks_torch(self, p, device):
+    def ld_blocks_torch(self, p, device, form='auto'):
         import torch
+        if self.kind == 'lowrank':
+            from .matrix_structures import dense_is_cheaper
+            for (U, sv) in self._eig[p]:
+                n, r = U.shape
+                if form == 'dense' or (form == 'auto' and dense_is_cheaper(n, r)):
+                    yield ('dense', (U * sv) @ U.T)
+                else:
+                    yield ('eig', U, sv)
+            return
         for blk in self.blocks:
             idx = torch.arange(blk.n, device=device, dtype=torch.float64)
             yield ('dense', torch.pow(torch.tensor(float(blk.rho[p]), device=device,
                                                    dtype=torch.float64),
                                       (idx[:, None] - idx[None, :]).abs()))
 
-    def block_specs(self):
+    def block_specs(self, form='auto'):
+        if self.kind == 'lowrank':
+            from .matrix_structures import dense_is_cheaper
+            out = []
+            for n, r in zip(self.sizes, self.ranks):
+                dense = form == 'dense' or (form == 'auto' and dense_is_cheaper(int(n), int(r)))
+                out.append(('dense', int(n), int(n)) if dense else ('eig', int(n), int(r)))
+            return out
         return [('dense', int(n), int(n)) for n in self.sizes]
 
     # ------------------------------------------------------------------ sumstats + constants
@@ -158,6 +184,8 @@ class SyntheticShard:
         Sets: betahat, se, ld_diags, sld, adj, scalings, annot [.., N] local arrays;
         chi_local [P], rank_local [P], inv_se2_local [P]; call finish_init(inv_se2_global) to
         get inverse_betas."""
+        if self.kind == 'lowrank':
+            return self._build_lowrank(device)
         P, N = self.P, self.N
         self.betahat = np.zeros((P, N))
         self.se = np.ones((P, N))
@@ -184,6 +212,70 @@ class SyntheticShard:
         self._device = device
         return self
 
+    # ------------------------------------------------------------------ eigen-form LD (C4)
+    def _build_lowrank(self, device):
+        """LD given directly in eigen form R = U diag(s) U^T with orthonormal U [n, r] (QR of a
+        seeded Gaussian matrix) and a decaying spectrum with trace n -- the shape --ldthresh 0.8
+        leaves.  Every load-time constant has a closed form in (U, s): R^+ = U s^-1 U^T,
+        adj = U U^T z / se, chi = |U^T z|^2_{1/s}, rank = r, diag = sum_c s_c U_ic^2."""
+        import torch
+        assert device is not None, 'the eigen-form synthetic workload is built on the GPU'
+        P, N = self.P, self.N
+        self.betahat = np.zeros((P, N))
+        self.se = np.ones((P, N))
+        self.ld_diags = np.zeros((P, N))
+        self.chi_local = np.zeros(P)
+        self.adj = np.zeros((P, N))
+        self._eig = [[] for _ in range(P)]
+        f64 = dict(dtype=torch.float64, device=device)
+        for i, blk in enumerate(self.blocks):
+            lo = self.snp_start[i]
+            sl = slice(lo, lo + blk.n)
+            r = int(self.ranks[i])
+            self.se[:, sl] = blk.se
+            for p in range(P):
+                rng = np.random.default_rng([self.seed, 5000 + self.b0 + i, p])
+                G = torch.as_tensor(rng.normal(size=(blk.n, r)), **f64)
+                U = torch.linalg.qr(G)[0].contiguous()
+                sv = torch.as_tensor(np.geomspace(1.0, 0.05, r), **f64)
+                sv = sv * (blk.n / sv.sum())
+                self._eig[p].append((U, sv))
+                se = torch.as_tensor(blk.se[p], **f64)
+                zt = torch.as_tensor(blk.beta[p] / blk.se[p], **f64)
+                eps = torch.as_tensor(rng.normal(size=r), **f64)
+                zhat = U @ (sv * (U.T @ zt)) + U @ (sv.sqrt() * eps)
+                proj = U.T @ zhat
+                self.chi_local[p] += float((proj * proj / sv).sum().item())
+                self.betahat[p, sl] = (se * zhat).cpu().numpy()
+                self.adj[p, sl] = ((U @ proj) / se).cpu().numpy()
+                self.ld_diags[p, sl] = ((U * U) @ sv).cpu().numpy()
+        self.rank_local = np.full(P, float(self.ranks.sum()))
+        self.sld = self.ld_diags / self.se ** 2
+        self.scalings = np.ones((P, N))
+        self.annot = np.zeros(N, dtype=np.int32)
+        self.inv_se2_local = (self.se ** -2).sum(axis=1)
+        self._device = device
+        return self
+
+    def _finish_lowrank(self, prior):
+        import torch
+        P, N = self.P, self.N
+        f64 = dict(dtype=torch.float64, device=self._device)
+        for i, blk in enumerate(self.blocks):
+            lo = self.snp_start[i]
+            sl = slice(lo, lo + blk.n)
+            for p in range(P):
+                U, sv = self._eig[p][i]
+                se = torch.as_tensor(blk.se[p], **f64)
+                dinv = 1.0 / (se * se / prior[p])                         # Woodbury on U s U^T + D
+                rhs = torch.as_tensor(self.adj[p, sl] * blk.se[p], **f64)
+                y = dinv * rhs
+                core = torch.diag(1.0 / sv) + U.T @ (dinv[:, None] * U)
+                sol = y - dinv * (U @ torch.linalg.solve(core, U.T @ y))
+                self.inverse_betas[p, sl] = (sol * se).cpu().numpy()
+                self.fake_mu[p, sl] = self.inverse_betas[p, sl] + 1e-3 * blk.se[p] * blk.init_noise[p]
+        return self
+
     def finish_init(self, inv_se2_global):
         """Ridge start inverse_betas (variational_inference.py:246-252) and the jittered
         fake_mu of _initialize (:649-657), per block."""
@@ -191,6 +283,8 @@ class SyntheticShard:
         prior = 2 * self.gwas_N * self.init_hg / np.asarray(inv_se2_global)
         self.inverse_betas = np.zeros((P, N))
         self.fake_mu = np.zeros((P, N))
+        if self.kind == 'lowrank':
+            return self._finish_lowrank(prior)
         for i, blk in enumerate(self.blocks):
             lo = self.snp_start[i]
             sl = slice(lo, lo + blk.n)
