@@ -41,6 +41,7 @@ class OracleEngine:
         L = self.layout
         self.results = torch.zeros(L.size, dtype=torch.float64)
         self._dsum, self._totals = self.results[L.dsum], self.results[L.totals]
+        self._ttotals = self.results[L.ttotals]
         self._sums, self._dmax = self.results[L.sums], self.results[L.dmax]
         self._hyper_t = self.results[L.hyper]
         self._last_trial_kind = None
@@ -112,7 +113,7 @@ class OracleEngine:
         grad = nm.fast_vi_delta_grad(self.hyper, self.log_det, self.annot)
         return nm.fast_invert_nat_vi_delta(mu, nat_mu, np.copy(c['logdet'].T), grad)
 
-    def _moments(self, mu, delta):
+    def _moments(self, mu, delta, out=None):
         c = self._consts()
         mean = nm.fast_posterior_mean(mu, delta)
         var = nm.fast_pmv(mean, mu, delta, np.einsum('kppi->kpi', c['sigma']))
@@ -124,8 +125,9 @@ class OracleEngine:
             (linked * z).sum(axis=1),
             [nm.fast_delta_kl(delta, self.hyper, self.annot) + nm.fast_beta_kl(c['summary'], delta),
              nm.fast_inner_product_comp(mu, self.prec[:, :, :, None], delta)]])
-        self._totals.copy_(torch.as_tensor(totals))
-        return st, self._totals
+        out = self._totals if out is None else out
+        out.copy_(torch.as_tensor(totals))
+        return st, out
 
     # ---- state
     def set_mu(self, vi_mu):
@@ -156,7 +158,8 @@ class OracleEngine:
         nat_mu = nm.sum_betas(old_nat, grad, step)
         new_mu = nm.fast_nat_inner_product(nat_mu, c['sigma'])
         self.mu_trial = new_mu
-        self.trial_state, totals = self._moments(new_mu, self._delta(new_mu, nat_mu))
+        self.trial_state, totals = self._moments(new_mu, self._delta(new_mu, nat_mu),
+                                                 out=self._ttotals)
         return totals
 
     def accept(self, take_mu):

@@ -24,12 +24,13 @@ class ResultLayout:
 
     def __init__(self, nt, am):
         self.nt, self.am = nt, am
-        self.dsum = slice(0, 3)
-        self.totals = slice(3, 3 + nt)
-        self.sums = slice(3 + nt, 3 + nt + am)
-        self.dmax = slice(3 + nt + am, 6 + nt + am)
-        self.hyper = slice(6 + nt + am, 6 + nt + 2 * am)
-        self.size = 6 + nt + 2 * am
+        self.dsum = slice(0, 3)                        # convergence statistics, additive part
+        self.totals = slice(3, 3 + nt)                 # sums of a plain evaluation (vilma_eval)
+        self.ttotals = slice(3 + nt, 3 + 2 * nt)       # sums of a beta trial (vilma_trial_beta)
+        self.sums = slice(3 + 2 * nt, 3 + 2 * nt + am)  # responsibility sums
+        self.dmax = slice(3 + 2 * nt + am, 6 + 2 * nt + am)
+        self.hyper = slice(6 + 2 * nt + am, 6 + 2 * nt + 2 * am)
+        self.size = 6 + 2 * nt + 2 * am
 
 
 class HipEngine:
@@ -53,13 +54,15 @@ class HipEngine:
         self.refresh_stream()
         # One device tensor for every small result, so a decision needs a single D2H copy and the
         # parts that are summed over ranks are contiguous:
-        #   [diff sums (3) | totals (3P+2) | delta sums (A*M) | diff maxima (3) | hyper (A*M)]
+        #   [diff sums (3) | eval totals (3P+2) | trial totals (3P+2) | delta sums (A*M) |
+        #    diff maxima (3) | hyper (A*M)]
         nt, am = _lib.ntotals(self.P), self.A * self.M
         self.layout = ResultLayout(nt, am)
         self.results = torch.zeros(self.layout.size, dtype=torch.float64, device=self.device)
         L = self.layout
         self._dsum = self.results[L.dsum]
         self._totals = self.results[L.totals]
+        self._ttotals = self.results[L.ttotals]
         self._sums = self.results[L.sums]
         self._dmax = self.results[L.dmax]
         self._hyper = self.results[L.hyper]
@@ -210,8 +213,8 @@ class HipEngine:
 
     def trial(self, step):
         self._check(self.lib.vilma_trial_beta(self.ctx, self._stream(), float(step),
-                                              C.c_void_p(self._totals.data_ptr())))
-        return self._totals
+                                              C.c_void_p(self._ttotals.data_ptr())))
+        return self._ttotals
 
     def accept(self, take_mu):
         self._check(self.lib.vilma_accept(self.ctx, 1 if take_mu else 0))

@@ -168,6 +168,8 @@ class SweepDriver:
         self._last_diff = None      # convergence statistics fetched together with an evaluation
         self._cur_sums = None       # all-reduced responsibility sums of the current state, if known
         self._trial_sums = None
+        self._pending = None        # a beta trial queued ahead of time: {'step', 'host'}
+        self._speculate = False     # optimize()/sweep() loops: queue the next sweep's first trial
         self._verbose = False
         self._version = 0           # bumped whenever the device state moves
         self._hyper = None
@@ -179,6 +181,7 @@ class SweepDriver:
 
     def start_from(self, vi_mu_local, hyper):
         """Make (vi_mu of this shard, hyper_delta) the current state and evaluate it."""
+        self._pending = None
         self.engine.set_tau(self.error_scaling)
         self._set_hyper(hyper)
         self.engine.set_mu(vi_mu_local)
@@ -199,42 +202,53 @@ class SweepDriver:
                     - 0.5 * rk[p] * math.log(tau[p]))
         return lik - (t[3 * P] + t[3 * P + 1])
 
-    def _fetch(self, with_sums=False, with_diff=False):
-        """All-reduce what has to be summed over ranks (ONE RCCL all-reduce on a contiguous part
-        of the engine's result vector) and download the whole vector in ONE device->host copy.
-        Returns the host copy; slices are in engine.layout."""
+    def _fetch(self, lo, hi, with_max=False):
+        """All-reduce what has to be summed over ranks -- ONE RCCL all-reduce on the contiguous
+        part [lo, hi) of the engine's result vector -- and download the whole vector in ONE
+        device->host copy.  Returns the host copy; slices are in engine.layout."""
         eng = self.engine
-        L = eng.layout
         if self.comm.world > 1:
-            lo = L.dsum.start if with_diff else L.totals.start
-            hi = L.sums.stop if with_sums else L.totals.stop
             self.comm.allreduce_inplace(eng.results[lo:hi])
-            if with_diff and self._verbose:
-                self.comm.allreduce_inplace(eng.results[L.dmax], op='max')
+            if with_max and self._verbose:
+                self.comm.allreduce_inplace(eng.results[eng.layout.dmax], op='max')
         return eng.fetch()
 
-    def _evaluate(self, step=None, with_sums=False):
-        """Objective of a candidate point: the current vi_mu (step None) or a natural-gradient
-        trial at `step`.  The candidate stays on the device as the trial state.  with_sums also
-        queues the responsibility sums of the candidate (the M-step statistic) so that an
-        accepted candidate needs no second round trip."""
-        from . import _lib
-        if step is None:
-            self.engine.eval()
-            which = _lib.STATE_TRIAL_EVAL
-        else:
-            self.engine.trial(step)
-            which = _lib.STATE_TRIAL_BETA
-        if with_sums:
-            # this overwrites the device copy of the sums: whatever was there (the current
-            # state's, from the accepted trial before) is gone until this candidate is accepted
-            self._cur_sums = None
-            self.engine.delta_sums(which)
-        host = self._fetch(with_sums=with_sums)
+    def _evaluate(self):
+        """Objective of the CURRENT vi_mu under the current hyper/tau.  The evaluated point
+        stays on the device as the trial state."""
         L = self.engine.layout
+        self._pending = None            # a queued trial's buffers are about to be overwritten
+        self.engine.eval()
+        host = self._fetch(L.totals.start, L.totals.stop)
         totals = host[L.totals]
-        self._trial_sums = host[L.sums] if with_sums else None
+        self._trial_sums = None
         self.n_evaluations += 1
+        return self._objective_from(totals), totals
+
+    def _launch_trial(self, step):
+        """Queue one natural-gradient trial at `step` plus the responsibility sums of the
+        candidate (the M-step statistic), so an accepted candidate needs no second round trip.
+        This overwrites the device copy of the sums: whatever was there (the current state's,
+        from the accepted trial before) is gone until this candidate is accepted."""
+        from . import _lib
+        self._cur_sums = None
+        self.engine.trial(step)
+        self.engine.delta_sums(_lib.STATE_TRIAL_BETA)
+
+    def _trial(self, step):
+        """Objective of the candidate at `step`: the result of the trial already queued behind
+        the previous sweep's last evaluation if there is one for this step, else queue it now."""
+        L = self.engine.layout
+        pend, self._pending = self._pending, None
+        if pend is not None and pend['step'] == step:
+            host = pend['host']
+        else:
+            self._launch_trial(step)
+            host = self._fetch(L.ttotals.start, L.sums.stop)
+        totals = host[L.ttotals]
+        self._trial_sums = host[L.sums]
+        self.n_evaluations += 1
+        self.n_trials += 1
         return self._objective_from(totals), totals
 
     def _accept(self, take_mu, obj, totals):
@@ -272,7 +286,10 @@ class SweepDriver:
 
     def _download(self, which):
         """This shard's vi_mu / vi_delta (MultiPopVI gathers them across ranks)."""
-        return self.engine.get_mu() if which == 'vi_mu' else self.engine.get_delta()
+        if which == 'vi_mu':
+            return self.engine.get_mu()
+        self._pending = None        # vilma_get_delta uses the trial vi_mu buffer as scratch
+        return self.engine.get_delta()
 
     # ------------------------------------------------------------------ one sweep
     def _update_beta(self, L, idx, lsr, orig_obj):
@@ -282,8 +299,7 @@ class SweepDriver:
             raise RuntimeError('nat_grad_vi_delta must always be set prior to running '
                                '_update_beta')
         while True:
-            new_obj, totals = self._evaluate(1. / L[idx], with_sums=True)
-            self.n_trials += 1
+            new_obj, totals = self._trial(1. / L[idx])
             logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
             # scalar arithmetic on Python floats: np.isclose & co cost ~20 us per call, which is
             # visible next to a 150 us evaluation on an 8-GPU shard
@@ -298,11 +314,13 @@ class SweepDriver:
                 return orig_obj, orig_obj
             L[idx] *= lsr
 
-    def _update_hyper_delta(self, orig_obj, with_diff=False):
+    def _update_hyper_delta(self, orig_obj, with_diff=False, next_step=None):
         """Closed-form M-step for the mixture weights (variational_inference.py:825-860), all on
         the device: responsibility sums (already all-reduced if they came with the accepted beta
         trial) -> new hyper_delta and its table -> re-evaluation, then ONE download.
-        The update is unconditional in the reference, so it is accepted before the download."""
+        The update is unconditional in the reference, so it is accepted before the download --
+        and because it is unconditional, the NEXT sweep's first beta trial (step `next_step`,
+        known from L alone) can be queued right behind it and fetched in the same round trip."""
         eng = self.engine
         L = eng.layout
         if self._cur_sums is None:
@@ -311,13 +329,19 @@ class SweepDriver:
             sums = eng.delta_sums()
             if self.comm.world > 1:
                 self.comm.allreduce_inplace(sums)
-        # the sums of the accepted trial are still in the result vector (all-reduced in place)
+        # otherwise the sums of the accepted trial are still in the result vector (all-reduced)
         eng.mstep()
         eng.eval()
         eng.accept(False)
         if with_diff:
             eng.mean_diff()
-        host = self._fetch(with_diff=with_diff)
+        lo = L.dsum.start if with_diff else L.totals.start
+        if next_step is not None:
+            self._launch_trial(next_step)
+            host = self._fetch(lo, L.sums.stop, with_max=with_diff)
+            self._pending = {'step': next_step, 'host': host}
+        else:
+            host = self._fetch(lo, L.totals.stop, with_max=with_diff)
         totals = host[L.totals]
         self._install_hyper(host[L.hyper].reshape(self.num_annotations, self.num_mix))
         self._last_diff = np.concatenate([host[L.dsum], host[L.dmax]]) if with_diff else None
@@ -360,8 +384,11 @@ class SweepDriver:
         logging.info('...Updating paramset %d, L=%f', 1, L[1])
         # without --learn-scaling this is the last evaluation of the sweep: piggy-back the
         # convergence statistics on its download
+        last = not self.scale_se
+        spec = 1. / max([1., L[0] / 1.25]) if (self._speculate and last) else None
         orig_obj, new_obj = self._update_hyper_delta(self._objective,
-                                                     with_diff=self._want_diff and not self.scale_se)
+                                                     with_diff=self._want_diff and last,
+                                                     next_step=spec)
         delta_sum += new_obj - orig_obj
         # ---- paramset 2: annotations -- nothing to do in this scheme (:862-866)
         L[2] = max([1., L[2] / 1.25])
@@ -398,11 +425,7 @@ class SweepDriver:
             return d
         self.engine.mean_diff()
         L = self.engine.layout
-        if self.comm.world > 1:
-            self.comm.allreduce_inplace(self.engine.results[L.dsum])
-            if self._verbose:
-                self.comm.allreduce_inplace(self.engine.results[L.dmax], op='max')
-        host = self.engine.fetch()
+        host = self._fetch(L.dsum.start, L.dsum.stop, with_max=True)
         return np.concatenate([host[L.dsum], host[L.dmax]])
 
     def sweep(self, state=None):
@@ -411,7 +434,7 @@ class SweepDriver:
         if state is None:
             self.engine.snapshot_mean()
             state = {'L': np.ones(5), 'elbo': self._objective, 'running': None}
-        self._want_diff, self._last_diff = True, None
+        self._want_diff, self._last_diff, self._speculate = True, None, True
         _, L, elbo, running = self._optimize_step(self._params(), L=state['L'],
                                                    curr_elbo=state['elbo'], line_search_rate=2.,
                                                    running_elbo_delta=state['running'])
@@ -443,6 +466,7 @@ class SweepDriver:
         self.engine.snapshot_mean()
         verbose = logging.getLogger().isEnabledFor(logging.INFO)
         self._verbose, self._want_diff, self._last_diff = verbose, True, None
+        self._speculate = True
         ckp_mean = self.real_posterior_mean(params) if (verbose and self.checkpoint) else None
         while num_its < self.num_its and not converged:
             if self.checkpoint and num_its % self.checkpoint_freq == 0:
@@ -462,6 +486,7 @@ class SweepDriver:
             if verbose:
                 self._dump_info(num_its, d, n_total, params, ckp_mean)
             num_its += 1
+        self._speculate, self._pending = False, None
         if num_its == self.num_its:
             logging.warning('Failed to converge')
         logging.info('Optimization ran for %d iterations', num_its)
@@ -652,6 +677,7 @@ class MultiPopVI(SweepDriver):
     def _download(self, which):
         if which == 'vi_mu':
             return self.comm.gather_snps(self.engine.get_mu(), self._snps, self.num_loci)
+        self._pending = None        # vilma_get_delta uses the trial vi_mu buffer as scratch
         delta = self.engine.get_delta()
         return np.ascontiguousarray(
             self.comm.gather_snps(np.ascontiguousarray(delta.T), self._snps, self.num_loci).T)
