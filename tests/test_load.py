@@ -140,3 +140,24 @@ def test_mixture_grid_rng_order(P, Kc):
     assert np.random.uniform() == float(G[tag + '_next_uniform'])
     want_m = Kc + 2 if P == 1 else 3 * (Kc + 2) * Kc ** (P * (P - 1) // 2) + 3 * P * (Kc + 1)
     assert len(covs) == want_m
+
+
+def test_lazy_loading_is_equivalent_and_deferred():
+    """lazy=True defers np.load + eigh per block until first use; assignment and factors equal."""
+    variants = load.load_variant_list(ref('good_variants.tsv'))
+    eager, miss_e = load.load_ld_from_schema(ref('ld_manifest.tsv'), variants, [3, 4], 0.8)
+    lazy, miss_l = load.load_ld_from_schema(ref('ld_manifest.tsv'), variants, [3, 4], 0.8, lazy=True)
+    assert miss_e == miss_l and np.array_equal(eager.perm, lazy.perm)
+    assert np.array_equal(eager.starts, lazy.starts) and lazy.shape == eager.shape
+    assert all(m.is_deferred() for m in lazy.matrices)
+    lazy.materialize(workers=2)
+    assert not any(m.is_deferred() for m in lazy.matrices)
+    for a, b in zip(eager.matrices, lazy.matrices):
+        np.testing.assert_allclose(b.reconstruct(), a.reconstruct(), atol=1e-14)
+        assert b.get_rank() == a.get_rank()
+    variants = load.load_variant_list(os.path.join(EX, 'keep_variants.txt'))
+    lazy, _ = load.load_ld_from_schema(os.path.join(EX, 'ld_mat', 'example_schema.schema'),
+                                       variants, [], 1.0, lazy=True)
+    assert lazy.matrices[1].is_deferred()
+    _ = lazy.matrices[1].s                      # touching a factor materialises just that block
+    assert not lazy.matrices[1].is_deferred() and lazy.matrices[0].is_deferred()

@@ -156,12 +156,14 @@ def _allele_match(want_a1, want_a2, have_a1, have_a2):
     return same, swapped
 
 
-def load_ld_from_schema(schema_path, variants, denylist, ldthresh, mmap=False):
+def load_ld_from_schema(schema_path, variants, denylist, ldthresh, mmap=False, lazy=False):
     """Block-diagonal LD for `variants` from a schema (reference load.py:237-354).
 
     Returns (BlockDiagonalMatrix, list of SNP positions without LD).  `perm` lists, block by
     block in manifest order, the positions (in `variants`) of the SNPs each block keeps,
-    followed by the SNPs no block covers."""
+    followed by the SNPs no block covers.  With lazy=True the .npy files are read and
+    eigendecomposed only when a block's factors are first used (so a multi-GPU fit touches only
+    its own shard's blocks, in parallel); the SNP -> block assignment is unaffected."""
     if mmap:
         raise NotImplementedError('--mmap is not supported: LD is kept resident in HBM')
     index = variants.set_index('ID')
@@ -192,9 +194,14 @@ def load_ld_from_schema(schema_path, variants, denylist, ldthresh, mmap=False):
             continue
         signs = np.ones(len(pos))
         signs[swapped] = -1
-        dense = load_ld_mat(npy_path, wanted, mismatch, signs)
         perm_parts.append(pos[~mismatch])
-        blocks.append(LowRankMatrix(dense, ldthresh))
+        if lazy:
+            def make(npy_path=npy_path, wanted=wanted.copy(), mismatch=mismatch.copy(),
+                     signs=signs.copy()):
+                return load_ld_mat(npy_path, wanted, mismatch, signs)
+            blocks.append(LowRankMatrix.deferred(make, int((~mismatch).sum()), ldthresh))
+        else:
+            blocks.append(LowRankMatrix(load_ld_mat(npy_path, wanted, mismatch, signs), ldthresh))
 
     perm = np.concatenate(perm_parts) if perm_parts else np.array([], dtype=float)
     uncovered = set(np.arange(variants.shape[0]).tolist()) - set(perm.tolist())

@@ -27,6 +27,35 @@ def _svd_threshold(matrix, ld_thresh):
     return u, np.array(w[sel]), np.array(u.T)
 
 
+def _default_workers():
+    try:
+        import os
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return 4
+
+
+def parallel_map(fn, items, workers=None):
+    """map over LD blocks on a thread pool (numpy/LAPACK release the GIL); BLAS is held to one
+    thread per worker meanwhile.  Order of results = order of items."""
+    items = list(items)
+    workers = _default_workers() if workers is None else workers
+    if workers <= 1 or len(items) < 2:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except ImportError:
+        limiter = None
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            return list(pool.map(fn, items))
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
+
+
 def dense_is_cheaper(n, r):
     """Bytes per product: dense symmetric (lower triangle by 128-column slabs) vs eigen form."""
     return 0.5 * n * n + 64.0 * n <= 2.0 * n * r
@@ -35,6 +64,36 @@ def dense_is_cheaper(n, r):
 class LowRankMatrix:
     """Symmetric block stored as u diag(s) v + diag(D), v = u^T
     (reference matrix_structures.py:38-234)."""
+
+    _LAZY_FIELDS = ('u', 's', 'v', 'D', 'inv_s')
+
+    @classmethod
+    def deferred(cls, make_matrix, n, t=1.0):
+        """A block whose dense matrix is produced (and eigendecomposed) only when first needed:
+        `make_matrix()` returns the symmetric n x n matrix.  Lets a fit decompose only the
+        blocks of its own shard, in parallel (BlockDiagonalMatrix.materialize)."""
+        self = cls.__new__(cls)
+        self._thunk = (make_matrix, t)
+        self.shape = (int(n), int(n))
+        return self
+
+    def is_deferred(self):
+        return self.__dict__.get('_thunk') is not None
+
+    def materialize(self):
+        thunk = self.__dict__.get('_thunk')
+        if thunk is not None:
+            make_matrix, t = thunk
+            self._thunk = None
+            self.__init__(make_matrix(), t)
+        return self
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails, i.e. for the factor fields of a deferred block
+        if name in LowRankMatrix._LAZY_FIELDS and self.__dict__.get('_thunk') is not None:
+            self.materialize()
+            return self.__dict__[name]
+        raise AttributeError(name)
 
     def __init__(self, X=None, t=1.0, u=None, s=None, v=None, D=None, hdf_file=None):
         if hdf_file is not None:
@@ -146,19 +205,26 @@ class BlockDiagonalMatrix:
                              'Some are missing.')
         self._engine = None
 
+    def materialize(self, block_ids=None, workers=None):
+        """Eigendecompose the deferred blocks among `block_ids` (default: all) on a thread pool;
+        LAPACK releases the GIL, BLAS is limited to one thread per worker meanwhile."""
+        todo = [self.matrices[b] for b in (range(len(self.matrices)) if block_ids is None
+                                           else block_ids) if self.matrices[b].is_deferred()]
+        parallel_map(lambda m: m.materialize(), todo, workers)
+        return self
+
     # -- device operator -------------------------------------------------------------------
     def device_blocks(self, form='auto'):
         """Blocks in the form the HIP LD store takes, chosen by bytes streamed per product: the
         dense symmetric form reads the lower triangle once (~n^2/2 + 64 n elements), the eigen
         form reads U and diag(s)U^T (2 n r) -- so eigen form only when r < n/4 + 32."""
-        out = []
-        for m in self.matrices:
+        def one(m):
             n, r = m.u.shape
             if not np.allclose(m.D, 0):
                 raise NotImplementedError('device LD blocks must have a zero diagonal part')
             dense = form == 'dense' or (form == 'auto' and dense_is_cheaper(n, r))
-            out.append(('dense', m.reconstruct()) if dense else ('eig', m.u, m.s))
-        return out
+            return ('dense', m.reconstruct()) if dense else ('eig', m.u, m.s)
+        return parallel_map(one, self.matrices)
 
     def _own_engine(self):
         if self._engine is None:
@@ -181,8 +247,8 @@ class BlockDiagonalMatrix:
     # -- host-side (load-time) operations ------------------------------------------------
     def _per_block(self, vector, fn):
         x = np.asarray(vector)[self.perm]
-        parts = [fn(m, x[lo:lo + m.shape[0]], lo)
-                 for m, lo in zip(self.matrices, self.starts[:-1])]
+        parts = parallel_map(lambda ml: fn(ml[0], x[ml[1]:ml[1] + ml[0].shape[0]], ml[1]),
+                             list(zip(self.matrices, self.starts[:-1])))
         parts.append(np.zeros([self.missing.shape[0]] + list(x.shape[1:])))
         return np.concatenate(parts, axis=0)[self.inv_perm]
 
@@ -226,7 +292,7 @@ class BlockDiagonalMatrix:
         if self._inverted:
             raise NotImplementedError('Getting the diagonal of an inverted matrix has not '
                                       'been implemented yet.')
-        parts = [m.diag() for m in self.matrices] + [np.zeros(self.missing.shape[0])]
+        parts = parallel_map(lambda m: m.diag(), self.matrices) + [np.zeros(self.missing.shape[0])]
         return np.concatenate(parts, axis=0)[self.inv_perm]
 
     def get_rank(self):

@@ -100,7 +100,9 @@ def block_costs(ld):
     from .matrix_structures import dense_is_cheaper
     out = []
     for m in ld.matrices:
-        n, r = m.u.shape
+        n = m.shape[0]
+        # a block that is not decomposed yet is costed as dense (its rank is unknown)
+        r = n if m.is_deferred() else m.u.shape[1]
         out.append(8.0 * (0.5 * n * n + 64.0 * n if dense_is_cheaper(n, r) else 2.0 * n * r))
     return np.asarray(out)
 

@@ -610,18 +610,21 @@ class MultiPopVI(SweepDriver):
             _engine_factory = HipEngine
         self.engine = _engine_factory(P, n_loc, M, self.num_annotations)
 
-        # ---- one-time constants (variational_inference.py:189-252), host numpy per block ----
-        self.ld_diags = np.stack([ld.diag() for ld in ld_mats])
-        self.scaled_ld_diags = self.std_errs ** -2 * self.ld_diags
+        # ---- one-time constants (variational_inference.py:189-252), host numpy per block: only
+        # this shard's blocks are eigendecomposed (deferred blocks, thread pool), the per-SNP
+        # results are gathered across ranks ----
         loc = self._snps
         local_lds = []
         for p, ld in enumerate(ld_mats):
+            ld.materialize(mine['blocks'][p])
             mats, perm, n_ld = local_ld(ld, loc, mine['blocks'][p], N)
             sub = matrix_structures.BlockDiagonalMatrix(mats, perm=perm,
                                                         missing=perm[n_ld:])
             local_lds.append(sub)
             self.engine.load_ld(p, sub.device_blocks(form), perm, n_ld)
         self._local_lds = local_lds
+        self.ld_diags = self.comm.gather_snps(np.stack([sub.diag() for sub in local_lds]), loc, N)
+        self.scaled_ld_diags = self.std_errs ** -2 * self.ld_diags
 
         mle = np.zeros((P, n_loc))
         chi_loc, rank_loc = np.zeros(P), np.zeros(P)

@@ -181,7 +181,7 @@ def main(args, _engine_factory=None):
         logging.info('Loading LD for population %d...', idx + 1)
         ld_mat, no_ld = load.load_ld_from_schema(schema_path, variants=variants,
                                                  denylist=missing, ldthresh=args.ldthresh,
-                                                 mmap=args.mmap)
+                                                 mmap=args.mmap, lazy=True)
         ld_mats.append(ld_mat)
         missing_ld_info[no_ld, idx] = True
     logging.info('Largest beta is... %f', np.max(np.abs(beta_rows)))
