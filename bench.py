@@ -200,7 +200,8 @@ def main():
 
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-    if os.path.exists(tpath):
+    # the PMC passes were taken on the C3 workload at 1 GPU (profiles/README.md)
+    if os.path.exists(tpath) and world == 1 and args.workload == 'C3' and args.emulate_shard <= 1:
         try:
             traffic = json.load(open(tpath)).get(dom + '_bytes_per_launch')
         except Exception:

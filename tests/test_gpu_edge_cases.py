@@ -1,0 +1,111 @@
+"""GPU parity on the edges of the problem space: minimal sizes, one-SNP blocks, a cohort without
+any LD, an annotation nobody has, many mixture components, three cohorts, big blocks.  Each case
+runs the product class API on the HIP engine against the oracle for a few sweeps."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ar1(n, rho):
+    i = np.arange(n)
+    return rho ** np.abs(i[:, None] - i[None, :])
+
+
+def _problem(rng, P, sizes_per_cohort, N, M, A=1, ldthresh=1.0, empty_annot=False):
+    """Random SPD blocks per cohort on random disjoint SNP subsets (different partitions per
+    cohort), sumstats from the model's own likelihood shape."""
+    perms, missings, blocks = [], [], []
+    for p in range(P):
+        sizes = sizes_per_cohort[p]
+        n_ld = int(np.sum(sizes))
+        order = rng.permutation(N)
+        perms.append(np.concatenate([order[:n_ld], np.sort(order[n_ld:])]).astype(np.int64))
+        missings.append(np.sort(order[n_ld:]).astype(np.int64))
+        blocks.append([_ar1(n, rng.uniform(0.2, 0.9)) for n in sizes])
+    se = rng.uniform(0.01, 0.05, size=(P, N))
+    betahat = rng.normal(size=(P, N)) * se * 1.5
+    for p in range(P):
+        betahat[p, missings[p]] = 0.0
+        se[p, missings[p]] = 1.0
+    var = np.geomspace(1e-7, 1e-2, M)
+    covs = [v * (0.6 * np.eye(P) + 0.4 * np.ones((P, P))) for v in var]
+    ann = np.zeros((N, A))
+    cols = rng.integers(0, A - 1 if (empty_annot and A > 1) else A, size=N)
+    ann[np.arange(N), cols] = 1
+    return dict(P=P, N=N, M=M, perms=perms, missings=missings, blocks=blocks, se=se,
+                betahat=betahat, covs=covs, ann=ann, t=ldthresh)
+
+
+def _build(pr, which, **kw):
+    common = dict(marginal_effects=pr['betahat'], std_errs=pr['se'], mixture_covs=pr['covs'],
+                  annotations=pr['ann'], checkpoint=False, gwas_N=np.full(pr['P'], 5e4),
+                  init_hg=np.full(pr['P'], 0.2), num_its=6, **kw)
+    if which == 'oracle':
+        from oracle.ldop import EigenBlock, BlockDiagonalLD
+        from oracle.vi import MultiPopVIOracle
+        ld = [BlockDiagonalLD([EigenBlock(X, pr['t']) for X in pr['blocks'][p]],
+                              perm=pr['perms'][p], missing=pr['missings'][p])
+              for p in range(pr['P'])]
+        return MultiPopVIOracle(ld_mats=ld, **common)
+    from vilma_amd.matrix_structures import LowRankMatrix, BlockDiagonalMatrix
+    from vilma_amd.variational_inference import MultiPopVI
+    ld = [BlockDiagonalMatrix([LowRankMatrix(X, pr['t']) for X in pr['blocks'][p]],
+                              perm=pr['perms'][p], missing=pr['missings'][p])
+          for p in range(pr['P'])]
+    return MultiPopVI(ld_mats=ld, **common)
+
+
+def _compare(pr, sweeps=4, **kw):
+    ovi, vi = _build(pr, 'oracle', **kw), _build(pr, 'product', **kw)
+    np.random.seed(7)
+    op = ovi._initialize()
+    np.random.seed(7)
+    pp = vi._initialize()
+    oe, pe = ovi.elbo(op), vi.elbo(pp)
+    assert abs(oe - pe) <= 1e-8 * abs(oe) + 1e-9
+    oL, pL, ored, pred = np.ones(5), np.ones(5), None, None
+    for it in range(sweeps):
+        op, oL, oe, ored = ovi._optimize_step(op, oL, oe, 2., ored)
+        pp, pL, pe, pred = vi._optimize_step(pp, pL, pe, 2., pred)
+        assert abs(oe - pe) <= 1e-8 * abs(oe) + 1e-9, (it, oe, pe)
+        assert np.array_equal(oL, pL), (it, oL, pL)
+    np.testing.assert_allclose(vi.real_posterior_mean(pp), ovi.real_posterior_mean(*op),
+                               rtol=1e-6, atol=1e-11)
+    np.testing.assert_allclose(pp[1], op[1], rtol=1e-6, atol=1e-300)
+    np.testing.assert_allclose(vi.error_scaling, ovi.error_scaling, rtol=1e-9)
+    return vi
+
+
+def test_minimal_sizes():
+    rng = np.random.default_rng(1)
+    _compare(_problem(rng, 1, [[1]], N=1, M=2))                       # one SNP, one 1x1 block
+    _compare(_problem(rng, 1, [[1, 1, 2]], N=5, M=2))                 # 1-SNP blocks + a missing SNP
+    _compare(_problem(rng, 2, [[3, 1], [2, 2]], N=4, M=3))
+
+
+def test_cohort_without_any_ld():
+    rng = np.random.default_rng(2)
+    pr = _problem(rng, 2, [[40, 25], []], N=70, M=6)
+    vi = _compare(pr)
+    assert np.all(vi.ld_diags[1] == 0) and vi.ld_ranks[1] == 0
+
+
+def test_annotation_nobody_has_and_learn_scaling():
+    rng = np.random.default_rng(3)
+    pr = _problem(rng, 1, [[60, 30]], N=100, M=8, A=3, empty_annot=True)
+    vi = _compare(pr, scale_se=True, sweeps=6)
+    assert vi.annotation_counts[2] == 0
+
+
+def test_many_components_three_cohorts():
+    rng = np.random.default_rng(4)
+    _compare(_problem(rng, 2, [[50, 70], [120]], N=130, M=582), sweeps=3)   # CLI default M at P=2
+    _compare(_problem(rng, 3, [[30, 40], [70], [20, 20, 30]], N=80, M=9), sweeps=3)
+
+
+def test_big_blocks_and_thresholding():
+    rng = np.random.default_rng(5)
+    _compare(_problem(rng, 1, [[700, 130, 129]], N=1000, M=5), sweeps=3)
+    _compare(_problem(rng, 2, [[300, 200], [257, 255]], N=520, M=5, ldthresh=0.5), sweeps=3,
+             scaled=True)
