@@ -25,6 +25,13 @@ static __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// sum over aligned groups of W consecutive lanes (W = 64: the whole wave)
+template <int W>
+static __device__ __forceinline__ double seg_sum(double v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 static __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -366,12 +373,16 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 #define KU 4
 #endif
 
+// (Splitting the components of one SNP over 4 lanes to get 4x the waves on small shards was
+// measured and rejected for this kernel: 63 vs 52 us per evaluation at 131 k SNPs -- the
+// per-component tables stop being wave-uniform.  It does pay for delta_kernel below.)
 template <int P, bool BLEND, bool ONE_ANNOT>
 __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
     constexpr int NT = 2 * P + 2;
     __shared__ double red[SNP_THREADS / 64][NT];
     const int N = a.N, M = a.M;
     const int64_t N64 = N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * SNP_THREADS + threadIdx.x;
     const bool live = i < N;
     const int ii = live ? i : N - 1;
@@ -477,6 +488,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
             }
         }
     }
+    const bool owner = live;
     const double invZ = 1.0 / Z;
     const double lse = mx + log(Z);
     double part[NT];
@@ -484,19 +496,18 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     for (int p = 0; p < P; ++p) {
         const double m = Sm[p] * invZ;
         const double v = S2[p] * invZ - m * m;
-        if (live) {
+        if (owner) {
             a.m_out[p * N64 + i] = m;
             a.v_out[p * N64 + i] = v;
             a.pool_out[p * N64 + a.invperm[p * N64 + i]] = m / se[p];
         }
-        part[p] = live ? m * adj[p] : 0.0;
-        part[P + p] = live ? sld[p] * v : 0.0;
+        part[p] = owner ? m * adj[p] : 0.0;
+        part[P + p] = owner ? sld[p] * v : 0.0;
     }
-    if (live) a.lse_out[i] = lse;
-    part[2 * P] = live ? (Skl * invZ - lse) : 0.0;
-    part[2 * P + 1] = live ? 0.5 * Sip * invZ : 0.0;
+    if (owner) a.lse_out[i] = lse;
+    part[2 * P] = owner ? (Skl * invZ - lse) : 0.0;
+    part[2 * P + 1] = owner ? 0.5 * Sip * invZ : 0.0;
 
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const double s = wave_sum(part[t]);
@@ -540,14 +551,20 @@ void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s) {
 // responsibilities of the current state: delta_ik = max(exp(u_ik - lse_i), 1e-100)
 // (invert_nat_cat_2D's clamp, numerics.py:192-194)
 // --------------------------------------------------------------------------------------------
-template <int P, bool ONE_ANNOT, bool WRITE>
+// KS = lanes that share one SNP (1 or 4).  With KS = 4 the quarter-waves take components
+// k = ks, ks+4, ... of the same 16 SNPs: 4x the waves for the same work, which small shards (an
+// 8-GPU rank holds ~130 k SNPs = 2 waves per SIMD at KS = 1) need to hide latency, and the
+// per-component sum over SNPs becomes a 16-lane shuffle reduction (29 vs 39 us at 131 k SNPs).
+template <int P, bool ONE_ANNOT, bool WRITE, int KS>
 __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
+    constexpr int SPW = 64 / KS;
     const int N = a.N, M = a.M, A = a.A;
     const int64_t N64 = N;
-    const int i = blockIdx.x * SNP_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ks = lane / SPW;
+    const int i = (blockIdx.x * (SNP_THREADS / 64) + w) * SPW + (lane % SPW);
     const bool live = i < N;
     const int ii = live ? i : N - 1;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double d[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / a.tau.v[p];
@@ -555,7 +572,9 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     const double *lh = a.lh + (int64_t)ann * M;
     const double lse = a.lse[ii];
     double *prow = WRITE ? nullptr : a.out + ((int64_t)blockIdx.x * (SNP_THREADS / 64) + w) * A * M;
-    for (int k = 0; k < M; ++k) {
+    // with KS = 4 the quarter-waves take components k = ks, ks+4, ... of the same 16 SNPs; the
+    // per-component sum over SNPs is then a 16-lane (segmented) shuffle reduction
+    for (int k = ks; k < M; k += KS) {
         double lam[P][P], mu[P];
         const double *pk = a.prec + (int64_t)k * P * P;
 #pragma unroll
@@ -578,18 +597,26 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
         if (WRITE) {
             if (live) a.out[(int64_t)k * N64 + i] = delta;
         } else if (ONE_ANNOT) {
-            const double s = wave_sum(live ? delta : 0.0);
-            if (lane == 0) prow[k] = s;
+            const double s = seg_sum<SPW>(live ? delta : 0.0);
+            if ((lane % SPW) == 0) prow[k] = s;
         } else {
             for (int aa = 0; aa < A; ++aa) {
-                const double s = wave_sum((live && ann == aa) ? delta : 0.0);
-                if (lane == 0) prow[(int64_t)aa * M + k] = s;
+                const double s = seg_sum<SPW>((live && ann == aa) ? delta : 0.0);
+                if ((lane % SPW) == 0) prow[(int64_t)aa * M + k] = s;
             }
         }
     }
 }
 
-int delta_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
+#ifndef KS_SPLIT_BELOW
+#define KS_SPLIT_BELOW 400000       // shards below this many SNPs use 4 lanes per SNP
+#endif
+static inline int delta_ks(int64_t N) { return N < KS_SPLIT_BELOW ? 4 : 1; }
+
+int delta_grid(int64_t N) {
+    const int64_t per_block = SNP_THREADS / delta_ks(N);
+    return (int)((N + per_block - 1) / per_block);
+}
 
 // out[chunk][c] = sum over the chunk's rows of in[r][c]: lanes along columns, the 4 waves take
 // interleaved rows with 4 independent accumulators each, fixed combination order.  Launched
@@ -634,11 +661,17 @@ static void reduce_cols(const double *in, int rows, int ncols, double *scratch, 
     hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, 1), dim3(256), 0, s, in, rows, ncols, out);
 }
 
+template <int P, bool WRITE, int KS>
+static void launch_delta_pk(const DeltaArgs &a, hipStream_t s) {
+    const dim3 grid(delta_grid(a.N)), block(SNP_THREADS);
+    if (a.A == 1) hipLaunchKernelGGL((delta_kernel<P, true, WRITE, KS>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((delta_kernel<P, false, WRITE, KS>), grid, block, 0, s, a);
+}
+
 template <int P, bool WRITE>
 static void launch_delta_p(const DeltaArgs &a, hipStream_t s) {
-    const dim3 grid(delta_grid(a.N)), block(SNP_THREADS);
-    if (a.A == 1) hipLaunchKernelGGL((delta_kernel<P, true, WRITE>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((delta_kernel<P, false, WRITE>), grid, block, 0, s, a);
+    if (delta_ks(a.N) == 4) launch_delta_pk<P, WRITE, 4>(a, s);
+    else launch_delta_pk<P, WRITE, 1>(a, s);
 }
 
 template <bool WRITE>

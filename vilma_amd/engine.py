@@ -165,6 +165,10 @@ class HipEngine:
             return a, _ptr(a)
         a = a.contiguous()      # torch tensor (device or host), float64
         assert a.dtype == self.torch.float64
+        if a.is_cuda:
+            # the library copies with hipMemcpy on the null stream: make sure whatever produced
+            # the tensor on torch's current stream has finished
+            self.torch.cuda.current_stream().synchronize()
         return a, C.c_void_p(a.data_ptr())
 
     def ld_bytes(self):
