@@ -186,7 +186,7 @@ int vilma_fetch(vilma_ctx *ctx, void *stream, const double *src_dev, double *dst
  * milliseconds and number of launches since the last reset (arrays of VILMA_PROF_KINDS). */
 #define VILMA_PROF_LD_SYM 0      /* ld_sym_kernel: symmetric dense blocks, lower triangle read once */
 #define VILMA_PROF_LD_COLSUM 1   /* ld_colsum_kernel: both passes of eigen-form blocks */
-#define VILMA_PROF_LD_COMBINE 2  /* ld_sym_combine_kernel */
+#define VILMA_PROF_LD_COMBINE 2  /* reserved (ld_sym_combine_kernel is not bracketed) */
 #define VILMA_PROF_KINDS 3
 int vilma_prof_enable(vilma_ctx *ctx, int enable);
 int vilma_prof_read(vilma_ctx *ctx, double *ms_total, int64_t *launches, int reset);

@@ -94,6 +94,7 @@ struct vilma_ctx {
     bool prof = false;
     struct Pending { hipEvent_t e0, e1; int kind; };
     std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
     double prof_ms[VILMA_PROF_KINDS] = {0, 0, 0};
     int64_t prof_launches[VILMA_PROF_KINDS] = {0, 0, 0};
 };
@@ -249,15 +250,26 @@ int ensure_ready(vilma_ctx *c) {
     return 0;
 }
 
+// Profiling events come from a recycled pool (creating events per launch costs microseconds of
+// host time inside the region being measured).
+hipEvent_t prof_event(vilma_ctx *c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
 void prof_begin(vilma_ctx *c, hipStream_t s, hipEvent_t &e0) {
     if (!c->prof) return;
-    (void)hipEventCreate(&e0);
+    e0 = prof_event(c);
     (void)hipEventRecord(e0, s);
 }
 void prof_end(vilma_ctx *c, hipStream_t s, hipEvent_t e0, int kind) {
     if (!c->prof) return;
-    hipEvent_t e1;
-    (void)hipEventCreate(&e1);
+    hipEvent_t e1 = prof_event(c);
     (void)hipEventRecord(e1, s);
     c->pending.push_back({e0, e1, kind});
 }
@@ -269,8 +281,8 @@ void prof_resolve(vilma_ctx *c) {
             c->prof_ms[pr.kind] += ms;
             c->prof_launches[pr.kind] += 1;
         }
-        (void)hipEventDestroy(pr.e0);
-        (void)hipEventDestroy(pr.e1);
+        c->event_pool.push_back(pr.e0);
+        c->event_pool.push_back(pr.e1);
     }
     c->pending.clear();
 }
@@ -294,11 +306,8 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, int cohort) {
         launch_ld_colsum(it.b, it.n_b, pl, c->dot_partials, s);
         prof_end(c, s, e0, VILMA_PROF_LD_COLSUM);
     }
-    if (it.n_comb > 0) {
-        prof_begin(c, s, e0);
+    if (it.n_comb > 0)      // not bracketed: tiny, and every event pair costs host time
         launch_ld_sym_combine(it.comb, it.n_comb, pl, c->sym_scratch, c->dot_partials, s);
-        prof_end(c, s, e0, VILMA_PROF_LD_COMBINE);
-    }
     if (c->pending.size() > 8192) prof_resolve(c);
 }
 
@@ -402,6 +411,7 @@ void vilma_destroy(vilma_ctx *c) {
     free_ready(c);
     for (auto &co : c->ld) dev_free(co.store);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
                     c->lh, c->counts, c->mu[0], c->mu[1], c->m[0], c->m[1], c->v[0], c->v[1], c->lse[0],
                     c->lse[1], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials,
@@ -697,6 +707,7 @@ int vilma_fetch(vilma_ctx *c, void *stream, const double *src_dev, double *dst_h
     if (n <= 0) return 0;
     if (n > c->pinned_elems) {
         if (c->pinned) (void)hipHostFree(c->pinned);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
         c->pinned = nullptr;
         c->pinned_elems = 0;
         HIPCHK(c, hipHostMalloc((void **)&c->pinned, (size_t)n * sizeof(double), hipHostMallocDefault));
