@@ -73,20 +73,55 @@ def cpu_baseline(workload, seed, n_blocks, n_sweeps):
         avail = os.cpu_count() or 1
     threads = max(1, min(16, avail))
     from threadpoolctl import threadpool_limits
+    cpu_elbos = []
     with threadpool_limits(limits=threads):
         np.random.seed(42)
         params = vi._initialize()
         elbo = vi.elbo(params)
+        cpu_elbos.append(elbo)
         L, red = np.ones(5), None
         params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)       # warm-up sweep
+        cpu_elbos.append(elbo)
         t0 = time.perf_counter()
         for _ in range(n_sweeps):
             params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
+            cpu_elbos.append(elbo)
         dt = time.perf_counter() - t0
     frac = sh.N / full.N_global
+    parity = None
+    try:
+        # "ELBO vs CPU": the same sample through the product class API on the GPU, same seed
+        from vilma_amd.matrix_structures import LowRankMatrix, BlockDiagonalMatrix
+        from vilma_amd.variational_inference import MultiPopVI
+        gld = [BlockDiagonalMatrix([LowRankMatrix(u=b.u, s=b.s, v=b.v, D=np.zeros(b.u.shape[0]))
+                                    for b in ld[p].blocks], perm=sh.perm, missing=sh.missing)
+               for p in range(P)]
+        gvi = MultiPopVI(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=gld,
+                         annotations=annotations, mixture_covs=list(sh.covs), checkpoint=False,
+                         scaled=False, scale_se=False, gwas_N=sh.gwas_N, init_hg=sh.init_hg,
+                         num_its=n_sweeps + 1)
+        np.random.seed(42)
+        gp = gvi._initialize()
+        gelbo, gL, gred = gvi.elbo(gp), np.ones(5), None
+        gpu_elbos = [gelbo]
+        for _ in range(n_sweeps + 1):
+            gp, gL, gelbo, gred = gvi._optimize_step(gp, gL, gelbo, 2., gred)
+            gpu_elbos.append(gelbo)
+        cm = vi.real_posterior_mean(*params)
+        gm = gvi.real_posterior_mean(gp)
+        dev = np.abs(np.array(gpu_elbos) - np.array(cpu_elbos)) / np.abs(np.array(cpu_elbos))
+        parity = {'sweeps': n_sweeps + 1, 'elbo_max_rel_dev': float(dev.max()),
+                  'post_mean_max_abs_dev': float(np.abs(gm - cm).max()),
+                  'post_mean_max_rel_dev_where_gt_1e-6': float(
+                      (np.abs(gm - cm) / np.maximum(np.abs(cm), 1e-300))[np.abs(cm) > 1e-6].max()),
+                  'L_trajectory_equal': bool(np.array_equal(gL, L)),
+                  'bar': 'ELBO and posterior means within 1e-5 relative'}
+        gvi.engine.close()
+    except Exception as exc:
+        parity = {'error': repr(exc)}
     return {
         'value': (n_sweeps / dt) * frac, 'unit': 'sweeps/s', 'cores': int(threads),
-        'kind': 'port',
+        'kind': 'port', 'parity_vs_cpu': parity,
         'sample': ('oracle (numpy restatement of the reference schedule; BLAS gemv threaded on '
                    '%d threads, per-SNP passes single-threaded) on the first %d of %d blocks '
                    '(%d of %d SNPs, all %d cohorts, M=%d): %d sweeps in %.2f s after 1 warm-up; '
