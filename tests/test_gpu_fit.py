@@ -168,3 +168,32 @@ def test_synthetic_eigen_form_constants_match_class_api():
         vi.optimize()
         elbos[form] = vi._objective
     assert abs(elbos['eig'] - elbos['dense']) < 1e-9 * abs(elbos['eig'])
+
+
+def test_cli_under_torchrun_two_ranks(tmp_path):
+    """`torchrun --nproc-per-node 2 -m vilma_amd fit ...` (rehearsed over gloo with both ranks on
+    this GPU): rank 0 writes the same outputs as the single-process run."""
+    import subprocess
+    ref = os.path.join(GOLDEN, 'refdata')
+    common = ['fit', '--ld-schema', os.path.join(ref, 'ld_manifest.tsv'),
+              '--sumstats', os.path.join(ref, 'good_sumstats_beta.tsv'),
+              '-K', '20', '--ldthresh', '0.8', '--init-hg', '0.2', '--samplesizes', '10e3',
+              '--names', 'c', '--learn-scaling', '--num-its', '12',
+              '--extract', os.path.join(ref, 'good_variants.tsv')]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    one = str(tmp_path / 'one')
+    subprocess.check_call([sys.executable, '-m', 'vilma_amd'] + common + ['--output', one],
+                          env=env, cwd=root)
+    two = str(tmp_path / 'two')
+    env2 = dict(env, VILMA_DIST_BACKEND='gloo', VILMA_SAME_DEVICE='1')
+    subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                           '--master-port', str(29700 + os.getpid() % 200), '-m', 'vilma_amd']
+                          + common + ['--output', two], env=env2, cwd=root)
+    a, b = np.load(one + '.npz'), np.load(two + '.npz')
+    for key in a.files:
+        np.testing.assert_allclose(b[key], a[key], rtol=1e-9, atol=1e-13, err_msg=key)
+    ta = open(one + '.estimates.tsv').read().splitlines()
+    tb = open(two + '.estimates.tsv').read().splitlines()
+    assert ta[0] == tb[0] and len(ta) == len(tb)

@@ -10,6 +10,33 @@ them with torch.distributed (backend "nccl" = RCCL over xGMI on MI355X, "gloo" i
 import numpy as np
 
 
+def init_distributed_from_env():
+    """Under a multi-process launcher (torchrun: WORLD_SIZE > 1) join the process group -- one
+    rank per GPU, backend nccl (= RCCL) -- and bind this process to its GPU.  Does nothing for a
+    plain single-process run or when the caller has already initialised torch.distributed.
+    VILMA_DIST_BACKEND=gloo and VILMA_SAME_DEVICE=1 exist for rehearsals on a one-GPU box."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return False
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return True
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('VILMA_SAME_DEVICE') == '1':
+        local_rank = 0
+    backend = os.environ.get('VILMA_DIST_BACKEND', 'nccl')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        dist.init_process_group(backend)
+    return True
+
+
 class Comm:
     """Thin wrapper over torch.distributed; a no-op for a single process."""
 

@@ -138,6 +138,8 @@ def _make_simple(num_pops, num_components, mins, maxes):
 
 
 def main(args, _engine_factory=None):
+    from .sharding import init_distributed_from_env
+    init_distributed_from_env()          # torchrun --nproc-per-node G: one rank per GPU
     np.random.seed(args.seed)
     n_schema_commas = args.ld_schema.count(',')
     if (not args.trait and n_schema_commas != 1
