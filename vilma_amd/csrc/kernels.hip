@@ -1,16 +1,20 @@
 // Hand-written gfx950 (CDNA4, wave64) kernels for the `vilma fit` hot path.
 //
-//   ld_colsum_kernel   block-diagonal LD product (dense blocks and both passes of the eigen
-//                      form) -- replaces BlockDiagonalMatrix.dot / LowRankMatrix.dot
-//                      (reference matrix_structures.py:389-408, 148-152).  HBM-streaming:
-//                      every matrix element is read exactly once with 16-byte coalesced loads.
+//   ld_sym_kernel      block-diagonal LD product on dense symmetric blocks: streams only the
+//                      lower triangle (128-column slab panels), forming column sums and row sums
+//                      of each panel in one pass; ld_sym_combine_kernel adds the partials in a
+//                      fixed order -- replaces BlockDiagonalMatrix.dot (reference
+//                      matrix_structures.py:389-408).  HBM-streaming, 16-byte coalesced loads.
+//   ld_colsum_kernel   out[c] = sum_j A[j][c] x[j] on a 128-column slab: both passes of
+//                      eigen-form blocks, LowRankMatrix.dot (matrix_structures.py:148-152).
 //   snp_pass_kernel    fused per-SNP pass: natural-gradient blend, new_mu, mixture
 //                      responsibilities (online softmax), posterior moments, KL and likelihood
 //                      partial sums -- replaces numerics.py:11-146, 179-213 and
 //                      variational_inference.py:762-823, 873-885 for one candidate point.
-//   delta_kernel       responsibilities of the current state reduced per annotation
-//                      (numerics.py:118-129) or written out.
-//   finalize / reduce  deterministic fixed-order reductions of per-workgroup partials.
+//   delta_kernel       responsibilities of a state reduced per annotation (numerics.py:118-129)
+//                      or written out;  mstep_kernel: the M-step table from those sums.
+//   finalize / reduce / mean_diff   deterministic fixed-order reductions of per-workgroup
+//                      partials and the convergence statistics.  No atomics anywhere.
 //
 // All arithmetic is IEEE double.  vi_sigma, nat_sigma, vi_sigma_log_det, vi_sigma_matches and
 // sigma_summary ([M,P,P,N] / [N,M] arrays in the reference, variational_inference.py:712-733)

@@ -94,9 +94,6 @@ class HipEngine:
         except Exception:
             pass
 
-    def new_result(self, n):
-        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
-
     def synchronize(self):
         self.torch.cuda.synchronize()
 
