@@ -197,3 +197,32 @@ def test_cli_under_torchrun_two_ranks(tmp_path):
     ta = open(one + '.estimates.tsv').read().splitlines()
     tb = open(two + '.estimates.tsv').read().splitlines()
     assert ta[0] == tb[0] and len(ta) == len(tb)
+
+
+def test_rccl_stream_ordering_with_one_rank_group():
+    """A one-rank nccl (= RCCL) process group with forced collectives: every decision of the fit
+    goes kernels -> RCCL all-reduce on a slice of the result vector -> pinned fetch, exactly the
+    multi-GPU sequence, and must reproduce the reference trajectory."""
+    import torch
+    import torch.distributed as dist
+    from vilma_amd.sharding import Comm
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ['MASTER_PORT'] = str(29800 + os.getpid() % 100)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        comm = Comm(force=True)
+        assert comm.active and comm.backend == 'nccl'
+        for name in ('p2_scale_se', 'p2_lowrank'):
+            g = golden('traj_%s.npz' % name)
+            vi, _ = product_vi_from_traj(g, comm=comm)
+            check_trajectory(vi, g)
+            np.random.seed(int(g['seed']))
+            vi2, _ = product_vi_from_traj(g, comm=comm, num_its=12)
+            vi2.optimize()                       # the pipelined loop under RCCL ordering
+            vi3, _ = product_vi_from_traj(g, num_its=12)
+            np.random.seed(int(g['seed']))
+            vi3.optimize()
+            assert vi2.num_its_run == vi3.num_its_run
+            assert abs(vi2._objective - vi3._objective) <= 1e-12 * abs(vi3._objective)
+    finally:
+        dist.destroy_process_group()

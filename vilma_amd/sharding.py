@@ -40,9 +40,10 @@ def init_distributed_from_env():
 class Comm:
     """Thin wrapper over torch.distributed; a no-op for a single process."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
         self.rank, self.world = 0, 1
         self._dist = None
+        self._force = force
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -54,9 +55,15 @@ class Comm:
         except ImportError:
             pass
 
+    @property
+    def active(self):
+        """True when collectives actually run: more than one rank, or `force` (a one-rank group
+        used to rehearse the RCCL stream ordering on a single GPU)."""
+        return self._dist is not None and (self.world > 1 or self._force)
+
     def allreduce(self, tensor, op='sum'):
         """All-reduce a small float64 torch tensor (any device) and return it as numpy."""
-        if self.world > 1:
+        if self.active:
             dist = self._dist
             t = tensor
             if self.backend == 'gloo' and t.is_cuda:
@@ -71,7 +78,7 @@ class Comm:
     def allreduce_inplace(self, tensor, op='sum'):
         """All-reduce a (view of a) torch tensor in place, without a host copy when the backend
         can work on its device (nccl/RCCL on GPU tensors, gloo on CPU tensors)."""
-        if self.world == 1:
+        if not self.active:
             return tensor
         dist = self._dist
         rop = dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX
@@ -84,7 +91,7 @@ class Comm:
         return tensor
 
     def allreduce_np(self, array, op='sum'):
-        if self.world == 1:
+        if not self.active:
             return np.array(array, dtype=np.float64)
         import torch
         return self.allreduce(torch.as_tensor(np.ascontiguousarray(array, dtype=np.float64)), op)

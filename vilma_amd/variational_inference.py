@@ -207,7 +207,7 @@ class SweepDriver:
         part [lo, hi) of the engine's result vector -- and download the whole vector in ONE
         device->host copy.  Returns the host copy; slices are in engine.layout."""
         eng = self.engine
-        if self.comm.world > 1:
+        if self.comm.active:
             self.comm.allreduce_inplace(eng.results[lo:hi])
             if with_max and self._verbose:
                 self.comm.allreduce_inplace(eng.results[eng.layout.dmax], op='max')
@@ -327,7 +327,7 @@ class SweepDriver:
             # no accepted beta step since the last evaluation (line search gave up or resumed
             # state): compute the statistic of the current state now
             sums = eng.delta_sums()
-            if self.comm.world > 1:
+            if self.comm.active:
                 self.comm.allreduce_inplace(sums)
         # otherwise the sums of the accepted trial are still in the result vector (all-reduced)
         eng.mstep()
@@ -638,7 +638,7 @@ class MultiPopVI(SweepDriver):
         sums = self.comm.allreduce_np(np.concatenate([chi_loc, rank_loc]))
         self.chi_stat, self.ld_ranks = sums[:P], sums[P:]
         inv_se2 = self.comm.allreduce_np((self.std_errs[:, loc] ** -2).sum(axis=1)) \
-            if self.comm.world > 1 else (self.std_errs ** -2).sum(axis=1)
+            if self.comm.active else (self.std_errs ** -2).sum(axis=1)
         inverse_loc = np.zeros((P, n_loc))
         for p in range(P):
             prior = 2 * self.gwas_N[p] * self.init_hg[p] / inv_se2[p]
