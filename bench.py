@@ -157,7 +157,13 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
-    comm = Comm()
+    force = os.environ.get('VILMA_BENCH_FORCE_RCCL') == '1'
+    if force and world == 1:
+        # diagnostic: a one-rank RCCL group so every decision pays a real all-reduce launch
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29621')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+    comm = Comm(force=force)
 
     cfg = dict(WORKLOADS[args.workload])
     t_setup = time.perf_counter()
