@@ -137,23 +137,10 @@ void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *do
 // 8 KiB streamed).  Both kinds of partial go to a scratch S[slab][j]; ld_sym_combine_kernel adds
 // them in slab order (fixed order => deterministic) and forms the y.z partials.
 // --------------------------------------------------------------------------------------------
-// one group of 8 panel rows: column-sum FMAs, row-sum partials, butterfly, scratch write
-template <bool FULL>
-static __device__ __forceinline__ void sym_group(const v2d (&v)[CS_ROWS], const double *__restrict__ xrow,
-                                                 int r0, int rows, double xs0, double xs1,
-                                                 double &acc0, double &acc1, int lane, int slab_w,
-                                                 double *__restrict__ srow) {
-    double p[CS_ROWS];
-#pragma unroll
-    for (int u = 0; u < CS_ROWS; ++u) {
-        const double xv = (FULL || r0 + u < rows) ? xrow[FULL ? r0 + u : min(r0 + u, rows - 1)] : 0.0;
-        const double xz = (FULL || r0 + u < rows) ? xv : 0.0;
-        acc0 = fma(v[u].x, xz, acc0);
-        acc1 = fma(v[u].y, xz, acc1);
-        p[u] = fma(v[u].x, xs0, v[u].y * xs1);
-    }
-    // halving butterfly: after the three steps lane l holds row (bit5*4 + bit4*2 + bit3) summed
-    // over the 8 lanes that differ from it in bits 5,4,3; three plain steps finish bits 2..0
+// halving butterfly over 8 row partials: after the three exchange steps lane l holds row
+// (bit5*4 + bit4*2 + bit3) summed over the 8 lanes that differ from it in bits 5,4,3; three
+// plain steps finish bits 2..0.  Returns the total of that row in every lane of its group.
+static __device__ __forceinline__ double sym_rowsum8(const double (&p)[CS_ROWS], int lane, int &row) {
     const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
     double q[4], r2[2], t1;
 #pragma unroll
@@ -176,15 +163,76 @@ static __device__ __forceinline__ void sym_group(const v2d (&v)[CS_ROWS], const 
     t1 += __shfl_xor(t1, 4);
     t1 += __shfl_xor(t1, 2);
     t1 += __shfl_xor(t1, 1);
-    const int rr = r0 + ((h5 ? 4 : 0) | (h4 ? 2 : 0) | (h3 ? 1 : 0));
-    if ((lane & 7) == 0 && (FULL || rr < rows) && rr >= slab_w)   // strictly below the diagonal tile
-        srow[rr] = t1;
+    row = (h5 ? 4 : 0) | (h4 ? 2 : 0) | (h3 ? 1 : 0);
+    return t1;
+}
+
+// one group of 8 panel rows BELOW the diagonal tile: every element feeds a column sum (with the
+// row's x) and a row sum (with the column's x); row sums go to scratch
+template <bool FULL>
+static __device__ __forceinline__ void sym_group(const v2d (&v)[CS_ROWS], const double *__restrict__ xrow,
+                                                 int r0, int rows, double xs0, double xs1,
+                                                 double &acc0, double &acc1, int lane,
+                                                 double *__restrict__ srow) {
+    double p[CS_ROWS];
+#pragma unroll
+    for (int u = 0; u < CS_ROWS; ++u) {
+        const double xv = xrow[FULL ? r0 + u : min(r0 + u, rows - 1)];
+        const double xz = (FULL || r0 + u < rows) ? xv : 0.0;
+        acc0 = fma(v[u].x, xz, acc0);
+        acc1 = fma(v[u].y, xz, acc1);
+        p[u] = fma(v[u].x, xs0, v[u].y * xs1);
+    }
+    int rsub;
+    const double t1 = sym_rowsum8(p, lane, rsub);
+    const int rr = r0 + rsub;
+    if ((lane & 7) == 0 && (FULL || rr < rows)) srow[rr] = t1;
+}
+
+// one group of 8 rows INSIDE the diagonal tile (row r, column c of the tile): only the lower
+// triangle is used -- c <= r feeds the column sum, c < r the row sum -- so for these rows only
+// the 128-byte lines up to the diagonal are loaded at all (lanes past them are masked off):
+// 56 % of a 128 x 128 tile.  Row sums of the tile go to LDS (they belong to the same output
+// entries as the tile's column sums).
+static __device__ __forceinline__ void sym_group_diag(const double *__restrict__ rp, int64_t ld,
+                                                      const double *__restrict__ xrow, int r0,
+                                                      int rows, int cl, double xs0, double xs1,
+                                                      double &acc0, double &acc1, int lane,
+                                                      double *__restrict__ rs_lds) {
+    v2d v[CS_ROWS];
+    // columns needed by rows r0..r0+7: c <= r0+7, rounded up to whole 16-double lines
+    const int lim = 8 * ((r0 + CS_ROWS - 1) / 16 + 1);           // lanes (2 columns each)
+    if (lane < lim) {
+#pragma unroll
+        for (int u = 0; u < CS_ROWS; ++u)
+            v[u] = *(gd2_ptr)(rp + (int64_t)min(u, rows - 1 - r0) * ld);
+    } else {
+#pragma unroll
+        for (int u = 0; u < CS_ROWS; ++u) v[u] = v2d{0.0, 0.0};
+    }
+    double p[CS_ROWS];
+#pragma unroll
+    for (int u = 0; u < CS_ROWS; ++u) {
+        const int r = r0 + u;
+        const double xv = xrow[min(r, rows - 1)];
+        const double xz = r < rows ? xv : 0.0;
+        const double a0 = cl <= r ? v[u].x : 0.0, a1 = cl + 1 <= r ? v[u].y : 0.0;   // c <= r
+        acc0 = fma(a0, xz, acc0);
+        acc1 = fma(a1, xz, acc1);
+        const double b0 = cl < r ? v[u].x : 0.0, b1 = cl + 1 < r ? v[u].y : 0.0;     // c <  r
+        p[u] = fma(b0, xs0, b1 * xs1);
+    }
+    int rsub;
+    const double t1 = sym_rowsum8(p, lane, rsub);
+    const int rr = r0 + rsub;
+    if ((lane & 7) == 0 && rr < rows) rs_lds[rr] = t1;
 }
 
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     const SymItem *__restrict__ items, const double *__restrict__ xpool,
     double *__restrict__ scratch) {
     __shared__ double red[CS_WAVES][128];
+    __shared__ double rs_diag[128];
     const SymItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -196,28 +244,35 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     // x of this lane's two columns (the slab's columns are rows j0.. of the same vector)
     const double xs0 = active ? xrow[cl] : 0.0;
     const double xs1 = (cl + 1 < it.w) ? xrow[cl + 1] : 0.0;
-    // loads are unconditional (a select around a load makes hipcc branch and wait per element):
-    // lanes beyond the slab read column 0 and are neutralised by xs = 0
+    // loads are unconditional within a group (a select around a load makes hipcc branch and wait
+    // per element): lanes beyond the slab read column 0 and are neutralised by xs = 0
     const double *ap = it.a + (active ? cl : 0);
     double *__restrict__ srow = scratch + it.s_off + it.j0;
     double acc0 = 0.0, acc1 = 0.0;
-    const int nfull = rows / CS_ROWS;              // full 8-row groups; group g belongs to wave g % 4
+    const int ngroups = (rows + CS_ROWS - 1) / CS_ROWS;     // group g belongs to wave g % 4
+    const int ndiag = (it.w + CS_ROWS - 1) / CS_ROWS;       // groups inside the diagonal tile
+    const int nfull = rows / CS_ROWS;
     const int64_t gstride = (int64_t)CS_WAVES * CS_ROWS * ld;
-    v2d v[CS_ROWS];
     const double *rp = ap + (int64_t)w * CS_ROWS * ld;
-    // plain loop: 8 x 1 KiB loads in flight per wave, latency hidden by occupancy (a manually
-    // software-pipelined version with two register sets measured the same, 1.20 ms @C3)
-    for (int g = w; g < nfull; g += CS_WAVES, rp += gstride) {
+    int g = w;
+    // (1) the diagonal tile: lower triangle only
+    for (; g < ndiag && g < ngroups; g += CS_WAVES, rp += gstride)
+        sym_group_diag(rp, ld, xrow, g * CS_ROWS, rows, active ? cl : 2 * 64, xs0, xs1, acc0, acc1,
+                       lane, rs_diag);
+    // (2) the rows below it: plain loop, 8 x 1 KiB loads in flight per wave, latency hidden by
+    // occupancy (a manually software-pipelined version measured the same, 1.20 ms @C3)
+    v2d v[CS_ROWS];
+    for (; g < nfull; g += CS_WAVES, rp += gstride) {
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u) v[u] = *(gd2_ptr)(rp + (int64_t)u * ld);
-        sym_group<true>(v, xrow, g * CS_ROWS, rows, xs0, xs1, acc0, acc1, lane, it.w, srow);
+        sym_group<true>(v, xrow, g * CS_ROWS, rows, xs0, xs1, acc0, acc1, lane, srow);
     }
-    if ((rows % CS_ROWS) != 0 && (nfull % CS_WAVES) == w) {     // the one partial group
+    if (g == nfull && g < ngroups) {                        // the one partial group, below the tile
         const int r0 = nfull * CS_ROWS;
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u)     // rows past the end re-read the last row
             v[u] = *(gd2_ptr)(ap + (int64_t)min(r0 + u, rows - 1) * ld);
-        sym_group<false>(v, xrow, r0, rows, xs0, xs1, acc0, acc1, lane, it.w, srow);
+        sym_group<false>(v, xrow, r0, rows, xs0, xs1, acc0, acc1, lane, srow);
     }
     red[w][2 * lane] = acc0;
     red[w][2 * lane + 1] = acc1;
@@ -226,7 +281,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
         double s = red[0][threadIdx.x];
 #pragma unroll
         for (int ww = 1; ww < CS_WAVES; ++ww) s += red[ww][threadIdx.x];
-        srow[threadIdx.x] = s;                                  // the slab's own (diagonal) entry
+        srow[threadIdx.x] = s + rs_diag[threadIdx.x];           // the slab's own (diagonal) entry
     }
 }
 
