@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--cpu-blocks', type=int, default=96,
                     help='blocks of the workload in the CPU-baseline sample')
     ap.add_argument('--cpu-sweeps', type=int, default=5)
+    ap.add_argument('--prof-every', type=int, default=4,
+                    help='bracket every k-th LD product with HIP events (roofline.avg_launch_ms)')
     ap.add_argument('--emulate-shard', type=int, default=0,
                     help='diagnostic: time rank 0 of a K-way sharding alone on one GPU '
                          '(no collectives; NOT a valid bench line)')
@@ -206,7 +208,7 @@ def main():
         engine.snapshot_mean()
         state = {'L': np.ones(5), 'elbo': driver._objective, 'running': None}
 
-    engine.prof_enable(True)
+    engine.prof_enable(True, every=args.prof_every)
     engine.prof_read(reset=True)
     ev0, tr0 = driver.n_evaluations, driver.n_trials
     if world > 1:

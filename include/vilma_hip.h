@@ -14,7 +14,12 @@
  *   - all floating point is IEEE double; index arrays are int32/int64 as declared.
  *   - "host or device" pointers may be either (copies use hipMemcpyDefault).
  *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  Calls that take a
- *     stream are asynchronous on it; calls without one synchronise internally.
+ *     stream are asynchronous on it; calls without one synchronise internally.  Work that depends
+ *     only on the per-SNP pass of the latest evaluation (vilma_delta_sums of a trial state,
+ *     vilma_mean_diff) may run on a context-owned side stream, concurrently with that
+ *     evaluation's LD product; `stream` is made to wait for it before the call returns, so
+ *     from the caller's side everything is still ordered on `stream` (VILMA_OVERLAP=0 in the
+ *     environment disables the side stream).
  *   - one context drives ONE GPU (the device current at vilma_create).  Multi-GPU = one
  *     process and one context per GPU, each holding a shard of the SNPs; the host all-reduces
  *     the small `totals` vectors (RCCL via torch.distributed).
@@ -181,9 +186,10 @@ int vilma_fetch(vilma_ctx *ctx, void *stream, const double *src_dev, double *dst
 
 /* ---- measurement ----------------------------------------------------------------------- */
 
-/* When enabled, every LD-product kernel launch is bracketed by HIP events on its stream.
- * vilma_prof_read synchronises the device and returns, per kernel kind, the accumulated kernel
- * milliseconds and number of launches since the last reset (arrays of VILMA_PROF_KINDS). */
+/* vilma_prof_enable(ctx, k): k = 0 off; k >= 1 brackets every k-th LD product's streaming kernels
+ * with HIP events on their stream (a pair costs a few microseconds of stream time, so small
+ * shards sample).  vilma_prof_read synchronises the device and returns, per kernel kind, the accumulated kernel
+ * milliseconds and number of bracketed launches since the last reset (arrays of VILMA_PROF_KINDS). */
 #define VILMA_PROF_LD_SYM 0      /* ld_sym_kernel: symmetric dense blocks, lower triangle read once */
 #define VILMA_PROF_LD_COLSUM 1   /* ld_colsum_kernel: both passes of eigen-form blocks */
 #define VILMA_PROF_LD_COMBINE 2  /* reserved (ld_sym_combine_kernel is not bracketed) */

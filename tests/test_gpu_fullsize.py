@@ -4,6 +4,8 @@ C2 (1 cohort, 100k SNPs, 500x200 blocks, M=25) is small enough for a direct comp
 oracle.  C3 (2 cohorts, 1M SNPs, ~1700 blocks, M=40) is checked through size-independent
 properties: the LD operator against the O(n) closed form of an AR(1) product, linearity,
 symmetry; the fit through ELBO monotonicity, line-search invariants and finiteness."""
+import os
+
 import numpy as np
 import pytest
 from scipy.signal import lfilter
@@ -119,4 +121,32 @@ def test_c2_three_sweeps_against_oracle():
         assert np.array_equal(state['L'], oL)
     mean, _ = eng.get_moments()
     np.testing.assert_allclose(mean, ovi._posterior_mean(*oparams), rtol=1e-6, atol=1e-10)
+    eng.close()
+
+
+@pytest.mark.skipif(os.environ.get('VILMA_TEST_C5') != '1',
+                    reason='C5 (4 cohorts, 5M SNPs, M=81) takes ~10 min of setup: set VILMA_TEST_C5=1')
+def test_c5_operator_and_fit_invariants():
+    """BASELINE.json configs[4] on ONE GPU: P=4 (Cholesky branch of the per-SNP pass), 34 000
+    block-cohorts, ~100 GB resident.  Same size-independent properties as C3."""
+    sh, eng, drv, vi_mu0, hyper0 = _setup('C5')
+    assert sh.P == 4 and sh.M == 81 and sh.N_global > 5_000_000 and len(sh.sizes_all) == 8500
+    rng = np.random.default_rng(6)
+    x = rng.normal(size=(sh.P, sh.N))
+    rx = eng.ld_matvec(x)
+    for p in range(sh.P):
+        np.testing.assert_allclose(rx[p], _ar1_product(sh, p, x[p]), rtol=1e-10, atol=1e-10)
+    assert np.all(rx[:, sh.missing] == 0.0)
+    drv.start_from(vi_mu0, hyper0)
+    state, elbo_prev = None, drv._objective
+    assert np.isfinite(elbo_prev)
+    for it in range(3):
+        state, stats = drv.sweep(state)
+        assert state['elbo'] >= elbo_prev - 25 * (1e-6 * abs(elbo_prev) + 1e-6)
+        assert np.all(np.isfinite(stats))
+        elbo_prev = state['elbo']
+    mean, var = eng.get_moments()
+    assert np.all(np.isfinite(mean)) and np.all(var >= 0)
+    obj, _ = drv._evaluate()
+    assert abs(obj - drv._objective) <= 1e-12 * abs(obj)
     eng.close()

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -81,7 +82,7 @@ struct vilma_ctx {
 
     double *snapshot = nullptr, *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;
-    int32_t *dot_start = nullptr;
+    std::vector<int32_t> dot_start;     // first y.z partial slot of each cohort (+ end)
 
     std::vector<CohortLd> ld;
     ItemSet all;
@@ -91,7 +92,16 @@ struct vilma_ctx {
     int64_t pinned_elems = 0;
     bool ready = false;
 
-    bool prof = false;
+    // Work that depends only on the per-SNP pass of an evaluation (responsibility sums of the
+    // trial state, convergence statistics) runs on `side`, concurrently with that evaluation's LD
+    // product on the caller's stream: gated on ev_snp, joined back through ev_side.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_snp = nullptr, ev_side = nullptr;
+    bool overlap = true, snp_marked = false;
+
+    int prof = 0;                   // 0 off, k >= 1: bracket every k-th LD launch
+    int64_t prof_tick = 0;
+    bool prof_now = false;
     struct Pending { hipEvent_t e0, e1; int kind; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
@@ -161,10 +171,12 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
                 H.sym.push_back(it);
                 off += sym_panel_elems(b.n, J);
             }
-            SymCombItem cb;
-            cb.n = b.n; cb.s_base = s_off; cb.y_off = PN + pN + b.start;
-            cb.dot_off = pN + b.start; cb.dot_slot = slot++; cb.pad = 0;
-            H.comb.push_back(cb);
+            for (int j0 = 0; j0 < b.n; j0 += 256) {         // one workgroup per 256 columns
+                SymCombItem cb;
+                cb.n = b.n; cb.s_base = s_off; cb.y_off = PN + pN + b.start;
+                cb.dot_off = pN + b.start; cb.dot_slot = slot++; cb.j0 = j0;
+                H.comb.push_back(cb);
+            }
             s_off += ns * b.n;
         } else {
             for (int c0 = 0; c0 < b.r; c0 += 128) {        // t = U^T x
@@ -244,8 +256,7 @@ int ensure_ready(vilma_ctx *c) {
         if (dev_alloc(c, &c->pool[s], pool_elems)) return 1;
     if (dev_alloc(c, &c->dot_partials, slot)) return 1;
     if (dev_alloc(c, &c->sym_scratch, s_base)) return 1;
-    HIPCHK(c, hipMemcpy(c->dot_start, dstart.data(), (c->P + 1) * sizeof(int32_t),
-                        hipMemcpyHostToDevice));
+    c->dot_start = dstart;
     c->ready = true;
     return 0;
 }
@@ -263,12 +274,12 @@ hipEvent_t prof_event(vilma_ctx *c) {
     return e;
 }
 void prof_begin(vilma_ctx *c, hipStream_t s, hipEvent_t &e0) {
-    if (!c->prof) return;
+    if (!c->prof_now) return;
     e0 = prof_event(c);
     (void)hipEventRecord(e0, s);
 }
 void prof_end(vilma_ctx *c, hipStream_t s, hipEvent_t e0, int kind) {
-    if (!c->prof) return;
+    if (!c->prof_now) return;
     hipEvent_t e1 = prof_event(c);
     (void)hipEventRecord(e1, s);
     c->pending.push_back({e0, e1, kind});
@@ -291,6 +302,7 @@ void prof_resolve(vilma_ctx *c) {
 void run_ld(vilma_ctx *c, hipStream_t s, double *pl, int cohort) {
     const ItemSet &it = cohort < 0 ? c->all : c->solo[cohort];
     hipEvent_t e0;
+    c->prof_now = c->prof > 0 && (c->prof_tick++ % c->prof) == 0;
     if (it.n_sym > 0) {
         prof_begin(c, s, e0);
         launch_ld_sym(it.sym, it.n_sym, pl, c->sym_scratch, s);
@@ -335,6 +347,20 @@ void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out, bool trial_mu = fa
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
 }
 
+// Stream for work that only needs the latest per-SNP pass: the side stream once that pass has
+// been marked on the caller's stream, else the caller's stream itself.
+hipStream_t side_begin(vilma_ctx *c, hipStream_t s) {
+    if (!c->overlap || !c->snp_marked || !c->side) return s;
+    if (hipStreamWaitEvent(c->side, c->ev_snp, 0) != hipSuccess) return s;
+    return c->side;
+}
+// Everything queued on `s` from here on is ordered after the side work.
+void side_end(vilma_ctx *c, hipStream_t s, hipStream_t used) {
+    if (used == s) return;
+    (void)hipEventRecord(c->ev_side, used);
+    (void)hipStreamWaitEvent(s, c->ev_side, 0);
+}
+
 int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *totals_dev) {
     if (ensure_ready(c)) return 1;
     if (blend && !c->have_moments)
@@ -342,8 +368,12 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     SnpKernelArgs a;
     fill_snp_args(c, a, step);
     launch_snp_pass(a, blend, s);
+    if (c->overlap && c->ev_snp) {
+        (void)hipEventRecord(c->ev_snp, s);
+        c->snp_marked = true;
+    }
     run_ld(c, s, c->pool[1 - c->mom_cur], -1);
-    launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start,
+    launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start.data(),
                     totals_dev, s);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -393,13 +423,23 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     rc |= dev_alloc(c, &c->delta_partials,
                     ((int64_t)delta_grid(N) * 4 + delta_grid(N) / 64 + 8) * A * M);
     rc |= dev_alloc(c, &c->diff_partials, (int64_t)mean_diff_grid(PN) * 6);
-    rc |= dev_alloc(c, &c->dot_start, P + 1);
     if (rc) {
         g_create_error = c->err;
         vilma_destroy(c);
         return 1;
     }
     c->log_det_host.assign(M, 0.0);
+    // VILMA_OVERLAP=0 keeps everything on the caller's stream (A/B measurements)
+    const char *ov = std::getenv("VILMA_OVERLAP");
+    c->overlap = !(ov && ov[0] == '0');
+    if (c->overlap &&
+        (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+         hipEventCreateWithFlags(&c->ev_snp, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess)) {
+        g_create_error = "cannot create the side stream";
+        vilma_destroy(c);
+        return 1;
+    }
     *out = c;
     return 0;
 }
@@ -412,10 +452,12 @@ void vilma_destroy(vilma_ctx *c) {
     for (auto &co : c->ld) dev_free(co.store);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->ev_snp) (void)hipEventDestroy(c->ev_snp);
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->side) (void)hipStreamDestroy(c->side);
     void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
                     c->lh, c->counts, c->mu[0], c->mu[1], c->m[0], c->m[1], c->v[0], c->v[1], c->lse[0],
-                    c->lse[1], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials,
-                    c->dot_start};
+                    c->lse[1], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials};
     for (void *p : ptrs) dev_free(p);
     delete c;
 }
@@ -679,7 +721,11 @@ int vilma_delta_sums(vilma_ctx *c, void *stream, double *sums_dev, int which) {
     // the trial of a beta step has its own vi_mu; the trial of a plain evaluation shares it
     fill_delta_args(c, a, c->delta_partials, which == VILMA_STATE_TRIAL_BETA,
                     which != VILMA_STATE_CURRENT);
-    launch_delta_sums(a, sums_dev, (hipStream_t)stream);
+    // a trial state's sums depend on its per-SNP pass alone: overlap them with its LD product
+    hipStream_t s = (hipStream_t)stream;
+    hipStream_t q = which == VILMA_STATE_CURRENT ? s : side_begin(c, s);
+    launch_delta_sums(a, sums_dev, q);
+    side_end(c, s, q);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -687,8 +733,11 @@ int vilma_delta_sums(vilma_ctx *c, void *stream, double *sums_dev, int which) {
 int vilma_mean_diff(vilma_ctx *c, void *stream, double *out_sum3_dev, double *out_max3_dev) {
     if (!c) return 1;
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    hipStream_t s = (hipStream_t)stream;
+    hipStream_t q = side_begin(c, s);
     launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,
-                     c->diff_partials, out_sum3_dev, out_max3_dev, true, (hipStream_t)stream);
+                     c->diff_partials, out_sum3_dev, out_max3_dev, true, q);
+    side_end(c, s, q);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -696,6 +745,7 @@ int vilma_mean_diff(vilma_ctx *c, void *stream, double *out_sum3_dev, double *ou
 int vilma_snapshot_mean(vilma_ctx *c, void *stream) {
     if (!c) return 1;
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    c->snp_marked = false;      // the snapshot is written on `stream`: a following mean_diff stays there
     launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,
                      c->diff_partials, nullptr, nullptr, false, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
@@ -707,7 +757,6 @@ int vilma_fetch(vilma_ctx *c, void *stream, const double *src_dev, double *dst_h
     if (n <= 0) return 0;
     if (n > c->pinned_elems) {
         if (c->pinned) (void)hipHostFree(c->pinned);
-    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
         c->pinned = nullptr;
         c->pinned_elems = 0;
         HIPCHK(c, hipHostMalloc((void **)&c->pinned, (size_t)n * sizeof(double), hipHostMallocDefault));
@@ -722,7 +771,8 @@ int vilma_fetch(vilma_ctx *c, void *stream, const double *src_dev, double *dst_h
 
 int vilma_prof_enable(vilma_ctx *c, int enable) {
     if (!c) return 1;
-    c->prof = enable != 0;
+    c->prof = enable > 0 ? enable : 0;
+    c->prof_tick = 0;
     return 0;
 }
 

@@ -38,7 +38,7 @@ struct SymCombItem {
     int32_t n;                // block size
     int32_t s_base;           // scratch offset of S[0][0] of the block
     int32_t y_off, dot_off, dot_slot;
-    int32_t pad;
+    int32_t j0;               // first of the (up to) 256 columns this workgroup combines
 };
 
 struct TauArg { double v[VILMA_MAX_P]; };
@@ -58,7 +58,7 @@ struct SnpKernelArgs {
     double *pool_out;         // trial pool (x_ld written)
     double *m_out, *v_out;    // [P][N]
     double *lse_out;          // [N]
-    double *partials;         // [grid][2P+3]
+    double *partials;         // [2P+2][grid] (column-major: finalize reads columns)
     double step;
     TauArg tau;
 };
@@ -75,7 +75,7 @@ void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
 
 // totals[0..2P) and [3P..3P+3) from the per-SNP partials, totals[2P..3P) from the matvec dots
 void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
-                     const int32_t *dot_start /*[P+1] device*/, double *totals, hipStream_t s);
+                     const int32_t *dot_start /*[P+1] host*/, double *totals, hipStream_t s);
 
 struct DeltaArgs {
     int32_t N, M, A, P;

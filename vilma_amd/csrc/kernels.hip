@@ -285,30 +285,30 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     }
 }
 
-// y[j] = sum_{J <= slab(j)} S[J][j] for one whole block per workgroup (slab order = fixed order),
-// with the block's y.z partial.
+// y[j] = sum_{J <= slab(j)} S[J][j] for 256 columns of one block per workgroup (slab order = fixed
+// order), with the chunk's y.z partial.  The slab index is wave-uniform; eight loads in flight.
 __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
     const SymCombItem *__restrict__ items, const double *__restrict__ xpool,
     double *__restrict__ ypool, const double *__restrict__ scratch,
     double *__restrict__ dot_partials) {
     __shared__ double dred[4];
     const SymCombItem it = items[blockIdx.x];
-    double dv = 0.0;
-    for (int j = threadIdx.x; j < it.n; j += 256) {
-        const int slab = j >> 7;
-        const double *sj = scratch + it.s_base + j;
-        double s = 0.0;
-        int J = 0;
-        for (; J + 3 <= slab; J += 4) {          // four independent loads in flight, fixed order
-            const double t0 = sj[(int64_t)J * it.n], t1 = sj[(int64_t)(J + 1) * it.n];
-            const double t2 = sj[(int64_t)(J + 2) * it.n], t3 = sj[(int64_t)(J + 3) * it.n];
-            s += (t0 + t1) + (t2 + t3);
-        }
-        for (; J <= slab; ++J) s += sj[(int64_t)J * it.n];
-        ypool[it.y_off + j] = s;
-        dv = fma(s, xpool[it.dot_off + j], dv);
+    const int j = it.j0 + threadIdx.x;
+    const bool live = j < it.n;
+    const int jj = live ? j : it.n - 1;
+    const int slab = jj >> 7;
+    const double *sj = scratch + it.s_base + jj;
+    const double xj = xpool[it.dot_off + jj];
+    double s = 0.0;
+    for (int J = 0; J <= slab; J += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = sj[(int64_t)min(J + u, slab) * it.n];   // no branch
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (J + u <= slab) ? t[u] : 0.0;
     }
-    dv = wave_sum(dv);
+    if (live) ypool[it.y_off + j] = s;
+    double dv = wave_sum(live ? s * xj : 0.0);
     if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = dv;
     __syncthreads();
     if (threadIdx.x == 0) dot_partials[it.dot_slot] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
         double s = red[0][threadIdx.x];
 #pragma unroll
         for (int ww = 1; ww < SNP_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
-        a.partials[(int64_t)blockIdx.x * NT + threadIdx.x] = s;
+        a.partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
     }
 }
 
@@ -798,66 +798,51 @@ static __device__ double block_strided_sum_1024(const double *__restrict__ v, in
     return block_sum_1024(acc, sh);
 }
 
-// One workgroup, ONE memory latency: every thread first accumulates all 2P+2 columns of its rows
-// (and its share of each cohort's y.z partials), then the columns are reduced across the
-// workgroup together (wave shuffles, one barrier, fixed order).
-#define FIN_MAXC (2 * VILMA_MAX_P + 2 + VILMA_MAX_P)
-__global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict__ snp_partials,
-                                                         int snp_rows, int P,
-                                                         const double *__restrict__ dot_partials,
-                                                         const int32_t *__restrict__ dot_start,
-                                                         double *__restrict__ totals) {
-    __shared__ double sh[16][FIN_MAXC];
+// One 256-thread workgroup per output: workgroups 0..2P+1 reduce a column of the per-SNP
+// partials (stored column-major, so the loads are contiguous), workgroups 2P+2.. reduce a cohort's
+// y.z partials.  Eight independent loads per thread per pass, fixed-order combination.
+struct DotStart { int32_t v[VILMA_MAX_P + 1]; };
+__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ snp_partials,
+                                                        int snp_rows, int P,
+                                                        const double *__restrict__ dot_partials,
+                                                        const DotStart dot_start,
+                                                        double *__restrict__ totals) {
+    __shared__ double sh[4];
     const int NT = 2 * P + 2;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double acc[FIN_MAXC];
-#pragma unroll
-    for (int c = 0; c < FIN_MAXC; ++c) acc[c] = 0.0;
-    for (int r = threadIdx.x; r < snp_rows; r += 1024) {
-        const double *row = snp_partials + (int64_t)r * NT;
-        double t[2 * VILMA_MAX_P + 2];
-#pragma unroll
-        for (int c = 0; c < 2 * VILMA_MAX_P + 2; ++c) t[c] = row[min(c, NT - 1)];   // no branch
-#pragma unroll
-        for (int c = 0; c < 2 * VILMA_MAX_P + 2; ++c) acc[c] += c < NT ? t[c] : 0.0;
+    const int c = blockIdx.x;
+    const double *src;
+    int n, out;
+    if (c < NT) {
+        src = snp_partials + (int64_t)c * snp_rows;
+        n = snp_rows;
+        out = c < 2 * P ? c : 3 * P + (c - 2 * P);
+    } else {
+        const int p = c - NT;
+        src = dot_partials + dot_start.v[p];
+        n = dot_start.v[p + 1] - dot_start.v[p];
+        out = 2 * P + p;
     }
+    double acc = 0.0;
+    for (int r0 = threadIdx.x; r0 < n; r0 += 8 * 256) {
+        double t[8];
 #pragma unroll
-    for (int p = 0; p < VILMA_MAX_P; ++p) {
-        if (p < P) {
-            const int lo = dot_start[p], hi = dot_start[p + 1];
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            int r = lo + threadIdx.x;
-            for (; r + 3 * 1024 < hi; r += 4 * 1024) {
-                a0 += dot_partials[r];
-                a1 += dot_partials[r + 1024];
-                a2 += dot_partials[r + 2 * 1024];
-                a3 += dot_partials[r + 3 * 1024];
-            }
-            for (; r < hi; r += 1024) a0 += dot_partials[r];
-            acc[2 * VILMA_MAX_P + 2 + p] = (a0 + a1) + (a2 + a3);
-        }
-    }
+        for (int u = 0; u < 8; ++u) t[u] = src[min(r0 + u * 256, n - 1)];
 #pragma unroll
-    for (int c = 0; c < FIN_MAXC; ++c) {
-        const double s = wave_sum(acc[c]);
-        if (lane == 0) sh[w][c] = s;
+        for (int u = 0; u < 8; ++u) t[u] = (r0 + u * 256 < n) ? t[u] : 0.0;
+        acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x < FIN_MAXC) {
-        const int c = threadIdx.x;
-        double s = sh[0][c];
-#pragma unroll
-        for (int ww = 1; ww < 16; ++ww) s += sh[ww][c];
-        if (c < NT) totals[c < 2 * P ? c : (3 * P + (c - 2 * P))] = s;
-        else if (c >= 2 * VILMA_MAX_P + 2 && c - (2 * VILMA_MAX_P + 2) < P)
-            totals[2 * P + (c - (2 * VILMA_MAX_P + 2))] = s;
-    }
+    if (threadIdx.x == 0) totals[out] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
                      const int32_t *dot_start, double *totals, hipStream_t s) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, s, snp_partials, snp_rows, P,
-                       dot_partials, dot_start, totals);
+    DotStart ds;
+    for (int p = 0; p <= VILMA_MAX_P; ++p) ds.v[p] = p <= P ? dot_start[p] : 0;
+    hipLaunchKernelGGL(finalize_kernel, dim3(3 * P + 2), dim3(256), 0, s, snp_partials, snp_rows, P,
+                       dot_partials, ds, totals);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -242,8 +242,10 @@ class HipEngine:
         self._check(self.lib.vilma_snapshot_mean(self.ctx, self._stream()))
 
     # ------------------------------------------------------------------ measurement
-    def prof_enable(self, on=True):
-        self._check(self.lib.vilma_prof_enable(self.ctx, 1 if on else 0))
+    def prof_enable(self, on=True, every=1):
+        """Bracket every `every`-th LD launch with HIP events (each pair costs a few microseconds
+        of stream time, which matters on small shards)."""
+        self._check(self.lib.vilma_prof_enable(self.ctx, max(1, int(every)) if on else 0))
 
     PROF_KINDS = ('ld_sym_kernel', 'ld_colsum_kernel', 'ld_sym_combine_kernel')
 

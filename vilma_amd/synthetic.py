@@ -12,6 +12,8 @@ host), on the host with numpy for the small parity cases.
 SNP layout: block after block, each block's LD SNPs followed by the LD-missing SNPs attached
 to it (`missing_frac` of all SNPs, multinomially spread), so `perm` is not the identity.
 """
+import sys
+
 import numpy as np
 
 WORKLOADS = {
@@ -22,6 +24,9 @@ WORKLOADS = {
     # C4: as C3 but eigen-truncated LD (what --ldthresh 0.8 leaves: kept rank ~0.28 n)
     'C4': dict(P=2, n_ld=1_000_000, B=1700, M=40, fixed=None, missing_frac=0.05,
                kind='lowrank', rank_frac=0.28),
+    # C5: 4 cohorts, 5M SNPs in 8500 LDetect-sized blocks, M=81: ~70 GB of
+    # LD panels + 2 x 13.6 GB of vi_mu resident on one GPU
+    'C5': dict(P=4, n_ld=5_000_000, B=8500, M=81, fixed=None, missing_frac=0.05),
     'tiny4': dict(P=2, n_ld=6_000, B=12, M=12, fixed=None, missing_frac=0.05,
                   kind='lowrank', rank_frac=0.28),
 }
@@ -96,6 +101,13 @@ class BlockData:
                                                            size=int(causal.sum())).T
         self.eps = rng.normal(size=(P, self.n))            # sampling noise of beta-hat
         self.init_noise = rng.normal(size=(P, self.n))     # the 1e-3*se jitter of _initialize
+
+
+def _progress(what, i, total, every=1000):
+    """A line on stderr every `every` blocks: setup of the big workloads takes minutes and a silent
+    job looks hung to a batch runner."""
+    if i and i % every == 0:
+        print('[synthetic] %s: block %d of %d' % (what, i, total), file=sys.stderr, flush=True)
 
 
 def ar1_numpy(n, rho):
@@ -194,6 +206,7 @@ class SyntheticShard:
         self.chi_local = np.zeros(P)
         self._z = np.zeros((P, N))
         for i, blk in enumerate(self.blocks):
+            _progress('sumstats', i, len(self.blocks))
             lo = self.snp_start[i]
             sl = slice(lo, lo + blk.n)
             self.se[:, sl] = blk.se
@@ -286,6 +299,7 @@ class SyntheticShard:
         if self.kind == 'lowrank':
             return self._finish_lowrank(prior)
         for i, blk in enumerate(self.blocks):
+            _progress('ridge start', i, len(self.blocks))
             lo = self.snp_start[i]
             sl = slice(lo, lo + blk.n)
             for p in range(P):
