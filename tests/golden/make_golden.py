@@ -17,6 +17,7 @@ Outputs (committed, data only):
                                            MultiPopVI._optimize_step (variational_inference.py:396)
     tests/golden/mixgrid_kat.npz           vi_options._make_simple outputs (RNG order pin)
     tests/golden/loader_kat.npz            load.py outputs on the reference's own fixtures
+    tests/golden/sim_kat.npz               sim.py draws for pinned seeds (RNG order pin of `vilma sim`)
 """
 import io
 import logging
@@ -32,6 +33,7 @@ from vilma import matrix_structures as rms            # noqa: E402
 from vilma import variational_inference as rvi        # noqa: E402
 from vilma import vi_options as rvo                   # noqa: E402
 from vilma import load as rload                       # noqa: E402
+from vilma import sim as rsim                         # noqa: E402
 
 
 # --------------------------------------------------------------------------------------
@@ -394,6 +396,71 @@ def loader_kat():
     np.savez_compressed(os.path.join(HERE, 'loader_kat.npz'), **out)
 
 
+def sim_kat():
+    """`vilma sim` building blocks with the legacy generator seeded: pins the order in which
+    the random stream is consumed (component per SNP, then effects, then sampling noise)."""
+    out = {}
+    rng = np.random.default_rng(11)
+    N, A, M, P = 300, 3, 5, 2
+    ann = np.zeros((N, A))
+    ann[np.arange(N), rng.integers(0, A, size=N)] = 1
+    w = rng.dirichlet(np.ones(M), size=A)
+    base = rng.normal(size=(M, P, P))
+    covs = np.einsum('kij,klj->kil', base, base) + 0.1 * np.eye(P)
+    out['annotations'], out['weights'], out['covs'] = ann, w, covs
+    np.random.seed(7)
+    out['components'] = rsim.sim_components(ann, w)
+    out['after_components_uniform'] = np.random.uniform()
+    np.random.seed(8)
+    out['true_effects'] = rsim.sim_true_effects(ann, w, covs)
+    out['after_effects_normal'] = np.random.normal()
+    # sim_gwas on a small block-diagonal operator with missing SNPs and a shuffled perm
+    sizes = [7, 5, 9]
+    blocks = [rms.LowRankMatrix(ar1(n, 0.6 + 0.1 * b), 0.999999) for b, n in enumerate(sizes)]
+    n_ld = sum(sizes)
+    total = n_ld + 3
+    perm = rng.permutation(total)
+    bd = rms.BlockDiagonalMatrix(blocks, perm=perm, missing=perm[n_ld:])
+    beta = rng.normal(size=total) * 1e-2
+    se = rng.uniform(0.01, 0.05, size=total)
+    np.random.seed(9)
+    out['gwas_blocks'] = np.array(sizes)
+    out['gwas_rho'] = np.array([0.6 + 0.1 * b for b in range(len(sizes))])
+    out['gwas_perm'], out['gwas_beta'], out['gwas_se'] = perm, beta, se
+    out['gwas_betahat'] = rsim.sim_gwas(beta, se, bd)
+    # the whole command on the reference's own fixtures (its test_cli_sim, tests/test.py:
+    # 2200-2245).  The .tsv shipped with the reference as the expected output of that test is
+    # NOT reproduced by the reference's own code under the numpy/pandas of this container, so
+    # the expected output is regenerated here; --mmap is forced off (h5py is not installed).
+    import argparse
+    import tempfile
+    import warnings
+    import pandas as pd
+    warnings.simplefilter('ignore')
+    ref = os.path.join(HERE, 'refdata')
+    load_ld = rload.load_ld_from_schema
+    rload.load_ld_from_schema = lambda *a, **k: load_ld(*a, **dict(k, mmap=False))
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            for tag in ('npy', 'npz'):
+                prefix = os.path.join(tmp, 'run_' + tag)
+                rsim.main(argparse.Namespace(
+                    ld_schema=os.path.join(ref, 'ld_manifest.tsv'),
+                    sumstats=os.path.join(ref, 'good_sumstats_beta.tsv'),
+                    annotations=os.path.join(ref, 'good_annotations.tsv'),
+                    covariance=os.path.join(ref, 'copy_vilma_run.covariance.pkl'),
+                    weights=os.path.join(ref, 'sim_weights.' + tag), output=prefix,
+                    names='simpop1', seed=143, gwas_n_scaling='1.'))
+                table = pd.read_csv(prefix + '.simpop1.simgwas.tsv', sep='\t')
+                out['cli_%s_columns' % tag] = np.array(list(table.columns))
+                out['cli_%s_ID' % tag] = np.array(table.ID, dtype=str)
+                for col in ('SE', 'BETA', 'true_beta'):
+                    out['cli_%s_%s' % (tag, col)] = np.array(table[col], dtype=float)
+    finally:
+        rload.load_ld_from_schema = load_ld
+    np.savez_compressed(os.path.join(HERE, 'sim_kat.npz'), **out)
+
+
 def main():
     which = set(sys.argv[1:])
 
@@ -402,6 +469,8 @@ def main():
 
     if want('kat'):
         numerics_kat(); ldop_kat(); mixgrid_kat(); loader_kat()
+    if want('kat') or want('sim'):
+        sim_kat()
     if want('p1_dense'):
         prob = make_problem(1, P=1, sizes=[90, 60, 120, 75, 100, 55], M=25, ldthresh=1.0,
                             kind='ar1', frac_missing=0.0, A=1, shuffle=False)

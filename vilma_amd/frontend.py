@@ -1,19 +1,23 @@
 """`vilma <command>` entry point (reference frontend.py:14-74) for the MI355X build.
 
-Only `fit` is implemented: it is the path this build accelerates.  The reference's offline
-tools (make_ld_schema, check_ld_schema, sim) are out of scope; their
-output formats are what `fit` consumes, so schemas built with the reference work unchanged.
+`fit` is the path this build accelerates; `sim` is the adjacent caller of the same LD operator
+(SURVEY.md 8f, N4).  The reference's schema tools (make_ld_schema, check_ld_schema) are out of
+scope; their output formats are what `fit` consumes, so schemas built with
+the reference work unchanged.
 """
 import logging
 import sys
 from argparse import ArgumentParser
 
 from . import VERSION
+from .sim import main as sim
+from .sim import args as sim_args
 from .vi_options import main as fit
 from .vi_options import args as fit_args
 
-COMMANDS = {'fit': {'cmd': fit, 'parser': fit_args}}
-_NOT_PORTED = ('make_ld_schema', 'check_ld_schema', 'sim')
+COMMANDS = {'fit': {'cmd': fit, 'parser': fit_args},
+            'sim': {'cmd': sim, 'parser': sim_args}}
+_NOT_PORTED = ('make_ld_schema', 'check_ld_schema')
 
 
 def build_parser():
