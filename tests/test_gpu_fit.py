@@ -199,6 +199,28 @@ def test_cli_under_torchrun_two_ranks(tmp_path):
     assert ta[0] == tb[0] and len(ta) == len(tb)
 
 
+def test_side_stream_does_not_change_a_bit(tmp_path):
+    """The side stream only changes WHEN the responsibility sums and convergence statistics run,
+    not what they compute: the fit with VILMA_OVERLAP=0 is bit-identical."""
+    import subprocess
+    ex = os.path.join(GOLDEN, 'example')
+    common = ['fit', '--sumstats', os.path.join(ex, 'example_data', 'example_gwas_sumstats.txt'),
+              '--ld-schema', os.path.join(ex, 'ld_mat', 'example_schema.schema'),
+              '--seed', '42', '-K', '81', '--init-hg', '0.2', '--samplesizes', '300e3',
+              '--names', 'ukbb', '--learn-scaling', '--num-its', '25',
+              '--extract', os.path.join(ex, 'keep_variants.txt')]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for flag in ('1', '0'):
+        outs[flag] = str(tmp_path / ('overlap' + flag))
+        subprocess.check_call([sys.executable, '-m', 'vilma_amd'] + common + ['--output', outs[flag]],
+                              env=dict(os.environ, PYTHONPATH=root, VILMA_OVERLAP=flag), cwd=root)
+    a, b = np.load(outs['1'] + '.npz'), np.load(outs['0'] + '.npz')
+    for key in a.files:
+        assert np.array_equal(a[key], b[key]), key
+    assert open(outs['1'] + '.estimates.tsv').read() == open(outs['0'] + '.estimates.tsv').read()
+
+
 def test_rccl_stream_ordering_with_one_rank_group():
     """A one-rank nccl (= RCCL) process group with forced collectives: every decision of the fit
     goes kernels -> RCCL all-reduce on a slice of the result vector -> pinned fetch, exactly the

@@ -3,6 +3,7 @@ golden problems (same seeded inputs).  Tolerances: 1e-9 relative on sums (the no
 1e-5 on ELBO/posterior means; fp64 kernels with a different summation order land ~1e-13)."""
 import numpy as np
 import pytest
+import torch
 
 from helpers import (golden, oracle_from_traj, engine_from_oracle, oracle_totals, TRAJ_NAMES)
 
@@ -108,7 +109,7 @@ def test_mean_diff():
     eng.snapshot_mean()
     eng.trial(0.7); eng.accept(True)
     new = eng.get_moments()[0] * vi.scalings
-    d = eng.mean_diff().cpu().numpy()
+    d = torch.cat(eng.mean_diff()).cpu().numpy()
     diff = np.abs(new - old)
     assert d[0] == np.sum(diff > 1e-6 + 1e-6 * np.abs(old))
     _close(d[1], diff.sum(), rtol=1e-10)
@@ -116,7 +117,7 @@ def test_mean_diff():
     _close(d[3], np.abs(new).max(), rtol=1e-12)
     _close(d[4], diff.max(), rtol=1e-12)
     _close(d[5], np.abs((new - old) / (old + 1e-100)).max(), rtol=1e-9)
-    d2 = eng.mean_diff().cpu().numpy()        # snapshot was replaced: no change now
+    d2 = torch.cat(eng.mean_diff()).cpu().numpy()        # snapshot was replaced: no change now
     assert d2[0] == 0 and d2[4] == 0
     eng.close()
 
@@ -135,7 +136,7 @@ def test_errors_are_loud():
 
 
 @pytest.mark.parametrize('sizes', [[1, 2, 3], [127, 128, 129], [255, 256, 257], [300, 64, 700],
-                                   [1000, 17]])
+                                   [1000, 17], [511, 513, 512], [2431]])
 def test_ld_matvec_block_sizes(sizes):
     """The symmetric (lower-triangle) dense kernel and the eigen-form kernel across slab
     boundaries: block sizes around multiples of 128, odd sizes, ragged mixes, perm + missing."""

@@ -66,8 +66,15 @@ class HipEngine:
         self._sums = self.results[L.sums]
         self._dmax = self.results[L.dmax]
         self._hyper = self.results[L.hyper]
+        # device addresses of the fixed result slices, resolved once (a data_ptr() lookup per
+        # launch costs about a microsecond of host time on the decision path)
+        self._p = {name: C.c_void_p(t.data_ptr()) for name, t in (
+            ('results', self.results), ('dsum', self._dsum), ('totals', self._totals),
+            ('ttotals', self._ttotals), ('sums', self._sums), ('dmax', self._dmax),
+            ('hyper', self._hyper))}
         self.n_totals = nt
         self._host = np.zeros(L.size)
+        self._host_ptr = _ptr(self._host)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -120,9 +127,8 @@ class HipEngine:
 
     def mstep(self, sums=None):
         """Device M-step from (all-reduced) delta sums; returns the device view of hyper_delta."""
-        sums = self._sums if sums is None else sums
-        self._check(self.lib.vilma_mstep(self.ctx, self._stream(), C.c_void_p(sums.data_ptr()),
-                                         C.c_void_p(self._hyper.data_ptr())))
+        src = self._p['sums'] if sums is None else C.c_void_p(sums.data_ptr())
+        self._check(self.lib.vilma_mstep(self.ctx, self._stream_handle, src, self._p['hyper']))
         return self._hyper
 
     def set_hyper(self, hyper):
@@ -208,13 +214,12 @@ class HipEngine:
 
     # ------------------------------------------------------------------ evaluations
     def eval(self):
-        self._check(self.lib.vilma_eval(self.ctx, self._stream(),
-                                        C.c_void_p(self._totals.data_ptr())))
+        self._check(self.lib.vilma_eval(self.ctx, self._stream_handle, self._p['totals']))
         return self._totals
 
     def trial(self, step):
-        self._check(self.lib.vilma_trial_beta(self.ctx, self._stream(), float(step),
-                                              C.c_void_p(self._ttotals.data_ptr())))
+        self._check(self.lib.vilma_trial_beta(self.ctx, self._stream_handle, float(step),
+                                              self._p['ttotals']))
         return self._ttotals
 
     def accept(self, take_mu):
@@ -222,21 +227,19 @@ class HipEngine:
 
     def fetch(self):
         """The whole result vector on the host (one pinned D2H copy behind the current stream)."""
-        self._check(self.lib.vilma_fetch(self.ctx, self._stream(),
-                                         C.c_void_p(self.results.data_ptr()), _ptr(self._host),
-                                         self.layout.size))
+        self._check(self.lib.vilma_fetch(self.ctx, self._stream_handle, self._p['results'],
+                                         self._host_ptr, self.layout.size))
         return self._host.copy()
 
     def delta_sums(self, which=_lib.STATE_CURRENT):
-        self._check(self.lib.vilma_delta_sums(self.ctx, self._stream(),
-                                              C.c_void_p(self._sums.data_ptr()), which))
+        self._check(self.lib.vilma_delta_sums(self.ctx, self._stream_handle, self._p['sums'],
+                                              which))
         return self._sums
 
     def mean_diff(self):
-        self._check(self.lib.vilma_mean_diff(self.ctx, self._stream(),
-                                             C.c_void_p(self._dsum.data_ptr()),
-                                             C.c_void_p(self._dmax.data_ptr())))
-        return self.torch.cat([self._dsum, self._dmax])
+        self._check(self.lib.vilma_mean_diff(self.ctx, self._stream_handle, self._p['dsum'],
+                                             self._p['dmax']))
+        return self._dsum, self._dmax       # slices of `results` (fetched with everything else)
 
     def snapshot_mean(self):
         self._check(self.lib.vilma_snapshot_mean(self.ctx, self._stream()))

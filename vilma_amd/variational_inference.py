@@ -171,6 +171,8 @@ class SweepDriver:
         self._pending = None        # a beta trial queued ahead of time: {'step', 'host'}
         self._speculate = False     # optimize()/sweep() loops: queue the next sweep's first trial
         self._verbose = False
+        self._log_info = False
+        self._views = {}            # slices of the engine's result vector handed to all-reduces
         self._version = 0           # bumped whenever the device state moves
         self._hyper = None
         self._totals = None         # all-reduced sums of the current (accepted) state
@@ -208,7 +210,10 @@ class SweepDriver:
         device->host copy.  Returns the host copy; slices are in engine.layout."""
         eng = self.engine
         if self.comm.active:
-            self.comm.allreduce_inplace(eng.results[lo:hi])
+            view = self._views.get((lo, hi))
+            if view is None:                    # tensor slicing costs microseconds per call
+                view = self._views[(lo, hi)] = eng.results[lo:hi]
+            self.comm.allreduce_inplace(view)
             if with_max and self._verbose:
                 self.comm.allreduce_inplace(eng.results[eng.layout.dmax], op='max')
         return eng.fetch()
@@ -261,10 +266,16 @@ class SweepDriver:
     def _install_hyper(self, hyper):
         """Host-side bookkeeping of a hyper_delta that is already installed on the device."""
         self._hyper = np.array(hyper)
-        log_h = np.log(self._hyper) - 0.5 * self.log_det[None, :]
-        # fast_vi_delta_grad (numerics.py:149-164) as an [A, M-1] table; the per-SNP array the
-        # reference stores is this table indexed by annotation
-        self._nat_table = log_h[:, :-1] - log_h[:, -1:]
+        self._nat_table = None          # derived on demand (nat_grad_vi_delta)
+
+    def _nat_table_of_hyper(self):
+        """fast_vi_delta_grad (numerics.py:149-164) as an [A, M-1] table; the per-SNP array the
+        reference stores is this table indexed by annotation.  Off the sweep's critical path: the
+        device keeps its own copy (vilma_set_hyper / vilma_mstep)."""
+        if self._nat_table is None and self._hyper is not None:
+            log_h = np.log(self._hyper) - 0.5 * self.log_det[None, :]
+            self._nat_table = log_h[:, :-1] - log_h[:, -1:]
+        return self._nat_table
 
     def _set_hyper(self, hyper):
         self.engine.set_hyper(np.asarray(hyper, dtype=np.float64))
@@ -300,7 +311,8 @@ class SweepDriver:
                                '_update_beta')
         while True:
             new_obj, totals = self._trial(1. / L[idx])
-            logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
+            if self._log_info:
+                logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
             # scalar arithmetic on Python floats: np.isclose & co cost ~20 us per call, which is
             # visible next to a 150 us evaluation on an 8-GPU shard
             if new_obj >= orig_obj - REL_TOL * abs(orig_obj) - ABS_TOL:
@@ -350,7 +362,8 @@ class SweepDriver:
         self._objective, self._totals = new_obj, totals
         self._cur_sums = self._trial_sums = None
         self._version += 1
-        logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
+        if self._log_info:
+            logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
         return orig_obj, new_obj
 
     def _update_error_scaling(self):
@@ -372,7 +385,8 @@ class SweepDriver:
         orig_obj = self._objective
         for _ in range(MAX_NUM_ITERS):
             L[0] = max([1., L[0] / 1.25])
-            logging.info('...Updating paramset %d, L=%f', 0, L[0])
+            if self._log_info:
+                logging.info('...Updating paramset %d, L=%f', 0, L[0])
             orig_obj, new_obj = self._update_beta(L, 0, line_search_rate, orig_obj)
             delta_sum += new_obj - orig_obj
             # == np.isclose(new_obj - orig_obj, 0, atol=conv_tol, rtol=0) for finite objectives
@@ -381,7 +395,8 @@ class SweepDriver:
             orig_obj = new_obj
         # ---- paramset 1: mixture weights (L[1] stays 1, so exactly one pass)
         L[1] = max([1., L[1] / 1.25])
-        logging.info('...Updating paramset %d, L=%f', 1, L[1])
+        if self._log_info:
+            logging.info('...Updating paramset %d, L=%f', 1, L[1])
         # without --learn-scaling this is the last evaluation of the sweep: piggy-back the
         # convergence statistics on its download
         last = not self.scale_se
@@ -392,7 +407,8 @@ class SweepDriver:
         delta_sum += new_obj - orig_obj
         # ---- paramset 2: annotations -- nothing to do in this scheme (:862-866)
         L[2] = max([1., L[2] / 1.25])
-        logging.info('...Updating paramset %d, L=%f', 2, L[2])
+        if self._log_info:
+            logging.info('...Updating paramset %d, L=%f', 2, L[2])
         if self.scale_se and delta_sum < EM_TOL:
             orig_obj = self._objective
             self._update_error_scaling()
@@ -408,7 +424,11 @@ class SweepDriver:
         if hasattr(self.engine, 'refresh_stream'):
             self.engine.refresh_stream()
         self._upload(params)
-        logging.info('Current ELBO = %f and L = %f,%f,%f,%f,%f', curr_elbo, *L[:5])
+        # one check per sweep instead of one per message (each costs ~1.3 us even when disabled,
+        # on the path between a decision and the next launch)
+        self._log_info = logging.getLogger().isEnabledFor(logging.INFO)
+        if self._log_info:
+            logging.info('Current ELBO = %f and L = %f,%f,%f,%f,%f', curr_elbo, *L[:5])
         L_new, elbo_change = self._nat_grad_step(L, line_search_rate, running_elbo_delta)
         elbo = curr_elbo + elbo_change
         if running_elbo_delta is None:
@@ -665,14 +685,14 @@ class MultiPopVI(SweepDriver):
     def nat_grad_vi_delta(self):
         """[N, M-1] natural parameter of the mixture weights (numerics.py:149-164), expanded
         from the [A, M-1] table the device uses; None until hyper_delta has been set."""
-        if getattr(self, '_nat_table', None) is None:
+        if getattr(self, '_hyper', None) is None:
             return None
-        return self._nat_table[self.annotations]
+        return self._nat_table_of_hyper()[self.annotations]
 
     @nat_grad_vi_delta.setter
     def nat_grad_vi_delta(self, value):
         if value is None:
-            self._nat_table = None
+            self._nat_table = self._hyper = None
 
     def _local_part(self, vi_mu_global):
         return vi_mu_global[:, :, self._snps]
