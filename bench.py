@@ -281,6 +281,12 @@ def main():
             'stored_bytes_per_launch': float(engine.ld_bytes()[1]),
             'other_ld_kernels_ms': {k: v[0] / max(v[1], 1) for k, v in prof.items() if k != dom and v[1]},
             'sweep_algorithmic_GBps': (n_eval * (alg_launch + state_bytes)) / elapsed / 1e9,
+            # `achieved` is priced on the ALGORITHMIC bytes (8 n^2 per dense block); the
+            # kernel reads each symmetric block's lower triangle once, so the rate on the bytes it
+            # actually moves (PMC traffic) is the utilisation of the HBM pipe
+            'moved_GBps': (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and launches) else None,
+            'moved_frac_of_peak': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                  if (traffic and launches) else None,
         },
     }
     if world == 1 and not args.no_cpu_baseline:
