@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--out', default='/tmp/vilma_cli_check')
     ap.add_argument('--num-its', type=int, default=30)
     ap.add_argument('-K', type=int, default=3)
+    ap.add_argument('--only-write', action='store_true',
+                    help='generate the on-disk schema and stop (no GPU needed)')
     args = ap.parse_args()
     from vilma_amd.synthetic import block_sizes, ar1_numpy
     rng = np.random.default_rng(0)
@@ -63,6 +65,8 @@ def main():
                                               sep='\t', index=False)
     print('wrote schema: N=%d SNPs, %d + %d blocks, %.1f s' % (N, len(sizes), len(psizes),
                                                                time.perf_counter() - t0))
+    if args.only_write:
+        return
     from vilma_amd import frontend
     import logging
     argv = ['fit', '--ld-schema', '%s/c0.schema,%s/c1.schema' % (args.out, args.out),

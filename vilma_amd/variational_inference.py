@@ -707,16 +707,31 @@ class MultiPopVI(SweepDriver):
 
     # ------------------------------------------------------------------ host-side views
     def _lam(self):
-        lam = np.zeros((self.num_mix, self.num_pops, self.num_pops, self.num_loci))
-        idx = np.arange(self.num_pops)
-        lam[:, idx, idx, :] = self.scaled_ld_diags / self.error_scaling.reshape((-1, 1))
-        return lam + self.mixture_prec
+        lam = np.empty((self.num_mix, self.num_pops, self.num_pops, self.num_loci))
+        lam[:] = self.mixture_prec                      # [M,P,P,1] broadcast over SNPs
+        diag = self.scaled_ld_diags / self.error_scaling.reshape((-1, 1))
+        for p in range(self.num_pops):
+            lam[:, p, p, :] = diag[p] + self.mixture_prec[:, p, p, :]
+        return lam
 
     @property
     def vi_sigma(self):
         """[M,P,P,N], computed on demand for outputs (variational_inference.py:712-724)."""
-        lam = np.transpose(self._lam(), (3, 0, 1, 2))
-        return np.transpose(_inv_small(lam), (1, 2, 3, 0))
+        lam = self._lam()
+        if self.num_pops == 1:
+            return 1.0 / lam
+        if self.num_pops == 2:
+            # the closed form of _inv_small written on the [M,P,P,N] layout itself (same
+            # arithmetic; the transposed views cost seconds at 1 M SNPs)
+            a, b, c, d = lam[:, 0, 0], lam[:, 0, 1], lam[:, 1, 0], lam[:, 1, 1]
+            r = 1.0 / (a * d - b * c)
+            out = np.empty_like(lam)
+            out[:, 0, 0] = d * r
+            out[:, 1, 1] = a * r
+            out[:, 1, 0] = -c * r
+            out[:, 0, 1] = out[:, 1, 0]
+            return out
+        return np.transpose(_inv_small(np.transpose(lam, (3, 0, 1, 2))), (1, 2, 3, 0))
 
     @property
     def nat_sigma(self):
