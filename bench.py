@@ -42,8 +42,10 @@ def parse():
     ap.add_argument('--cpu-blocks', type=int, default=96,
                     help='blocks of the workload in the CPU-baseline sample')
     ap.add_argument('--cpu-sweeps', type=int, default=5)
-    ap.add_argument('--prof-every', type=int, default=4,
-                    help='bracket every k-th LD product with HIP events (roofline.avg_launch_ms)')
+    ap.add_argument('--prof-every', type=int, default=0,
+                    help='bracket every k-th LD product with HIP events (roofline.avg_launch_ms); '
+                         'default: every product on 1 GPU, every 8th on a sharded run, where the '
+                         '~10 us of stream time an event pair costs is percents of a sweep')
     ap.add_argument('--emulate-shard', type=int, default=0,
                     help='diagnostic: time rank 0 of a K-way sharding alone on one GPU '
                          '(no collectives; NOT a valid bench line)')
@@ -208,7 +210,8 @@ def main():
         engine.snapshot_mean()
         state = {'L': np.ones(5), 'elbo': driver._objective, 'running': None}
 
-    engine.prof_enable(True, every=args.prof_every)
+    prof_every = args.prof_every or (1 if (world == 1 and args.emulate_shard <= 1) else 8)
+    engine.prof_enable(True, every=prof_every)
     engine.prof_read(reset=True)
     ev0, tr0 = driver.n_evaluations, driver.n_trials
     if world > 1:
@@ -277,7 +280,7 @@ def main():
             'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'algorithmic_bytes_per_launch': alg_launch,
-            'avg_launch_ms': avg_ms, 'launches': int(launches),
+            'avg_launch_ms': avg_ms, 'launches': int(launches), 'bracketed_every': prof_every,
             'stored_bytes_per_launch': float(engine.ld_bytes()[1]),
             'other_ld_kernels_ms': {k: v[0] / max(v[1], 1) for k, v in prof.items() if k != dom and v[1]},
             'sweep_algorithmic_GBps': (n_eval * (alg_launch + state_bytes)) / elapsed / 1e9,
