@@ -36,3 +36,18 @@ def test_no_cpu_fallback_in_product():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+
+
+def test_library_binds_to_the_hip_runtime_torch_ships():
+    """Two HIP runtimes in one process cannot both own the GPU: whatever the import order, the
+    library and torch must end up on ONE libamdhip64 (a process that loaded the library before
+    torch used to see 'no HIP device available' on the GPU box)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from vilma_amd import _lib; _lib.load(); "
+            "import torch; "
+            "print(len(set(l.split()[-1] for l in open('/proc/self/maps') if 'amdhip64' in l)))"
+            % root)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, check=True)
+    assert out.stdout.strip().splitlines()[-1] == '1', out.stdout + out.stderr

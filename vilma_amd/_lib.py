@@ -38,6 +38,14 @@ def load():
             'libvilma_hip.so is not built (%s). Run `python -m vilma_amd.build` or '
             '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback '
             'for the fit hot path.' % LIB_PATH)
+    # torch ships its own libamdhip64; whichever HIP runtime is loaded FIRST in a process is the
+    # one that can own the GPU (a second runtime initialised later sees no device).  The engine
+    # shares device memory and streams with torch, so both must bind to the same runtime: load
+    # torch's before dlopen resolves this library's libamdhip64 dependency by soname.
+    try:
+        import torch        # noqa: F401
+    except ImportError:     # stand-alone use of the C-ABI: the system runtime
+        pass
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     sigs = {
