@@ -1,0 +1,64 @@
+"""bench.py keeps its one-JSON-line contract (keys the driver and the judge read), on a small
+workload so it finishes in seconds; and the 2-rank launch line the driver uses works (rehearsed
+over gloo with both ranks on this GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOP = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+       'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline')
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, stdout          # exactly ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract_one_gpu():
+    out = subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '4',
+                          '--warmup', '1', '--cpu-blocks', '6', '--cpu-sweeps', '2'],
+                         cwd=ROOT, capture_output=True, text=True, check=True)
+    d = _last_json(out.stdout)
+    for key in TOP + ('cpu_baseline',):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 1
+    assert d['higher_is_better'] is True and d['vs_baseline'] is None and d['dtype'] == 'f64'
+    assert d['unit'] == 'sweeps/s' and d['value'] > 0
+    assert abs(d['value'] * d['ms_per_step'] - 1e3) < 1e-6 * 1e3
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in r, key
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert r['launches'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    c = d['cpu_baseline']
+    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert key in c, key
+    assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1
+    p = c['parity_vs_cpu']
+    assert p['L_trajectory_equal'] and p['elbo_max_rel_dev'] < 1e-9
+
+
+def test_bench_two_ranks_launch_line():
+    env = dict(os.environ, VILMA_BENCH_BACKEND='gloo', VILMA_BENCH_SAME_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(29900 + os.getpid() % 90),
+           'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--workload', 'tiny']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, check=True)
+    d = _last_json(out.stdout)
+    for key in TOP:
+        assert key in d, key
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and 'cpu_baseline' not in d
+    # same global problem as the 1-GPU run: the fit reaches the same ELBO
+    one = subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '3',
+                          '--warmup', '1', '--no-cpu-baseline'], cwd=ROOT, capture_output=True,
+                         text=True, check=True)
+    e1, e2 = _last_json(one.stdout)['config']['elbo_end'], d['config']['elbo_end']
+    assert abs(e1 - e2) < 1e-9 * abs(e1)
