@@ -78,6 +78,18 @@ def cpu_baseline(workload, seed, n_blocks, n_sweeps):
     threads = max(1, min(16, avail))
     from threadpoolctl import threadpool_limits
     cpu_elbos = []
+    # split the timed region into LD products and per-SNP passes: the reference threads its
+    # per-SNP loops (numba prange) while this port's numpy passes run on one core, so the
+    # baseline is also quoted with the per-SNP part divided by the core count (an upper bound
+    # on what a prange-threaded CPU path can reach on this host)
+    ld_seconds = [0.0]
+    for op in ld:
+        def timed_dot(x, _dot=op.dot):
+            t = time.perf_counter()
+            y = _dot(x)
+            ld_seconds[0] += time.perf_counter() - t
+            return y
+        op.dot = timed_dot
     with threadpool_limits(limits=threads):
         np.random.seed(42)
         params = vi._initialize()
@@ -86,11 +98,14 @@ def cpu_baseline(workload, seed, n_blocks, n_sweeps):
         L, red = np.ones(5), None
         params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)       # warm-up sweep
         cpu_elbos.append(elbo)
+        ld_seconds[0] = 0.0
         t0 = time.perf_counter()
         for _ in range(n_sweeps):
             params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
             cpu_elbos.append(elbo)
         dt = time.perf_counter() - t0
+    t_ld = min(ld_seconds[0], dt)
+    dt_threaded = t_ld + (dt - t_ld) / threads
     frac = sh.N / full.N_global
     parity = None
     try:
@@ -126,6 +141,8 @@ def cpu_baseline(workload, seed, n_blocks, n_sweeps):
     return {
         'value': (n_sweeps / dt) * frac, 'unit': 'sweeps/s', 'cores': int(threads),
         'kind': 'port', 'parity_vs_cpu': parity,
+        'ld_product_share_of_cpu_time': t_ld / dt,
+        'value_if_per_snp_passes_scaled_over_cores': (n_sweeps / dt_threaded) * frac,
         'sample': ('oracle (numpy restatement of the reference schedule; BLAS gemv threaded on '
                    '%d threads, per-SNP passes single-threaded) on the first %d of %d blocks '
                    '(%d of %d SNPs, all %d cohorts, M=%d): %d sweeps in %.2f s after 1 warm-up; '
