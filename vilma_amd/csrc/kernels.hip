@@ -56,6 +56,14 @@ static __device__ __forceinline__ double wave_max(double v) {
 // pointer; pin it to the global address space to get global_load_dwordx4
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef const v2d __attribute__((address_space(1))) *gd2_ptr;
+// Wave-uniform reads of the small per-component tables (mixture precisions, log-weights): through
+// the constant address space the compiler may use scalar loads (SGPR results, scalar cache) even
+// in kernels that also store to global memory -- from a generic pointer it must assume the
+// stores alias the table, falls back to vector loads and then waits on vmcnt(0), i.e. on every
+// outstanding vi_mu load AND store, once per component.  The tables are written only by other
+// kernels (mstep, uploads), never by the kernel reading them.
+typedef const double __attribute__((address_space(4))) *const_tab;
+static __device__ __forceinline__ const_tab as_table(const double *p) { return (const_tab)p; }
 
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
     const LdItem *__restrict__ items, const double *__restrict__ xpool, double *__restrict__ ypool,
@@ -479,28 +487,52 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
 #pragma unroll
     for (int p = 0; p < P; ++p) { Sm[p] = 0.0; S2[p] = 0.0; }
 
-    // vi_mu of KU components is loaded up front (KU*P independent 512-B wave loads in flight),
-    // then the components are folded in one at a time
-    for (int k0 = 0; k0 < M; k0 += KU) {
-        double mul[KU][P];
+    // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
+    // buffered: the loads of batch b+1 are issued BEFORE batch b is folded in and its new vi_mu
+    // stored.  On gfx9 loads and stores retire through one in-order counter (vmcnt), so a wave that
+    // stores and then loads waits for its own stores to reach HBM before it sees the loaded data;
+    // with the next loads ahead of the stores it only ever waits for loads.
+    constexpr int KB = P <= 2 ? KU : (KU > 2 ? 2 : KU);
+    const const_tab prec_tab = as_table(a.prec);
+    const const_tab lh_tab = as_table(a.lh);          // one annotation: the row is wave-uniform
+    // tables of a whole batch are fetched up front too (P <= 2: 5 doubles per component fit the
+    // scalar registers), so the batch computes without a scalar-load stall per component
+    constexpr bool TAB_AHEAD = P <= 2;
+
+    auto fetch = [&](double (&dst)[KB][P], int k0) {
 #pragma unroll
-        for (int kk = 0; kk < KU; ++kk) {
+        for (int kk = 0; kk < KB; ++kk) {
             const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
 #pragma unroll
-            for (int p = 0; p < P; ++p) mul[kk][p] = a.mu_in[((int64_t)kc * P + p) * N64 + ii];
+            for (int p = 0; p < P; ++p) dst[kk][p] = a.mu_in[((int64_t)kc * P + p) * N64 + ii];
+        }
+    };
+    auto fold = [&](const double (&mul)[KB][P], int k0) {
+        double prt[TAB_AHEAD ? KB : 1][P][P], lht[TAB_AHEAD ? KB : 1];
+        if (TAB_AHEAD) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int kc = min(k0 + kk, M - 1);
+#pragma unroll
+                for (int e = 0; e < P * P; ++e) prt[kk][e / P][e % P] = prec_tab[(int64_t)kc * P * P + e];
+                lht[kk] = ONE_ANNOT ? lh_tab[kc] : lh[kc];
+            }
         }
 #pragma unroll
-        for (int kk = 0; kk < KU; ++kk) {
+        for (int kk = 0; kk < KB; ++kk) {
             const int k = k0 + kk;
             if (k >= M) break;
             double pr[P][P], lam[P][P], sig[P][P], nat[P], mun[P];
-            const double *pk = a.prec + (int64_t)k * P * P;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
 #pragma unroll
-                for (int q = 0; q < P; ++q) { pr[p][q] = pk[p * P + q]; lam[p][q] = pr[p][q]; }
+                for (int q = 0; q < P; ++q) {
+                    pr[p][q] = TAB_AHEAD ? prt[kk][p][q] : prec_tab[(int64_t)k * P * P + p * P + q];
+                    lam[p][q] = pr[p][q];
+                }
                 lam[p][p] += d[p];
             }
+            const double lhk = TAB_AHEAD ? lht[kk] : (ONE_ANNOT ? lh_tab[k] : lh[k]);
             const double wk = spd_inverse<P>(lam, sig);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -530,7 +562,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                     ip += mun[p] * mun[q] * pr[q][p];
                     tr += pr[p][q] * sig[q][p];
                 }
-            const double ak = 0.5 * quad + lh[k];
+            const double ak = 0.5 * quad + lhk;
             const double dk = ak - mx;
             const double t = exp(-fabs(dk));
             const bool up = dk > 0.0;
@@ -546,6 +578,16 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                 S2[p] = fma(S2[p], sc, e * (sig[p][p] + mun[p] * mun[p]));
             }
         }
+    };
+
+    double bufA[KB][P], bufB[KB][P];
+    fetch(bufA, 0);
+    for (int k0 = 0; k0 < M; k0 += 2 * KB) {
+        fetch(bufB, k0 + KB);              // past the end the clamped loads re-read component M-1
+        fold(bufA, k0);
+        if (k0 + KB >= M) break;           // wave-uniform
+        fetch(bufA, k0 + 2 * KB);
+        fold(bufB, k0 + KB);
     }
     const bool owner = live;
     const double invZ = 1.0 / Z;
