@@ -554,14 +554,18 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                 mun[p] = t;
                 quad += t * nat[p];
             }
-            double ip = 0.0, tr = 0.0;
+            // mu^T Prec mu and tr(Prec Sig) through Lam = Prec + D (D diagonal), Sig = Lam^-1:
+            //   mu^T Prec mu = mu^T Lam mu - sum_p d_p mu_p^2 = quad - sum_p d_p mu_p^2
+            //   tr(Prec Sig) = tr(I) - tr(D Sig)              = P    - sum_p d_p Sig_pp
+            // 2P+1 operations instead of 3P^2 (the double sums were a fifth of the P = 4 pass);
+            // the cancellation costs at most ~P eps absolute per (component, SNP) in terms that
+            // enter the ELBO additively next to O(1) neighbours.
+            double ip = quad, tr = (double)P;
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    ip += mun[p] * mun[q] * pr[q][p];
-                    tr += pr[p][q] * sig[q][p];
-                }
+            for (int p = 0; p < P; ++p) {
+                ip = fma(-d[p] * mun[p], mun[p], ip);
+                tr = fma(-d[p], sig[p][p], tr);
+            }
             const double ak = 0.5 * quad + lhk;
             const double dk = ak - mx;
             const double t = exp(-fabs(dk));
