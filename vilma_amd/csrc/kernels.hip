@@ -679,35 +679,71 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     double *prow = WRITE ? nullptr : a.out + ((int64_t)blockIdx.x * (SNP_THREADS / 64) + w) * A * M;
     // with KS = 4 the quarter-waves take components k = ks, ks+4, ... of the same 16 SNPs; the
     // per-component sum over SNPs is then a 16-lane (segmented) shuffle reduction
-    for (int k = ks; k < M; k += KS) {
-        double lam[P][P], mu[P];
-        const double *pk = a.prec + (int64_t)k * P * P;
+    // KS == 1: k is wave-uniform, the tables go through the constant address space (scalar loads);
+    // KS == 4: the quarter-waves read different components, plain vector loads.
+    // Components go in batches of KD: all vi_mu loads of a batch first, then the arithmetic, then
+    // the (few) stores together, so a wave waits on its own stores once per batch, not per component.
+    constexpr int KD = 4;
+    const const_tab prec_tab = as_table(a.prec);
+    const const_tab lh_tab = as_table(a.lh);
+    for (int k0 = ks; k0 < M; k0 += KS * KD) {
+        double mu[KD][P], delta[KD];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
+        for (int u = 0; u < KD; ++u) {
+            const int kc = min(k0 + u * KS, M - 1);       // unconditional loads; extras ignored
 #pragma unroll
-            for (int q = 0; q < P; ++q) lam[p][q] = pk[p * P + q];
-            lam[p][p] += d[p];
-            mu[p] = a.mu[((int64_t)k * P + p) * N64 + ii];
+            for (int p = 0; p < P; ++p) mu[u][p] = a.mu[((int64_t)kc * P + p) * N64 + ii];
         }
-        const double wdet = spd_rsqrt_det<P>(lam);
-        double quad = 0.0;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            double t = 0.0;
+        for (int u = 0; u < KD; ++u) {
+            const int k = min(k0 + u * KS, M - 1);
+            double lam[P][P];
+            const double *pk = a.prec + (int64_t)k * P * P;
 #pragma unroll
-            for (int q = 0; q < P; ++q) t += lam[p][q] * mu[q];
-            quad += mu[p] * t;
+            for (int p = 0; p < P; ++p) {
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+                    lam[p][q] = KS == 1 ? prec_tab[(int64_t)k * P * P + p * P + q] : pk[p * P + q];
+                lam[p][p] += d[p];
+            }
+            const double lhk = (KS == 1 && ONE_ANNOT) ? lh_tab[k] : lh[k];
+            const double wdet = spd_rsqrt_det<P>(lam);
+            double quad = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < P; ++q) t += lam[p][q] * mu[u][q];
+                quad += mu[u][p] * t;
+            }
+            delta[u] = fmax(wdet * exp(0.5 * quad + lhk - lse), 1e-100);
         }
-        const double delta = fmax(wdet * exp(0.5 * quad + lh[k] - lse), 1e-100);
         if (WRITE) {
-            if (live) a.out[(int64_t)k * N64 + i] = delta;
+#pragma unroll
+            for (int u = 0; u < KD; ++u) {
+                const int k = k0 + u * KS;
+                if (live && k < M) a.out[(int64_t)k * N64 + i] = delta[u];
+            }
         } else if (ONE_ANNOT) {
-            const double s = seg_sum<SPW>(live ? delta : 0.0);
-            if ((lane % SPW) == 0) prow[k] = s;
+            double sums[KD];
+#pragma unroll
+            for (int u = 0; u < KD; ++u) sums[u] = seg_sum<SPW>(live ? delta[u] : 0.0);
+#pragma unroll
+            for (int u = 0; u < KD; ++u) {
+                const int k = k0 + u * KS;
+                if ((lane % SPW) == 0 && k < M) prow[k] = sums[u];
+            }
         } else {
             for (int aa = 0; aa < A; ++aa) {
-                const double s = seg_sum<SPW>((live && ann == aa) ? delta : 0.0);
-                if ((lane % SPW) == 0) prow[(int64_t)aa * M + k] = s;
+                double sums[KD];
+#pragma unroll
+                for (int u = 0; u < KD; ++u)
+                    sums[u] = seg_sum<SPW>((live && ann == aa) ? delta[u] : 0.0);
+#pragma unroll
+                for (int u = 0; u < KD; ++u) {
+                    const int k = k0 + u * KS;
+                    if ((lane % SPW) == 0 && k < M) prow[(int64_t)aa * M + k] = sums[u];
+                }
             }
         }
     }
