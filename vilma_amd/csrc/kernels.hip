@@ -499,15 +499,18 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     // scalar registers), so the batch computes without a scalar-load stall per component
     constexpr bool TAB_AHEAD = P <= 2;
 
-    auto fetch = [&](double (&dst)[KB][P], int k0) {
+    // with several annotations the log-weight row differs per lane: those (vector) loads travel
+    // with the vi_mu batch, ahead of the previous batch's stores
+    auto fetch = [&](double (&dst)[KB][P], double (&lhv)[KB], int k0) {
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
             const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
 #pragma unroll
             for (int p = 0; p < P; ++p) dst[kk][p] = a.mu_in[((int64_t)kc * P + p) * N64 + ii];
+            lhv[kk] = ONE_ANNOT ? 0.0 : lh[kc];
         }
     };
-    auto fold = [&](const double (&mul)[KB][P], int k0) {
+    auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0) {
         double prt[TAB_AHEAD ? KB : 1][P][P], lht[TAB_AHEAD ? KB : 1];
         if (TAB_AHEAD) {
 #pragma unroll
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                 const int kc = min(k0 + kk, M - 1);
 #pragma unroll
                 for (int e = 0; e < P * P; ++e) prt[kk][e / P][e % P] = prec_tab[(int64_t)kc * P * P + e];
-                lht[kk] = ONE_ANNOT ? lh_tab[kc] : lh[kc];
+                lht[kk] = ONE_ANNOT ? lh_tab[kc] : lhv[kk];
             }
         }
 #pragma unroll
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                 }
                 lam[p][p] += d[p];
             }
-            const double lhk = TAB_AHEAD ? lht[kk] : (ONE_ANNOT ? lh_tab[k] : lh[k]);
+            const double lhk = TAB_AHEAD ? lht[kk] : (ONE_ANNOT ? lh_tab[k] : lhv[kk]);
             const double wk = spd_inverse<P>(lam, sig);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -584,14 +587,14 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
         }
     };
 
-    double bufA[KB][P], bufB[KB][P];
-    fetch(bufA, 0);
+    double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
+    fetch(bufA, lhA, 0);
     for (int k0 = 0; k0 < M; k0 += 2 * KB) {
-        fetch(bufB, k0 + KB);              // past the end the clamped loads re-read component M-1
-        fold(bufA, k0);
+        fetch(bufB, lhB, k0 + KB);         // past the end the clamped loads re-read component M-1
+        fold(bufA, lhA, k0);
         if (k0 + KB >= M) break;           // wave-uniform
-        fetch(bufA, k0 + 2 * KB);
-        fold(bufB, k0 + KB);
+        fetch(bufA, lhA, k0 + 2 * KB);
+        fold(bufB, lhB, k0 + KB);
     }
     const bool owner = live;
     const double invZ = 1.0 / Z;
