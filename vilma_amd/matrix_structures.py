@@ -63,10 +63,16 @@ def dense_bytes_moved(n):
     return 0.5 * n * n + 32.0 * n
 
 
+# the two eigen-form passes (plus their extra launches, on the small blocks that would choose
+# them) run at about 3/4 of the dense kernel's rate per byte: workload C4 (kept rank 0.28 n) on
+# one box: all-dense 325 sweeps/s, by bytes alone 308, all-eigen 286 (another box)
+EIGEN_FORM_PENALTY = 1.3
+
+
 def dense_is_cheaper(n, r):
-    """Elements read per product: dense symmetric form vs eigen form (U and diag(s)U^T, 2 n r).
-    Measured at kept rank 0.28 n (workload C4): all-dense 297 sweeps/s, all-eigen 286."""
-    return dense_bytes_moved(n) <= 2.0 * n * r
+    """Dense symmetric form vs eigen form (U and diag(s)U^T, 2 n r elements per product), by
+    elements read weighted with the measured efficiency of the eigen-form passes."""
+    return dense_bytes_moved(n) <= EIGEN_FORM_PENALTY * 2.0 * n * r
 
 
 class LowRankMatrix:
@@ -225,7 +231,8 @@ class BlockDiagonalMatrix:
     def device_blocks(self, form='auto'):
         """Blocks in the form the HIP LD store takes, chosen by bytes streamed per product: the
         dense symmetric form reads the lower triangle once (~n^2/2 + 32 n elements), the eigen
-        form reads U and diag(s)U^T (2 n r) -- so eigen form only when r < n/4 + 16."""
+        form reads U and diag(s)U^T (2 n r) at ~3/4 of the rate -- so eigen form only when
+        r < (n/4 + 16) / 1.3."""
         def one(m):
             n, r = m.u.shape
             if not np.allclose(m.D, 0):
