@@ -56,12 +56,44 @@ static __device__ __forceinline__ double wave_max(double v) {
 // pointer; pin it to the global address space to get global_load_dwordx4
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef const v2d __attribute__((address_space(1))) *gd2_ptr;
+// The LD stream is read exactly once per product: its loads are non-temporal (`nt`), so 7 GB of
+// once-read lines do not churn through the 256 MB Infinity Cache.  Measured on ld_sym_kernel
+// alone at C3: 1.14-1.18 ms -> 1.01 ms (6.1 -> 6.9 TB/s on the stored bytes).
+#ifndef LD_NT
+#define LD_NT 1
+#endif
+#if LD_NT
+#define LD_STREAM_LOAD(p) __builtin_nontemporal_load((gd2_ptr)(p))
+#else
+#define LD_STREAM_LOAD(p) (*(gd2_ptr)(p))
+#endif
 // Wave-uniform reads of the small per-component tables (mixture precisions, log-weights): through
 // the constant address space the compiler may use scalar loads (SGPR results, scalar cache) even
 // in kernels that also store to global memory -- from a generic pointer it must assume the
 // stores alias the table, falls back to vector loads and then waits on vmcnt(0), i.e. on every
 // outstanding vi_mu load AND store, once per component.  The tables are written only by other
 // kernels (mstep, uploads), never by the kernel reading them.
+// vi_mu streams of the per-SNP kernels.  The new vi_mu of a trial (0.67 GB at C3) is stored
+// non-temporally: written back normally it is still draining from the caches while the LD
+// product that follows streams, and takes bandwidth from it (sweep -2.5 % at C3 on top of the
+// LD loads; the trial pass itself -7 % at M = 40).  Non-temporal vi_mu LOADS measured neutral.
+#ifndef MU_NT
+#define MU_NT 0
+#endif
+#ifndef MUOUT_NT
+#define MUOUT_NT 1
+#endif
+#if MU_NT
+#define MU_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define MU_LOAD(p) (*(p))
+#endif
+#if MUOUT_NT
+#define MU_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define MU_STORE(p, v) (*(p) = (v))
+#endif
+
 typedef const double __attribute__((address_space(4))) *const_tab;
 static __device__ __forceinline__ const_tab as_table(const double *p) { return (const_tab)p; }
 
@@ -85,7 +117,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
                 v2d v[CS_ROWS];
 #pragma unroll
                 for (int u = 0; u < CS_ROWS; ++u)
-                    v[u] = *(gd2_ptr)(ap + (int64_t)(j + u) * ld);
+                    v[u] = LD_STREAM_LOAD(ap + (int64_t)(j + u) * ld);
 #pragma unroll
                 for (int u = 0; u < CS_ROWS; ++u) {
                     const double xv = xp[j + u];
@@ -94,7 +126,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
                 }
             } else {
                 for (int jj = j; jj < rows; ++jj) {
-                    const v2d v = *(gd2_ptr)(ap + (int64_t)jj * ld);
+                    const v2d v = LD_STREAM_LOAD(ap + (int64_t)jj * ld);
                     const double xv = xp[jj];
                     acc0 = fma(v.x, xv, acc0);
                     acc1 = fma(v.y, xv, acc1);
@@ -213,7 +245,7 @@ static __device__ __forceinline__ void sym_group_diag(const double *__restrict__
     if (lane < lim) {
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u)
-            v[u] = *(gd2_ptr)(rp + (int64_t)min(u, rows - 1 - r0) * ld);
+            v[u] = LD_STREAM_LOAD(rp + (int64_t)min(u, rows - 1 - r0) * ld);
     } else {
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u) v[u] = v2d{0.0, 0.0};
@@ -272,14 +304,14 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     v2d v[CS_ROWS];
     for (; g < nfull; g += CS_WAVES, rp += gstride) {
 #pragma unroll
-        for (int u = 0; u < CS_ROWS; ++u) v[u] = *(gd2_ptr)(rp + (int64_t)u * ld);
+        for (int u = 0; u < CS_ROWS; ++u) v[u] = LD_STREAM_LOAD(rp + (int64_t)u * ld);
         sym_group<true>(v, xrow, g * CS_ROWS, rows, xs0, xs1, acc0, acc1, lane, srow);
     }
     if (g == nfull && g < ngroups) {                        // the one partial group, below the tile
         const int r0 = nfull * CS_ROWS;
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u)     // rows past the end re-read the last row
-            v[u] = *(gd2_ptr)(ap + (int64_t)min(r0 + u, rows - 1) * ld);
+            v[u] = LD_STREAM_LOAD(ap + (int64_t)min(r0 + u, rows - 1) * ld);
         sym_group<false>(v, xrow, r0, rows, xs0, xs1, acc0, acc1, lane, srow);
     }
     red[w][2 * lane] = acc0;
@@ -506,7 +538,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
         for (int kk = 0; kk < KB; ++kk) {
             const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
 #pragma unroll
-            for (int p = 0; p < P; ++p) dst[kk][p] = a.mu_in[((int64_t)kc * P + p) * N64 + ii];
+            for (int p = 0; p < P; ++p) dst[kk][p] = MU_LOAD(&a.mu_in[((int64_t)kc * P + p) * N64 + ii]);
             lhv[kk] = ONE_ANNOT ? 0.0 : lh[kc];
         }
     };
@@ -552,7 +584,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                     t = 0.0;
 #pragma unroll
                     for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
-                    if (live) a.mu_out[((int64_t)k * P + p) * N64 + i] = t;
+                    if (live) MU_STORE(&a.mu_out[((int64_t)k * P + p) * N64 + i], t);
                 }
                 mun[p] = t;
                 quad += t * nat[p];
@@ -695,7 +727,7 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
         for (int u = 0; u < KD; ++u) {
             const int kc = min(k0 + u * KS, M - 1);       // unconditional loads; extras ignored
 #pragma unroll
-            for (int p = 0; p < P; ++p) mu[u][p] = a.mu[((int64_t)kc * P + p) * N64 + ii];
+            for (int p = 0; p < P; ++p) mu[u][p] = MU_LOAD(&a.mu[((int64_t)kc * P + p) * N64 + ii]);
         }
 #pragma unroll
         for (int u = 0; u < KD; ++u) {
