@@ -109,3 +109,20 @@ def test_big_blocks_and_thresholding():
     _compare(_problem(rng, 1, [[700, 130, 129]], N=1000, M=5), sweeps=3)
     _compare(_problem(rng, 2, [[300, 200], [257, 255]], N=520, M=5, ldthresh=0.5), sweeps=3,
              scaled=True)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_configurations(seed):
+    """Seeded random problems across the kernel template space (P, M, A, LD thresholds, block
+    sizes on and around the 128-column slab and 256-column chunk boundaries, --scaled /
+    --learn-scaling), three sweeps each against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.integers(1, 5))
+    M = int(rng.choice([2, 3, 7, 12, 33, 70]))
+    A = int(rng.integers(1, 4))
+    pool = [1, 2, 5, 31, 64, 127, 128, 129, 200, 255, 256, 257, 300, 513]
+    sizes = [[int(v) for v in rng.choice(pool, size=int(rng.integers(1, 5)))] for _ in range(P)]
+    N = max(sum(s) for s in sizes) + int(rng.integers(0, 9))
+    pr = _problem(rng, P, sizes, N=N, M=M, A=A, ldthresh=float(rng.choice([1.0, 0.7])),
+                  empty_annot=bool(rng.integers(0, 2)))
+    _compare(pr, sweeps=3, scaled=bool(rng.integers(0, 2)), scale_se=bool(rng.integers(0, 2)))
