@@ -147,6 +147,25 @@ int vilma_get_moments(vilma_ctx *ctx, double *mean, double *var);
  * _beta_KL (variational_inference.py:412-417, 452-470, 873-885). */
 int vilma_eval(vilma_ctx *ctx, void *stream, double *totals_dev);
 
+/* The same sums at (current vi_mu, a vi_delta SUPPLIED by the caller, current hyper/tau), for
+ * callers of elbo(params) / real_posterior_mean(vi_mu, vi_delta, hyper_delta) that pass a vi_delta
+ * which is not the fixed point of (vi_mu, hyper_delta, error_scaling) -- the reference evaluates
+ * what it is handed (variational_inference.py:412-417, 740-760, 873-885; numerics.py:49-65,
+ * 98-146).  delta_km_dev: device pointer, [M*N] component-major (vi_delta transposed).  Writes
+ * VILMA_NTOTALS(P) + 1 doubles: the sums, then max_ik |vi_delta_ik - derived delta_ik|.  Needs an
+ * accepted evaluation of the current state; the moments land in the trial buffers
+ * (vilma_get_trial_moments) and that trial state cannot be accepted.  Off the sweep path. */
+int vilma_eval_given_delta(vilma_ctx *ctx, void *stream, const double *delta_km_dev,
+                           double *totals_dev);
+int vilma_get_trial_moments(vilma_ctx *ctx, double *mean, double *var);
+
+/* _initialize's per-SNP part (variational_inference.py:658-692) on the device: from fake_mu
+ * [P*N] (host or device; the jittered ridge start, drawn by the host with the reference's RNG
+ * call) compute the heuristic responsibilities, write vi_mu = Sigma_ki (avg Sigma_i)^-1 fake_mu
+ * as the current state and the per-annotation responsibility sums [A*M] to sums_dev; the host
+ * all-reduces them, forms hyper_delta (:667-674), calls vilma_set_hyper and vilma_eval. */
+int vilma_init_state(vilma_ctx *ctx, void *stream, const double *fake_mu, double *sums_dev);
+
 /* One line-search trial of _update_beta (variational_inference.py:777-787) from the current
  * state with step size `step` = 1/L: natural-gradient blend (sum_betas, numerics.py:11-15;
  * _nat_grad_beta, variational_inference.py:804-823), new_mu, new_vi_delta, and the objective

@@ -492,6 +492,22 @@ def main():
         prob = make_problem(5, P=1, sizes=[64, 80, 50], M=10, ldthresh=1.0,
                             kind='ar1', frac_missing=0.03, A=3, shuffle=True)
         trajectory('p1_scaled', prob, n_sweeps=10, scaled=True, scale_se=True)
+    if want('p4_m81'):
+        # the shape of BASELINE.json configs[4]: 4 cohorts, M = 81 (the P > 2 branch of
+        # numerics.py:238-290 with a large component count), blocks wider than one 128-column slab
+        prob = make_problem(6, P=4, sizes=[140, 135], M=81, ldthresh=1.0,
+                            kind='ar1', frac_missing=0.03, A=1, shuffle=True)
+        trajectory('p4_m81', prob, n_sweeps=6)
+    if want('p2_bigblock'):
+        # a 330-SNP block: three slabs of the symmetric dense product, two combine chunks
+        prob = make_problem(7, P=2, sizes=[330, 140], M=10, ldthresh=1.0,
+                            kind='ar1', frac_missing=0.02, A=1, shuffle=True)
+        trajectory('p2_bigblock', prob, n_sweeps=8)
+    if want('p2_bigblock_lr'):
+        # the same shape with eigen-truncated factor-model LD (--ldthresh 0.8): multi-slab U
+        prob = make_problem(8, P=2, sizes=[330, 140], M=10, ldthresh=0.8,
+                            kind='factor', frac_missing=0.02, A=1, shuffle=True)
+        trajectory('p2_bigblock_lr', prob, n_sweeps=8)
 
 
 if __name__ == '__main__':

@@ -4,7 +4,8 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-TRAJ_NAMES = ['p1_dense', 'p2_lowrank', 'p2_scale_se', 'p4_general', 'p1_scaled']
+TRAJ_NAMES = ['p1_dense', 'p2_lowrank', 'p2_scale_se', 'p4_general', 'p1_scaled', 'p4_m81',
+              'p2_bigblock', 'p2_bigblock_lr']
 
 
 def golden(name):

@@ -143,6 +143,32 @@ class OracleEngine:
     def get_moments(self):
         return np.copy(self.cur['mean']), np.copy(self.cur['var'])
 
+    def init_state(self, fake_mu):
+        """_initialize's per-SNP part (variational_inference.py:658-692), restated with numpy."""
+        c = self._consts()
+        f = np.asarray(fake_mu)
+        matches = np.einsum('kpq,kqpi->ik', self.prec, c['sigma'])
+        probs = np.einsum('pi,oi,kpo->ik', 1.6 * f, 1.6 * f, self.prec) + matches - self.log_det
+        probs = np.exp(-0.5 * (probs - probs.min(axis=1, keepdims=True)))
+        delta = np.maximum(probs / probs.sum(axis=1, keepdims=True), nm.EPSILON)
+        avg = np.einsum('kpqi,ik->ipq', c['sigma'], delta)
+        nat = np.einsum('pi,iqp->qi', f, np.linalg.inv(avg))
+        self.mu = np.einsum('kqpi,pi->kqi', c['sigma'], nat)
+        self.cur = None
+        self._sums.copy_(torch.as_tensor(nm.sum_annotations(delta, self.annot, self.A).ravel()))
+        return self._sums
+
+    def eval_given_delta(self, vi_delta):
+        derived = self.cur['delta']
+        keep = self._totals.clone()
+        self.given_state, totals = self._moments(self.mu, np.asarray(vi_delta))
+        out = torch.cat([totals.clone(), torch.as_tensor([np.abs(vi_delta - derived).max()])])
+        self._totals.copy_(keep)
+        return out
+
+    def get_trial_moments(self):
+        return np.copy(self.given_state['mean']), np.copy(self.given_state['var'])
+
     # ---- evaluations
     def eval(self):
         self.mu_trial = None

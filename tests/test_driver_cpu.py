@@ -84,6 +84,67 @@ def test_validation_errors():
         MultiPopVI(**bad)
 
 
+def _supplied_delta_checks(vi, ovi, seed):
+    """elbo(params) / real_posterior_*(params) evaluate the vi_delta they are handed, as the
+    reference does (variational_inference.py:412-417, 740-751; its test_MultiPopVI_elbo,
+    tests/test.py:1517-1525, calls elbo on a hand-made tuple), while the fit itself continues
+    from the fixed point."""
+    np.random.seed(seed)
+    mu, delta, hyper = ovi._initialize()
+    np.random.seed(seed)
+    params = vi._initialize()
+    # a device-resident tuple needs no check at all
+    assert vi.elbo(params) == vi._objective and vi._given is None
+    rng = np.random.default_rng(3)
+    other = rng.dirichlet(np.ones(delta.shape[1]), size=delta.shape[0])    # not the fixed point
+    want, got = ovi.elbo((mu, other, hyper)), vi.elbo((mu, other, hyper))
+    assert vi._given is not None and vi._given['max_dev'] > 1e-3
+    assert abs(want - got) <= 1e-9 * abs(want)
+    # the reference's identity at that point: elbo = loglik - beta_KL - annotation_KL
+    assert np.isclose(want, ovi._log_likelihood((mu, other, hyper)) - ovi._beta_KL(mu, other, hyper))
+    np.testing.assert_allclose(vi.real_posterior_mean(mu, other, hyper),
+                               ovi.real_posterior_mean(mu, other, hyper), rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(vi.real_posterior_variance(mu, other, hyper),
+                               ovi.real_posterior_variance(mu, other, hyper), rtol=1e-8,
+                               atol=1e-16)
+    # the fixed point itself is recognised (no second evaluation kept) and gives the usual ELBO
+    assert abs(vi.elbo((mu, delta, hyper)) - ovi.elbo((mu, delta, hyper))) <= 1e-9 * abs(want)
+    assert vi._given is None
+    # a sweep started from the foreign vi_delta continues from the fixed point, with a warning
+    L = np.ones(5)
+    p2, L, e2, _ = vi._optimize_step((mu, other, hyper), L, got, 2., None)
+    assert vi._given is None and np.isfinite(e2)
+
+
+def test_elbo_honours_a_supplied_vi_delta():
+    from helpers import oracle_from_traj
+    g = golden('traj_p2_scale_se.npz')
+    vi, _ = product_vi_from_traj(g, engine_factory=OracleEngine)
+    ovi, _ = oracle_from_traj(g)
+    _supplied_delta_checks(vi, ovi, int(g['seed']))
+
+
+def test_every_rank_detects_an_empty_shard():
+    """Fewer LD components than ranks: the deterministic plan is the same everywhere, so every
+    rank raises before the first collective (nobody is left waiting in an all-reduce)."""
+    from vilma_amd.variational_inference import MultiPopVI
+
+    class FakeComm:
+        active, backend, group = False, 'gloo', None
+
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+    g = golden('traj_p1_dense.npz')
+    _, ld = product_vi_from_traj(g, engine_factory=OracleEngine)
+    n_comp = len(ld[0].matrices) + len(g['missing'])
+    kw = dict(marginal_effects=g['betahat'], std_errs=g['se'], ld_mats=ld,
+              mixture_covs=list(g['covs']), annotations=g['annotations'], gwas_N=g['gwas_N'],
+              init_hg=g['init_hg'], num_its=3, _engine_factory=OracleEngine)
+    for rank in (0, n_comp):                  # a rank that has SNPs and one that has none
+        with pytest.raises(ValueError, match='no SNPs'):
+            MultiPopVI(_comm=FakeComm(rank, n_comp + 1), **kw)
+
+
 def _rank_main(rank, world, port, name, q):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

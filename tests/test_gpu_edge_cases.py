@@ -111,6 +111,36 @@ def test_big_blocks_and_thresholding():
              scaled=True)
 
 
+def test_c5_shape_p4_m81():
+    """The shape of BASELINE.json configs[4] -- 4 cohorts, M = 81 mixture components -- at a few
+    thousand SNPs against the oracle: the Cholesky (P > 2) branch of every per-SNP kernel
+    (reference numerics.py:238-290) with a large component count, multi-slab blocks, different
+    partitions per cohort; plain and with --learn-scaling."""
+    rng = np.random.default_rng(81)
+    sizes = [[700, 300, 260], [520, 740], [129, 1131], [400, 400, 400, 60]]
+    pr = _problem(rng, 4, sizes, N=1300, M=81)
+    _compare(pr, sweeps=3)
+    _compare(pr, sweeps=3, scale_se=True)
+    pr = _problem(rng, 4, [[257, 300], [600], [128, 128, 300], [555]], N=640, M=81, A=2,
+                  ldthresh=0.7)
+    _compare(pr, sweeps=3, scaled=True)
+
+
+def test_elbo_at_a_supplied_vi_delta():
+    """MultiPopVI.elbo / real_posterior_* honour a vi_delta that is not the fixed point
+    (vilma_eval_given_delta), P = 1, 2 and 4."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_driver_cpu import _supplied_delta_checks
+    rng = np.random.default_rng(12)
+    for P, sizes, N, M, A in ((1, [[130, 40]], 180, 7, 1),
+                              (2, [[50, 70], [120]], 130, 6, 2),
+                              (4, [[60], [30, 30], [129], [10, 200]], 230, 9, 1)):
+        pr = _problem(rng, P, sizes, N=N, M=M, A=A)
+        _supplied_delta_checks(_build(pr, 'product'), _build(pr, 'oracle'), 7)
+
+
 @pytest.mark.parametrize('seed', range(10))
 def test_random_configurations(seed):
     """Seeded random problems across the kernel template space (P, M, A, LD thresholds, block

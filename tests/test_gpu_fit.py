@@ -24,7 +24,7 @@ def test_fit_trajectory(name):
 
 
 @pytest.mark.parametrize('form', ['dense', 'eig'])
-@pytest.mark.parametrize('name', ['p2_lowrank', 'p4_general'])
+@pytest.mark.parametrize('name', ['p2_lowrank', 'p4_general', 'p2_bigblock_lr'])
 def test_fit_trajectory_forms(name, form):
     g = golden('traj_%s.npz' % name)
     vi, _ = product_vi_from_traj(g, form=form)

@@ -4,8 +4,6 @@ C2 (1 cohort, 100k SNPs, 500x200 blocks, M=25) is small enough for a direct comp
 oracle.  C3 (2 cohorts, 1M SNPs, ~1700 blocks, M=40) is checked through size-independent
 properties: the LD operator against the O(n) closed form of an AR(1) product, linearity,
 symmetry; the fit through ELBO monotonicity, line-search invariants and finiteness."""
-import os
-
 import numpy as np
 import pytest
 from scipy.signal import lfilter
@@ -13,12 +11,12 @@ from scipy.signal import lfilter
 pytestmark = pytest.mark.gpu
 
 
-def _setup(workload, seed=0):
+def _setup(workload, seed=0, form='auto'):
     import torch
     from vilma_amd.synthetic import SyntheticShard, WORKLOADS
     from vilma_amd.engine import HipEngine
     from vilma_amd.sharding import Comm
-    from vilma_amd.variational_inference import SweepDriver, initial_vi_mu, initial_hyper
+    from vilma_amd.variational_inference import SweepDriver
     device = torch.device('cuda', 0)
     sh = SyntheticShard(seed=seed, **WORKLOADS[workload]).build(device)
     sh.finish_init(sh.inv_se2_local)
@@ -27,12 +25,16 @@ def _setup(workload, seed=0):
     prec, log_det = np.linalg.inv(sh.covs), np.linalg.slogdet(sh.covs)[1]
     eng.set_mixture(prec, log_det)
     for p in range(sh.P):
-        eng.load_ld(p, sh.ld_blocks_torch(p, device), sh.perm, sh.n_ld, specs=sh.block_specs())
+        if sh.kind == 'lowrank':
+            eng.load_ld(p, sh.ld_blocks_torch(p, device, form), sh.perm, sh.n_ld,
+                        specs=sh.block_specs(form))
+        else:
+            eng.load_ld(p, sh.ld_blocks_torch(p, device), sh.perm, sh.n_ld,
+                        specs=sh.block_specs())
     drv = SweepDriver()
     drv._setup_driver(eng, Comm(), sh.P, sh.M, 1, sh.chi_local, sh.rank_local, [sh.N_global],
                       log_det, scale_se=False, num_its=100)
-    vi_mu0, sums = initial_vi_mu(sh.fake_mu, sh.sld, np.ones(sh.P), prec, log_det, sh.annot, 1)
-    return sh, eng, drv, vi_mu0, initial_hyper(sums)
+    return sh, eng, drv
 
 
 def _ar1_product(sh, p, x):
@@ -49,7 +51,7 @@ def _ar1_product(sh, p, x):
 
 
 def test_c3_ld_operator_properties():
-    sh, eng, drv, _, _ = _setup('C3')
+    sh, eng, drv = _setup('C3')
     assert sh.N_global > 1_000_000 and len(sh.sizes_all) == 1700
     rng = np.random.default_rng(5)
     x, y = rng.normal(size=(sh.P, sh.N)), rng.normal(size=(sh.P, sh.N))
@@ -67,8 +69,8 @@ def test_c3_ld_operator_properties():
 
 
 def test_c3_fit_invariants():
-    sh, eng, drv, vi_mu0, hyper0 = _setup('C3')
-    drv.start_from(vi_mu0, hyper0)
+    sh, eng, drv = _setup('C3')
+    drv.initialize_from(sh.fake_mu)       # _initialize's per-SNP part on the device
     state, elbo_prev = None, drv._objective
     assert np.isfinite(elbo_prev)
     for it in range(4):
@@ -92,7 +94,7 @@ def test_c2_three_sweeps_against_oracle():
     from oracle.ldop import EigenBlock, BlockDiagonalLD
     from oracle.vi import MultiPopVIOracle
     from vilma_amd.synthetic import ar1_numpy
-    sh, eng, drv, vi_mu0, hyper0 = _setup('C2')
+    sh, eng, drv = _setup('C2')
     assert sh.N == 100_000 and len(sh.blocks) == 500
     ld = [BlockDiagonalLD([EigenBlock(ar1_numpy(b.n, b.rho[p]), 1.0) for b in sh.blocks],
                           perm=sh.perm, missing=sh.missing) for p in range(sh.P)]
@@ -104,14 +106,24 @@ def test_c2_three_sweeps_against_oracle():
     np.testing.assert_allclose(ovi.adj_marginal_effects, sh.adj, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(ovi.chi_stat, sh.chi_local, rtol=1e-8)
     np.testing.assert_allclose(ovi.inverse_betas, sh.inverse_betas, rtol=1e-5, atol=1e-9)
-    # same start for both (the oracle's own _initialize draws different jitter)
+    # same start for both (the oracle's own _initialize draws different jitter): the device's
+    # _initialize, checked here against the oracle's restatement of it on the same fake_mu
+    drv.initialize_from(sh.fake_mu)
+    vi_mu0, hyper0 = eng.get_mu(), drv._hyper
+    from oracle_engine import OracleEngine
+    oeng = OracleEngine(sh.P, sh.N, sh.M, 1)
+    oeng.set_snp_data(sh.adj, sh.se, sh.sld, sh.scalings, sh.annot)
+    oeng.set_mixture(np.linalg.inv(sh.covs), np.linalg.slogdet(sh.covs)[1])
+    osums = oeng.init_state(sh.fake_mu).numpy()
+    np.testing.assert_allclose(vi_mu0, oeng.mu, rtol=1e-9, atol=1e-14)
+    ohyper = (osums.reshape(1, -1) + 1.) / (osums.sum() + sh.M)
+    np.testing.assert_allclose(hyper0, np.maximum(ohyper, 1e-100), rtol=1e-10)
     ovi.nat_grad_vi_delta = None
     from oracle import numerics as nm
     ovi.nat_grad_vi_delta = nm.fast_vi_delta_grad(hyper0, ovi.log_det, ovi.annotations)
     _, d0, _ = ovi._nat_to_not_vi_delta((vi_mu0, None, hyper0))
     oparams = (vi_mu0, d0, hyper0)
     oelbo = ovi.elbo(oparams)
-    drv.start_from(vi_mu0, hyper0)
     assert abs(drv._objective - oelbo) < 1e-8 * abs(oelbo)
     state, oL, ored = None, np.ones(5), None
     for it in range(3):
@@ -124,12 +136,50 @@ def test_c2_three_sweeps_against_oracle():
     eng.close()
 
 
-@pytest.mark.skipif(os.environ.get('VILMA_TEST_C5') != '1',
-                    reason='C5 (4 cohorts, 5M SNPs, M=81) takes ~10 min of setup: set VILMA_TEST_C5=1')
+def test_c4_eigen_form_operator_and_fit():
+    """BASELINE.json configs[3] at full size with EVERY block in eigen form: ld_colsum_kernel on
+    multi-slab U / diag(s)U^T (reference LowRankMatrix.dot, matrix_structures.py:148-152) against
+    U (s * (U^T x)) formed with torch on a sample of blocks, plus linearity, symmetry, zero rows
+    at LD-missing SNPs, and the fit invariants."""
+    import torch
+    sh, eng, drv = _setup('C4', form='eig')
+    assert sh.kind == 'lowrank' and sh.N_global > 1_000_000 and len(sh.sizes_all) == 1700
+    alg, stored = eng.ld_bytes()
+    assert alg == sh.ld_bytes and 2.0 * alg <= stored < 2.2 * alg      # U and diag(s)U^T, padded rows
+    rng = np.random.default_rng(9)
+    x, y = rng.normal(size=(sh.P, sh.N)), rng.normal(size=(sh.P, sh.N))
+    rx, ry = eng.ld_matvec(x), eng.ld_matvec(y)
+    order = np.argsort(sh.sizes)
+    sample = sorted(set(range(0, len(sh.blocks), 40)) | set(order[:3].tolist()) | set(order[-3:].tolist()))
+    assert max(int(sh.ranks[i]) for i in sample) > 512                  # several 128-column slabs of U
+    for p in range(sh.P):
+        for i in sample:
+            U, sv = sh._eig[p][i]
+            lo = sh.snp_start[i]
+            xb = torch.as_tensor(x[p, lo:lo + U.shape[0]], device=U.device)
+            want = (U @ (sv * (U.T @ xb))).cpu().numpy()
+            np.testing.assert_allclose(rx[p, lo:lo + U.shape[0]], want, rtol=1e-10, atol=1e-10)
+    assert np.all(rx[:, sh.missing] == 0.0)
+    rz = eng.ld_matvec(2.5 * x - 0.75 * y)
+    np.testing.assert_allclose(rz, 2.5 * rx - 0.75 * ry, rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose((x * ry).sum(axis=1), (y * rx).sum(axis=1), rtol=1e-10)
+    drv.initialize_from(sh.fake_mu)
+    state, elbo_prev = None, drv._objective
+    assert np.isfinite(elbo_prev)
+    for it in range(3):
+        state, stats = drv.sweep(state)
+        assert state['elbo'] >= elbo_prev - 25 * (1e-6 * abs(elbo_prev) + 1e-6)
+        assert np.all(np.isfinite(stats))
+        elbo_prev = state['elbo']
+    obj, _ = drv._evaluate()
+    assert abs(obj - drv._objective) <= 1e-12 * abs(obj)
+    eng.close()
+
+
 def test_c5_operator_and_fit_invariants():
     """BASELINE.json configs[4] on ONE GPU: P=4 (Cholesky branch of the per-SNP pass), 34 000
     block-cohorts, ~100 GB resident.  Same size-independent properties as C3."""
-    sh, eng, drv, vi_mu0, hyper0 = _setup('C5')
+    sh, eng, drv = _setup('C5')
     assert sh.P == 4 and sh.M == 81 and sh.N_global > 5_000_000 and len(sh.sizes_all) == 8500
     rng = np.random.default_rng(6)
     x = rng.normal(size=(sh.P, sh.N))
@@ -137,7 +187,7 @@ def test_c5_operator_and_fit_invariants():
     for p in range(sh.P):
         np.testing.assert_allclose(rx[p], _ar1_product(sh, p, x[p]), rtol=1e-10, atol=1e-10)
     assert np.all(rx[:, sh.missing] == 0.0)
-    drv.start_from(vi_mu0, hyper0)
+    drv.initialize_from(sh.fake_mu)
     state, elbo_prev = None, drv._objective
     assert np.isfinite(elbo_prev)
     for it in range(3):

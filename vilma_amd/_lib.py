@@ -72,6 +72,9 @@ def load():
         'vilma_get_delta': (C.c_int, [vp, vp]),
         'vilma_get_moments': (C.c_int, [vp, vp, vp]),
         'vilma_eval': (C.c_int, [vp, vp, vp]),
+        'vilma_eval_given_delta': (C.c_int, [vp, vp, vp, vp]),
+        'vilma_get_trial_moments': (C.c_int, [vp, vp, vp]),
+        'vilma_init_state': (C.c_int, [vp, vp, vp, vp]),
         'vilma_trial_beta': (C.c_int, [vp, vp, C.c_double, vp]),
         'vilma_accept': (C.c_int, [vp, C.c_int]),
         'vilma_delta_sums': (C.c_int, [vp, vp, vp, C.c_int]),

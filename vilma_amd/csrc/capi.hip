@@ -79,6 +79,7 @@ struct vilma_ctx {
     int mom_cur = 0;
     int64_t pool_elems = 0;
     bool have_moments = false;
+    bool trial_tainted = false;     // trial moments come from vilma_eval_given_delta
 
     double *snapshot = nullptr, *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;
@@ -419,10 +420,11 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     }
     rc |= dev_alloc(c, &c->snapshot, PN);
     rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * P + 2));
-    // per-wave rows plus the scratch rows of the two-stage column reduction (<= rows/256 + 2)
+    // per-wave rows plus the scratch rows of every pass of the column reduction (exact)
     rc |= dev_alloc(c, &c->delta_partials,
-                    ((int64_t)delta_grid(N) * 4 + delta_grid(N) / 64 + 8) * A * M);
-    rc |= dev_alloc(c, &c->diff_partials, (int64_t)mean_diff_grid(PN) * 6);
+                    std::max(delta_partial_rows(N), init_partial_rows(N)) * A * M);
+    rc |= dev_alloc(c, &c->diff_partials,
+                    std::max((int64_t)mean_diff_grid(PN) * 6, (int64_t)snp_pass_grid(N)));
     if (rc) {
         g_create_error = c->err;
         vilma_destroy(c);
@@ -695,17 +697,70 @@ int vilma_get_moments(vilma_ctx *c, double *mean, double *var) {
 
 int vilma_eval(vilma_ctx *c, void *stream, double *totals_dev) {
     if (!c) return 1;
+    c->trial_tainted = false;
     return evaluate(c, (hipStream_t)stream, false, 0.0, totals_dev);
+}
+
+int vilma_eval_given_delta(vilma_ctx *c, void *stream, const double *delta_km_dev,
+                           double *totals_dev) {
+    if (!c) return 1;
+    if (ensure_ready(c)) return 1;
+    if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
+    hipStream_t s = (hipStream_t)stream;
+    SnpKernelArgs a;
+    fill_snp_args(c, a, 0.0);
+    c->snp_marked = false;          // nothing of this evaluation may overlap on the side stream
+    launch_snp_given_delta(a, delta_km_dev, c->lse[c->mom_cur], c->diff_partials,
+                           totals_dev + VILMA_NTOTALS(c->P), s);
+    run_ld(c, s, c->pool[1 - c->mom_cur], -1);
+    launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start.data(),
+                    totals_dev, s);
+    HIPCHK(c, hipGetLastError());
+    c->trial_tainted = true;        // these moments belong to no state the line search may accept
+    return 0;
+}
+
+int vilma_get_trial_moments(vilma_ctx *c, double *mean, double *var) {
+    if (!c) return 1;
+    if (!c->ready) return fail(c, "no trial state");
+    HIPCHK(c, hipDeviceSynchronize());
+    const size_t b = (size_t)c->P * c->N * sizeof(double);
+    if (mean) HIPCHK(c, hipMemcpy(mean, c->m[1 - c->mom_cur], b, hipMemcpyDefault));
+    if (var) HIPCHK(c, hipMemcpy(var, c->v[1 - c->mom_cur], b, hipMemcpyDefault));
+    return 0;
+}
+
+int vilma_init_state(vilma_ctx *c, void *stream, const double *fake_mu, double *sums_dev) {
+    if (!c) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipDeviceSynchronize());
+    // the snapshot buffer ([P][N]) is free until the sweep loop starts: staging for fake_mu
+    HIPCHK(c, hipMemcpy(c->snapshot, fake_mu, (size_t)c->P * c->N * sizeof(double), hipMemcpyDefault));
+    InitArgs a;
+    a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
+    a.fake_mu = c->snapshot; a.sld = c->sld; a.annot = c->annot;
+    a.prec = c->prec; a.log_det = c->log_det;
+    a.mu_out = c->mu[c->mu_cur];
+    a.partials = c->delta_partials;
+    for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
+    launch_init_state(a, sums_dev, s);
+    HIPCHK(c, hipGetLastError());
+    c->have_moments = false;
+    return 0;
 }
 
 int vilma_trial_beta(vilma_ctx *c, void *stream, double step, double *totals_dev) {
     if (!c) return 1;
+    c->trial_tainted = false;
     return evaluate(c, (hipStream_t)stream, true, step, totals_dev);
 }
 
 int vilma_accept(vilma_ctx *c, int take_mu) {
     if (!c) return 1;
     if (!c->ready) return fail(c, "nothing to accept");
+    if (c->trial_tainted)
+        return fail(c, "the trial state was evaluated with a caller-supplied vi_delta and cannot "
+                       "be accepted");
     c->mom_cur = 1 - c->mom_cur;
     if (take_mu) c->mu_cur = 1 - c->mu_cur;
     c->have_moments = true;

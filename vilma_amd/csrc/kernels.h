@@ -90,6 +90,29 @@ struct DeltaArgs {
 void launch_delta_sums(const DeltaArgs &a, double *sums_out /*[A*M]*/, hipStream_t s);
 void launch_delta_write(const DeltaArgs &a, hipStream_t s);
 int delta_grid(int64_t N);
+// rows ([A*M] doubles each) of the partials buffer launch_delta_sums needs: one per wave plus the
+// scratch rows of its multi-pass column reduction
+int64_t delta_partial_rows(int64_t N);
+
+// _initialize's per-SNP part on the device: vi_mu [M][P][N] and the heuristic responsibility sums
+struct InitArgs {
+    int32_t N, M, A, P;
+    const double *fake_mu;    // [P][N]
+    const double *sld;        // [P][N]
+    const int32_t *annot;
+    const double *prec, *log_det;
+    double *mu_out;           // [M][P][N]
+    double *partials;         // [init_partial_rows(N)][A*M]
+    TauArg tau;
+};
+void launch_init_state(const InitArgs &a, double *sums_out /*[A*M]*/, hipStream_t s);
+int64_t init_partial_rows(int64_t N);
+
+// objective pieces with a caller-supplied vi_delta ([M][N], component-major); writes the trial
+// moments / pool like launch_snp_pass and max |delta - derived delta| to *maxdev_out
+void launch_snp_given_delta(const SnpKernelArgs &a, const double *delta_km, const double *lse_cur,
+                            double *maxdev_partials /*[snp_pass_grid]*/, double *maxdev_out,
+                            hipStream_t s);
 
 void launch_gather_x(const double *x_snp, const int32_t *invperm, double *pool_x, int N, int P,
                      hipStream_t s);

@@ -822,9 +822,25 @@ __global__ __launch_bounds__(256) void reduce_cols_kernel(const double *__restri
         out[(int64_t)blockIdx.y * ncols + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// rows of scratch reduce_cols needs behind `rows` partial rows: the chunk rows of every pass but
+// the last (which writes the result)
+int64_t reduce_cols_scratch_rows(int64_t rows) {
+    int64_t total = 0;
+    while (rows > RC_CHUNK_ROWS) {
+        rows = (rows + RC_CHUNK_ROWS - 1) / RC_CHUNK_ROWS;
+        total += rows;
+    }
+    return total;
+}
+
+int64_t delta_partial_rows(int64_t N) {
+    const int64_t rows = (int64_t)delta_grid(N) * (SNP_THREADS / 64);
+    return rows + reduce_cols_scratch_rows(rows);
+}
+
 static void reduce_cols(const double *in, int rows, int ncols, double *scratch, double *out,
                         hipStream_t s) {
-    // scratch must hold ceil(rows / RC_CHUNK_ROWS) * ncols doubles
+    // scratch must hold reduce_cols_scratch_rows(rows) * ncols doubles
     const int colblocks = (ncols + 63) / 64;
     while (rows > RC_CHUNK_ROWS) {
         const int chunks = (rows + RC_CHUNK_ROWS - 1) / RC_CHUNK_ROWS;
@@ -869,6 +885,282 @@ void launch_delta_sums(const DeltaArgs &a, double *sums_out, hipStream_t s) {
 }
 
 void launch_delta_write(const DeltaArgs &a, hipStream_t s) { launch_delta_any<true>(a, s); }
+
+// --------------------------------------------------------------------------------------------
+// _initialize on the device (variational_inference.py:658-692): from the jittered start fake_mu
+// [P][N] (drawn on the host with the reference's legacy RNG call) the heuristic responsibilities
+//   delta_ik ~ exp(-0.5 (1.6^2 f^T Prec_k f + tr(Prec_k Sig_ki) - log_det_k)),  clamped at 1e-100,
+// their per-annotation sums (-> hyper_delta on the host), avg_i = sum_k delta_ik Sig_ki and
+//   vi_mu_ki = Sig_ki avg_i^-1 f_i
+// written straight into the vi_mu buffer: no [M,P,N] array is ever built on the host or crosses
+// PCIe.  Thread per SNP; two passes over the components (normaliser, then outputs), everything
+// else in registers.  Partial sums per wave row, reduced by reduce_cols like delta_kernel's.
+// --------------------------------------------------------------------------------------------
+template <int P, bool ONE_ANNOT>
+__global__ __launch_bounds__(SNP_THREADS) void init_state_kernel(const InitArgs a) {
+    const int N = a.N, M = a.M, A = a.A;
+    const int64_t N64 = N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * SNP_THREADS + threadIdx.x;
+    const bool live = i < N;
+    const int ii = live ? i : N - 1;
+    double d[P], f[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        d[p] = a.sld[p * N64 + ii] / a.tau.v[p];
+        f[p] = a.fake_mu[p * N64 + ii];
+    }
+    const int ann = ONE_ANNOT ? 0 : a.annot[ii];
+    const const_tab prec_tab = as_table(a.prec);
+    const const_tab ld_tab = as_table(a.log_det);
+    // pass 1: x_k = -0.5 probs_k, running maximum, Z = sum exp(x_k - max), avg ~ sum e_k Sig_k
+    auto half_neg_probs = [&](int k, double (&sig)[P][P]) {
+        double pr[P][P], lam[P][P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                pr[p][q] = prec_tab[(int64_t)k * P * P + p * P + q];
+                lam[p][q] = pr[p][q];
+            }
+            lam[p][p] += d[p];
+        }
+        spd_inverse<P>(lam, sig);
+        double quad = 0.0, tr = (double)P;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < P; ++q) t += pr[p][q] * (1.6 * f[q]);
+            quad += (1.6 * f[p]) * t;
+            tr = fma(-d[p], sig[p][p], tr);          // tr(Prec Sig) = P - tr(D Sig)
+        }
+        return -0.5 * (quad + tr - ld_tab[k]);
+    };
+    double mx = NEG_INF, Z = 0.0, avg[P][P];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < P; ++q) avg[p][q] = 0.0;
+    for (int k = 0; k < M; ++k) {
+        double sig[P][P];
+        const double x = half_neg_probs(k, sig);
+        const double dk = x - mx;
+        const double t = exp(-fabs(dk));
+        const bool up = dk > 0.0;
+        const double sc = up ? t : 1.0, e = up ? 1.0 : t;
+        mx = up ? x : mx;
+        Z = fma(Z, sc, e);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int q = 0; q < P; ++q) avg[p][q] = fma(avg[p][q], sc, e * sig[p][q]);
+    }
+    const double invZ = 1.0 / Z;
+    double avgn[P][P], iavg[P][P], nat[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < P; ++q) avgn[p][q] = avg[p][q] * invZ;
+    spd_inverse<P>(avgn, iavg);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) t += iavg[p][q] * f[q];
+        nat[p] = t;
+    }
+    // pass 2: vi_mu_k = Sig_k nat and the responsibility sums
+    double *prow = a.partials + ((int64_t)blockIdx.x * (SNP_THREADS / 64) + w) * A * M;
+    for (int k = 0; k < M; ++k) {
+        double sig[P][P];
+        const double x = half_neg_probs(k, sig);
+        const double delta = fmax(exp(x - mx) * invZ, 1e-100);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+            if (live) a.mu_out[((int64_t)k * P + p) * N64 + i] = t;
+        }
+        if (ONE_ANNOT) {
+            const double s = wave_sum(live ? delta : 0.0);
+            if (lane == 0) prow[k] = s;
+        } else {
+            for (int aa = 0; aa < A; ++aa) {
+                const double s = wave_sum((live && ann == aa) ? delta : 0.0);
+                if (lane == 0) prow[(int64_t)aa * M + k] = s;
+            }
+        }
+    }
+}
+
+int64_t init_partial_rows(int64_t N) {
+    const int64_t rows = (int64_t)snp_pass_grid(N) * (SNP_THREADS / 64);
+    return rows + reduce_cols_scratch_rows(rows);
+}
+
+template <int P>
+static void launch_init_p(const InitArgs &a, hipStream_t s) {
+    const dim3 grid(snp_pass_grid(a.N)), block(SNP_THREADS);
+    if (a.A == 1) hipLaunchKernelGGL((init_state_kernel<P, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((init_state_kernel<P, false>), grid, block, 0, s, a);
+}
+
+void launch_init_state(const InitArgs &a, double *sums_out, hipStream_t s) {
+    switch (a.P) {
+        case 1: launch_init_p<1>(a, s); break;
+        case 2: launch_init_p<2>(a, s); break;
+        case 3: launch_init_p<3>(a, s); break;
+        case 4: launch_init_p<4>(a, s); break;
+        default: break;
+    }
+    const int ncols = a.A * a.M;
+    const int rows = snp_pass_grid(a.N) * (SNP_THREADS / 64);
+    reduce_cols(a.partials, rows, ncols, a.partials + (int64_t)rows * ncols, sums_out, s);
+}
+
+// --------------------------------------------------------------------------------------------
+// Objective pieces of (current vi_mu, a vi_delta GIVEN by the caller, current hyper / tau): what
+// elbo(params), real_posterior_mean/variance compute in the reference when they are handed a
+// vi_delta that is not the coordinate-ascent fixed point of (vi_mu, hyper_delta, error_scaling)
+// (variational_inference.py:412-417, 740-760, 873-885; numerics.py:49-65, 98-146).  Off the sweep
+// path: logs per (component, SNP), no cancellation tricks.  delta comes component-major [M][N].
+// Also reports max |delta_given - delta_derived| (derived from the lse of the accepted state).
+// --------------------------------------------------------------------------------------------
+template <int P, bool ONE_ANNOT>
+__global__ __launch_bounds__(SNP_THREADS) void snp_given_delta_kernel(const SnpKernelArgs a,
+                                                                      const double *__restrict__ delta_km,
+                                                                      const double *__restrict__ lse_cur,
+                                                                      double *__restrict__ maxdev_partials) {
+    constexpr int NT = 2 * P + 2;
+    __shared__ double red[SNP_THREADS / 64][NT + 1];
+    const int N = a.N, M = a.M;
+    const int64_t N64 = N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * SNP_THREADS + threadIdx.x;
+    const bool live = i < N;
+    const int ii = live ? i : N - 1;
+    double d[P], se[P], adj[P], sld[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        se[p] = a.se[p * N64 + ii];
+        adj[p] = a.adj[p * N64 + ii];
+        sld[p] = a.sld[p * N64 + ii];
+        d[p] = sld[p] / a.tau.v[p];
+    }
+    const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
+    const double lse = lse_cur[ii];
+    double Skl = 0.0, Sip = 0.0, dev = 0.0, Sm[P], S2[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { Sm[p] = 0.0; S2[p] = 0.0; }
+    for (int k = 0; k < M; ++k) {
+        double pr[P][P], lam[P][P], sig[P][P], mu[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                pr[p][q] = a.prec[(int64_t)k * P * P + p * P + q];
+                lam[p][q] = pr[p][q];
+            }
+            lam[p][p] += d[p];
+            mu[p] = a.mu_in[((int64_t)k * P + p) * N64 + ii];
+        }
+        const double wk = spd_inverse<P>(lam, sig);            // det(lam)^-1/2
+        const double dl = delta_km[(int64_t)k * N64 + ii];
+        double quad = 0.0, ip = 0.0, tr = 0.0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            double t = 0.0, u = 0.0;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                t += lam[p][q] * mu[q];
+                u += pr[p][q] * mu[q];
+                tr += pr[p][q] * sig[q][p];
+            }
+            quad += mu[p] * t;
+            ip += mu[p] * u;
+        }
+        // log h_k = lh_k + 0.5 log_det_k;  log det Sig_ki = 2 log wk
+        const double log_h = lh[k] + 0.5 * a.log_det[k];
+        const double sigma_summary = a.log_det[k] - 2.0 * log(wk) + tr;
+        Skl += dl * (log(dl) - log_h) + 0.5 * sigma_summary * dl;
+        Sip += 0.5 * dl * ip;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            Sm[p] = fma(dl, mu[p], Sm[p]);
+            S2[p] = fma(dl, sig[p][p] + mu[p] * mu[p], S2[p]);
+        }
+        const double derived = fmax(wk * exp(0.5 * quad + lh[k] - lse), 1e-100);
+        dev = fmax(dev, fabs(dl - derived));
+    }
+    double part[NT + 1];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const double m = Sm[p];
+        const double v = S2[p] - m * m;
+        if (live) {
+            a.m_out[p * N64 + i] = m;
+            a.v_out[p * N64 + i] = v;
+            a.pool_out[p * N64 + a.invperm[p * N64 + i]] = m / se[p];
+        }
+        part[p] = live ? m * adj[p] : 0.0;
+        part[P + p] = live ? sld[p] * v : 0.0;
+    }
+    part[2 * P] = live ? Skl : 0.0;
+    part[2 * P + 1] = live ? Sip : 0.0;
+    part[NT] = live ? dev : 0.0;
+#pragma unroll
+    for (int t = 0; t <= NT; ++t) {
+        const double s = t < NT ? wave_sum(part[t]) : wave_max(part[t]);
+        if (lane == 0) red[w][t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x <= NT) {
+        const int t = threadIdx.x;
+        double s = red[0][t];
+#pragma unroll
+        for (int ww = 1; ww < SNP_THREADS / 64; ++ww) s = t < NT ? s + red[ww][t] : fmax(s, red[ww][t]);
+        if (t < NT) a.partials[(int64_t)t * gridDim.x + blockIdx.x] = s;
+        else maxdev_partials[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void max_reduce_kernel(const double *__restrict__ v, int n,
+                                                          double *__restrict__ out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < n; r += 256) acc = fmax(acc, v[r]);
+    acc = wave_max(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+template <int P>
+static void launch_given_p(const SnpKernelArgs &a, const double *delta_km, const double *lse_cur,
+                           double *maxdev_partials, hipStream_t s) {
+    const dim3 grid(snp_pass_grid(a.N)), block(SNP_THREADS);
+    if (a.A == 1)
+        hipLaunchKernelGGL((snp_given_delta_kernel<P, true>), grid, block, 0, s, a, delta_km, lse_cur,
+                           maxdev_partials);
+    else
+        hipLaunchKernelGGL((snp_given_delta_kernel<P, false>), grid, block, 0, s, a, delta_km, lse_cur,
+                           maxdev_partials);
+}
+
+void launch_snp_given_delta(const SnpKernelArgs &a, const double *delta_km, const double *lse_cur,
+                            double *maxdev_partials, double *maxdev_out, hipStream_t s) {
+    switch (a.P) {
+        case 1: launch_given_p<1>(a, delta_km, lse_cur, maxdev_partials, s); break;
+        case 2: launch_given_p<2>(a, delta_km, lse_cur, maxdev_partials, s); break;
+        case 3: launch_given_p<3>(a, delta_km, lse_cur, maxdev_partials, s); break;
+        case 4: launch_given_p<4>(a, delta_km, lse_cur, maxdev_partials, s); break;
+        default: break;
+    }
+    hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, s, maxdev_partials,
+                       snp_pass_grid(a.N), maxdev_out);
+}
 
 // --------------------------------------------------------------------------------------------
 // deterministic block-wide sum helper for single-workgroup finalisers

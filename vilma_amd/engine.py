@@ -212,6 +212,35 @@ class HipEngine:
         self._check(self.lib.vilma_get_moments(self.ctx, _ptr(mean), _ptr(var)))
         return mean, var
 
+    def init_state(self, fake_mu):
+        """_initialize's per-SNP part on the device: vi_mu becomes the current state; returns the
+        device view of the heuristic responsibility sums [A*M] (the `sums` slice of `results`)."""
+        fake_mu = _f64(fake_mu)
+        assert fake_mu.shape == (self.P, self.N)
+        self._check(self.lib.vilma_init_state(self.ctx, self._stream_handle, _ptr(fake_mu),
+                                              self._p['sums']))
+        return self._sums
+
+    def eval_given_delta(self, vi_delta):
+        """Sums of (current vi_mu, the vi_delta given [N,M], current hyper/tau) plus
+        max |vi_delta - derived delta| as a device tensor [3P+3]; the moments of that point are
+        then available from get_trial_moments()."""
+        t = self.torch
+        vi_delta = np.asarray(vi_delta, dtype=np.float64)
+        assert vi_delta.shape == (self.N, self.M)
+        dkm = t.as_tensor(np.ascontiguousarray(vi_delta.T), device=self.device)
+        out = t.zeros(self.n_totals + 1, dtype=t.float64, device=self.device)
+        self._check(self.lib.vilma_eval_given_delta(self.ctx, self._stream_handle,
+                                                    C.c_void_p(dkm.data_ptr()),
+                                                    C.c_void_p(out.data_ptr())))
+        self.torch.cuda.current_stream().synchronize()      # dkm must outlive the kernels
+        return out
+
+    def get_trial_moments(self):
+        mean, var = np.empty((self.P, self.N)), np.empty((self.P, self.N))
+        self._check(self.lib.vilma_get_trial_moments(self.ctx, _ptr(mean), _ptr(var)))
+        return mean, var
+
     # ------------------------------------------------------------------ evaluations
     def eval(self):
         self._check(self.lib.vilma_eval(self.ctx, self._stream_handle, self._p['totals']))

@@ -5,9 +5,10 @@ global problem is identical however the blocks are sharded over GPUs -- the 1/2/
 of bench.py fit the same data.  LD is AR(1) per (block, cohort), which is positive definite:
 the reference's eigen-decomposition at ldthresh=1 keeps every eigenpair, so the operator is
 the matrix itself, R^+ = R^-1 and rank = n -- the load-time constants of VIScheme.__init__
-(reference variational_inference.py:236-252) are computed here in that closed form, on the
-GPU with torch.linalg for the full-size workloads (no per-block eigh of 3400 blocks on the
-host), on the host with numpy for the small parity cases.
+(reference variational_inference.py:236-252) are computed here in closed form: the Cholesky
+factor of an AR(1) matrix is the AR(1) recursion and its inverse is tridiagonal, so sumstats,
+chi statistics and the ridge start cost O(n) per block on the host (no per-block
+factorisation of the 3 400 / 34 000 block-cohorts of workloads C3 / C5).
 
 SNP layout: block after block, each block's LD SNPs followed by the LD-missing SNPs attached
 to it (`missing_frac` of all SNPs, multinomially spread), so `perm` is not the identity.
@@ -175,9 +176,7 @@ class SyntheticShard:
             return
         for blk in self.blocks:
             idx = torch.arange(blk.n, device=device, dtype=torch.float64)
-            yield ('dense', torch.pow(torch.tensor(float(blk.rho[p]), device=device,
-                                                   dtype=torch.float64),
-                                      (idx[:, None] - idx[None, :]).abs()))
+            yield ('dense', torch.pow(float(blk.rho[p]), (idx[:, None] - idx[None, :]).abs()))
 
     def block_specs(self, form='auto'):
         if self.kind == 'lowrank':
@@ -191,8 +190,8 @@ class SyntheticShard:
 
     # ------------------------------------------------------------------ sumstats + constants
     def build(self, device=None):
-        """Sumstats and the load-time constants for this shard.  With `device` (a torch CUDA
-        device) the per-block linear algebra runs on the GPU via torch.linalg; otherwise numpy.
+        """Sumstats and the load-time constants for this shard (closed forms on the host for
+        AR(1) LD; the eigen-form workload builds its factors on `device` with torch.linalg).
         Sets: betahat, se, ld_diags, sld, adj, scalings, annot [.., N] local arrays;
         chi_local [P], rank_local [P], inv_se2_local [P]; call finish_init(inv_se2_global) to
         get inverse_betas."""
@@ -312,32 +311,45 @@ class SyntheticShard:
         return self
 
 
-def _block_sumstats(n, rho, z_true, eps, device):
-    """z-hat = R z + R^(1/2) eps (recipe of reference sim.py:136-156) and z-hat^T R^-1 z-hat."""
-    if device is None:
-        R = ar1_numpy(n, rho)
-        L = np.linalg.cholesky(R)
-        zhat = R @ z_true + L @ eps
-        w = np.linalg.solve(L, zhat)
-        return zhat, float(w @ w)
-    import torch
-    idx = torch.arange(n, device=device, dtype=torch.float64)
-    R = torch.pow(torch.tensor(float(rho), device=device, dtype=torch.float64),
-                  (idx[:, None] - idx[None, :]).abs())
-    L = torch.linalg.cholesky(R)
-    zt = torch.as_tensor(z_true, device=device)
-    ep = torch.as_tensor(eps, device=device)
-    zhat = R @ zt + L @ ep
-    w = torch.linalg.solve_triangular(L, zhat[:, None], upper=False)[:, 0]
-    return zhat.cpu().numpy(), float((w @ w).item())
+def ar1_apply(rho, x):
+    """R x for the AR(1) matrix R_ij = rho^|i-j| by its O(n) two-sided recursion."""
+    from scipy.signal import lfilter
+    fwd = lfilter([1.0], [1.0, -rho], x)
+    bwd = lfilter([1.0], [1.0, -rho], x[::-1])[::-1]
+    return fwd + bwd - x
 
 
-def _block_ridge(n, rho, reg, rhs, device):
-    if device is None:
-        return np.linalg.solve(ar1_numpy(n, rho) + np.diag(reg), rhs)
-    import torch
-    idx = torch.arange(n, device=device, dtype=torch.float64)
-    R = torch.pow(torch.tensor(float(rho), device=device, dtype=torch.float64),
-                  (idx[:, None] - idx[None, :]).abs())
-    R = R + torch.diag(torch.as_tensor(reg, device=device))
-    return torch.linalg.solve(R, torch.as_tensor(rhs, device=device)).cpu().numpy()
+def _block_sumstats(n, rho, z_true, eps, device=None):
+    """z-hat = R z + R^(1/2) eps (recipe of reference sim.py:136-156) and z-hat^T R^-1 z-hat,
+    in closed form for an AR(1) block: the Cholesky factor of R is the AR(1) recursion itself
+    (L eps: w_0 = eps_0, w_i = rho w_{i-1} + sqrt(1-rho^2) eps_i), so everything is O(n) on the
+    host -- the 34 000 block-cohorts of workload C5 need no per-block factorisation."""
+    from scipy.signal import lfilter
+    c = np.sqrt(1.0 - rho * rho)
+    e = c * eps
+    e[0] = eps[0]
+    zhat = ar1_apply(rho, z_true) + lfilter([1.0], [1.0, -rho], e)
+    w = np.empty(n)                       # w = L^-1 z-hat
+    w[0] = zhat[0]
+    w[1:] = (zhat[1:] - rho * zhat[:-1]) / c
+    return zhat, float(w @ w)
+
+
+def _block_ridge(n, rho, reg, rhs, device=None):
+    """(R + diag(reg))^-1 rhs for an AR(1) block: R^-1 = T is tridiagonal, so
+    (I + T diag(reg)) x = T rhs is one banded solve."""
+    if n == 1:
+        return rhs / (1.0 + reg)
+    from scipy.linalg import solve_banded
+    q = 1.0 / (1.0 - rho * rho)
+    tdiag = np.full(n, (1.0 + rho * rho) * q)
+    tdiag[0] = tdiag[-1] = q
+    toff = -rho * q
+    b = tdiag * rhs
+    b[:-1] += toff * rhs[1:]
+    b[1:] += toff * rhs[:-1]
+    ab = np.zeros((3, n))
+    ab[0, 1:] = toff * reg[1:]
+    ab[1] = 1.0 + tdiag * reg
+    ab[2, :-1] = toff * reg[:-1]
+    return solve_banded((1, 1), ab, b)

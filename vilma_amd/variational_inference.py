@@ -35,9 +35,6 @@ ELBO_MOMENTUM = 0.5
 MAX_NUM_ITERS = 20
 EPSILON = 1e-100    # reference numerics.py:8
 
-_INIT_CHUNK = 1 << 15
-
-
 def _inv_small(mats):
     """Inverse of [..., P, P] matrices; closed forms for P<=2 as the reference's helpers
     (numerics.py:216-244)."""
@@ -63,36 +60,6 @@ def _logdet_small(mats):
     if P == 2:
         return np.log(mats[..., 0, 0] * mats[..., 1, 1] - mats[..., 0, 1] * mats[..., 1, 0])
     return np.linalg.slogdet(mats)[1]
-
-
-def initial_vi_mu(fake_mu, sld, tau, prec, log_det, annot, num_annotations):
-    """The per-SNP part of _initialize (reference variational_inference.py:658-692) for the
-    SNPs given, in chunks so [n,M,P,P] temporaries stay small: heuristic responsibilities from
-    the 1.6x-inflated quadratic form, then vi_mu = Sigma_ki (avg Sigma_i)^-1 fake_mu.
-    Returns (vi_mu [M,P,n], per-annotation sums of the heuristic responsibilities [A,M])."""
-    P, n = fake_mu.shape
-    M = prec.shape[0]
-    vi_mu = np.empty((M, P, n))
-    sums = np.zeros((num_annotations, M))
-    idx = np.arange(P)
-    for lo in range(0, n, _INIT_CHUNK):
-        hi = min(n, lo + _INIT_CHUNK)
-        f = fake_mu[:, lo:hi]
-        lam = np.broadcast_to(prec[None], (hi - lo, M, P, P)).copy()
-        lam[:, :, idx, idx] += (sld[:, lo:hi] / tau[:, None]).T[:, None, :]
-        sigma = _inv_small(lam)                                  # [n,M,P,P]
-        probs = np.einsum('pi,oi,kpo->ik', 1.6 * f, 1.6 * f, prec)
-        probs += np.einsum('kpq,ikqp->ik', prec, sigma)
-        probs -= log_det
-        probs = np.exp(-0.5 * (probs - probs.min(axis=1, keepdims=True)))
-        delta = np.maximum(probs / probs.sum(axis=1, keepdims=True), EPSILON)
-        ann = annot[lo:hi]
-        for a in range(num_annotations):
-            sums[a] += delta[ann == a].sum(axis=0)
-        avg = np.einsum('ikpq,ik->ipq', sigma, delta)
-        nat = np.einsum('pi,iqp->qi', f, np.linalg.inv(avg))
-        vi_mu[:, :, lo:hi] = np.einsum('ikqp,pi->kqi', sigma, nat)
-    return vi_mu, sums
 
 
 def initial_hyper(delta_sums):
@@ -163,6 +130,7 @@ class SweepDriver:
         if not hasattr(self, 'error_scaling'):
             self.error_scaling = np.ones(num_pops)
         self._nat_table = None
+        self._given = None          # evaluation at a caller-supplied vi_delta (see _upload)
         self._want_diff = False
         self.engine.set_annotation_counts(self.annotation_counts)
         self._last_diff = None      # convergence statistics fetched together with an evaluation
@@ -182,14 +150,28 @@ class SweepDriver:
         self.num_its_run = 0
 
     def start_from(self, vi_mu_local, hyper):
-        """Make (vi_mu of this shard, hyper_delta) the current state and evaluate it."""
+        """Make (vi_mu of this shard, hyper_delta) the current state and evaluate it.
+        vi_mu_local = None: the device already holds vi_mu (engine.init_state)."""
         self._pending = None
+        self._given = None
         self.engine.set_tau(self.error_scaling)
         self._set_hyper(hyper)
-        self.engine.set_mu(vi_mu_local)
+        if vi_mu_local is not None:
+            self.engine.set_mu(vi_mu_local)
         obj, totals = self._evaluate()
         self._accept(False, obj, totals)
         return self._params()
+
+    def initialize_from(self, fake_mu_local):
+        """_initialize from the jittered ridge start of this shard's SNPs [P, N_local]: the
+        per-SNP part (heuristic responsibilities, vi_mu; variational_inference.py:658-692) runs
+        on the device and leaves vi_mu there -- no [M,P,N] array on the host -- and only the
+        [A,M] responsibility sums come back for hyper_delta (:667-674)."""
+        self.engine.set_tau(self.error_scaling)
+        sums = self.engine.init_state(fake_mu_local)
+        hyper = initial_hyper(self.comm.allreduce(sums).reshape(self.num_annotations,
+                                                                 self.num_mix))
+        return self.start_from(None, hyper)
 
     # ------------------------------------------------------------------ device plumbing
     def _objective_from(self, t):
@@ -282,15 +264,64 @@ class SweepDriver:
         self._install_hyper(hyper)
 
     def _upload(self, params):
-        """Make `params` the current device state and evaluate it."""
+        """Make `params` the current device state and evaluate it.
+
+        The device keeps vi_delta implicit -- it is the fixed point _nat_to_not_vi_delta(vi_mu,
+        hyper_delta, error_scaling) (variational_inference.py:632-641), which is what every state
+        the reference's own loop produces carries.  A vi_delta handed in from outside is checked
+        against it: if it differs, the point (vi_mu, that vi_delta, hyper_delta) is evaluated as
+        given and kept in self._given for elbo() / real_posterior_*(), which the reference defines
+        on whatever they are handed (:412-417, 740-751)."""
         if isinstance(params, DeviceParams) and params._owner is self \
                 and params._version == self._version:
+            self._given = None
             return
-        vi_mu, _, hyper = params[0], params[1], params[2]
+        vi_mu, hyper = params[0], params[2]
         self.start_from(self._local_part(np.asarray(vi_mu)), hyper)
+        # a DeviceParams' vi_delta was derived by the device itself: nothing to check (and
+        # indexing it would download [N, M])
+        delta = None if isinstance(params, DeviceParams) else params[1]
+        if delta is not None:
+            self._check_given_delta(np.asarray(delta, dtype=np.float64))
+
+    GIVEN_DELTA_ATOL = 1e-9     # on entries of vi_delta, which lie in [1e-100, 1]
+
+    def _check_given_delta(self, vi_delta):
+        P = self.num_pops
+        if vi_delta.shape != (self._num_snps_global(), self.num_mix):
+            raise ValueError('vi_delta has the wrong shape.')
+        out = self.engine.eval_given_delta(self._local_rows(vi_delta))
+        nt = 3 * P + 2
+        if self.comm.active:
+            self.comm.allreduce_inplace(out[:nt])
+            self.comm.allreduce_inplace(out[nt:], op='max')
+        host = out.cpu().numpy()
+        if not host[nt] > self.GIVEN_DELTA_ATOL:        # consistent (NaN counts as inconsistent)
+            return
+        mean, var = self.engine.get_trial_moments()
+        self._given = {'objective': self._objective_from(host[:nt]), 'mean': mean, 'var': var,
+                       'max_dev': float(host[nt])}
+
+    def _require_fixed_point(self, what):
+        """Entry points that CONTINUE from a state (sweeps, checkpoints) can only start from the
+        fixed-point vi_delta; say so when the one handed in was something else."""
+        if getattr(self, '_given', None) is not None:
+            dev = self._given['max_dev']
+            self._given = None
+            logging.warning('%s: the vi_delta provided differs from the coordinate-ascent fixed '
+                            'point of (vi_mu, hyper_delta, error_scaling) by up to %.3e; the '
+                            'device state keeps vi_delta implicit, so the fit continues from the '
+                            'fixed point (the reference would replace it at its first update).',
+                            what, dev)
 
     def _local_part(self, vi_mu_global):
         return vi_mu_global
+
+    def _local_rows(self, vi_delta_global):
+        return vi_delta_global
+
+    def _num_snps_global(self):
+        return self.engine.N
 
     def _params(self):
         return DeviceParams(self, self._version, self._hyper)
@@ -424,6 +455,7 @@ class SweepDriver:
         if hasattr(self.engine, 'refresh_stream'):
             self.engine.refresh_stream()
         self._upload(params)
+        self._require_fixed_point('_optimize_step')
         # one check per sweep instead of one per message (each costs ~1.3 us even when disabled,
         # on the path between a decision and the next launch)
         self._log_info = logging.getLogger().isEnabledFor(logging.INFO)
@@ -476,6 +508,7 @@ class SweepDriver:
                                 'is okay, but we will have to assume that the error scalings '
                                 'are 1.')
             self._upload(loaded)
+            self._require_fixed_point('optimize(loaded_checkpoint)')
             params = self._params()
         converged = False
         elbo = self._objective
@@ -622,9 +655,11 @@ class MultiPopVI(SweepDriver):
         mine = self._plan[self.comm.rank]
         self._snps = mine['snps']
         n_loc = len(self._snps)
-        if n_loc == 0:
-            raise ValueError('rank %d received no SNPs: fewer LD components than GPUs'
-                             % self.comm.rank)
+        empty = [r for r, part in enumerate(self._plan) if len(part['snps']) == 0]
+        if empty:
+            # every rank computes the same plan, so every rank raises here, before any collective
+            raise ValueError('rank(s) %s would receive no SNPs: fewer independent LD components '
+                             'than GPUs (%d)' % (empty, self.comm.world))
         if _engine_factory is None:
             from .engine import HipEngine
             _engine_factory = HipEngine
@@ -697,6 +732,12 @@ class MultiPopVI(SweepDriver):
     def _local_part(self, vi_mu_global):
         return vi_mu_global[:, :, self._snps]
 
+    def _local_rows(self, vi_delta_global):
+        return vi_delta_global[self._snps]
+
+    def _num_snps_global(self):
+        return self.num_loci
+
     def _download(self, which):
         if which == 'vi_mu':
             return self.comm.gather_snps(self.engine.get_mu(), self._snps, self.num_loci)
@@ -751,13 +792,16 @@ class MultiPopVI(SweepDriver):
 
     # ------------------------------------------------------------------ public API
     def elbo(self, params):
-        """ELBO of `params` (variational_inference.py:412-417)."""
+        """ELBO of `params` (variational_inference.py:412-417), at the vi_delta given."""
         self._upload(params)
-        return self._objective
+        return self._objective if self._given is None else self._given['objective']
 
     def _moments(self, params):
         self._upload(params)
-        mean, var = self.engine.get_moments()
+        if self._given is not None:
+            mean, var = self._given['mean'], self._given['var']
+        else:
+            mean, var = self.engine.get_moments()
         return (self.comm.gather_snps(mean, self._snps, self.num_loci),
                 self.comm.gather_snps(var, self._snps, self.num_loci))
 
@@ -791,13 +835,9 @@ class MultiPopVI(SweepDriver):
         fake_mu[missing] = fill[missing]
         fake_mu[np.isnan(fake_mu)] = 0.
 
-        loc = self._snps
-        vi_mu, sums = initial_vi_mu(fake_mu[:, loc], self.scaled_ld_diags[:, loc],
-                                    self.error_scaling, self.mixture_prec[:, :, :, 0],
-                                    self.log_det, self.annotations[loc], self.num_annotations)
-        hyper = initial_hyper(self.comm.allreduce_np(sums))
-        return self.start_from(vi_mu, hyper)
+        return self.initialize_from(fake_mu[:, self._snps])
 
     def _set_state(self, params):
         self._upload(params)
+        self._require_fixed_point('_set_state')
 
