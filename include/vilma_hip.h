@@ -147,6 +147,14 @@ int vilma_get_moments(vilma_ctx *ctx, double *mean, double *var);
  * _beta_KL (variational_inference.py:412-417, 452-470, 873-885). */
 int vilma_eval(vilma_ctx *ctx, void *stream, double *totals_dev);
 
+/* vilma_eval with the convergence statistics of vilma_mean_diff fused into its per-SNP pass: the
+ * posterior means of the point being evaluated are compared with the snapshot and become the
+ * snapshot.  For evaluations the caller accepts unconditionally (the one after the M-step,
+ * variational_inference.py:849-858 followed by :374-382): saves a pass over [P*N] and a stream
+ * hop per sweep.  The caller must vilma_accept(ctx, 0) this evaluation. */
+int vilma_eval_diff(vilma_ctx *ctx, void *stream, double *totals_dev, double *out_sum3_dev,
+                    double *out_max3_dev);
+
 /* The same sums at (current vi_mu, a vi_delta SUPPLIED by the caller, current hyper/tau), for
  * callers of elbo(params) / real_posterior_mean(vi_mu, vi_delta, hyper_delta) that pass a vi_delta
  * which is not the fixed point of (vi_mu, hyper_delta, error_scaling) -- the reference evaluates

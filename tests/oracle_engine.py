@@ -170,9 +170,11 @@ class OracleEngine:
         return np.copy(self.given_state['mean']), np.copy(self.given_state['var'])
 
     # ---- evaluations
-    def eval(self):
+    def eval(self, diff=False):
         self.mu_trial = None
         self.trial_state, totals = self._moments(self.mu, self._delta(self.mu))
+        if diff:
+            self._diff_against_snapshot(self.trial_state['mean'])
         return totals
 
     def trial(self, step):
@@ -203,7 +205,10 @@ class OracleEngine:
         self.snap = self.cur['mean'] * self.scal
 
     def mean_diff(self):
-        new = self.cur['mean'] * self.scal
+        return self._diff_against_snapshot(self.cur['mean'])
+
+    def _diff_against_snapshot(self, mean):
+        new = mean * self.scal
         old = self.snap
         df = np.abs(new - old)
         out = np.array([np.sum(df > 1e-6 + 1e-6 * np.abs(old)), df.sum(), (df ** 2).sum(),

@@ -72,6 +72,7 @@ def load():
         'vilma_get_delta': (C.c_int, [vp, vp]),
         'vilma_get_moments': (C.c_int, [vp, vp, vp]),
         'vilma_eval': (C.c_int, [vp, vp, vp]),
+        'vilma_eval_diff': (C.c_int, [vp, vp, vp, vp, vp]),
         'vilma_eval_given_delta': (C.c_int, [vp, vp, vp, vp]),
         'vilma_get_trial_moments': (C.c_int, [vp, vp, vp]),
         'vilma_init_state': (C.c_int, [vp, vp, vp, vp]),

@@ -334,6 +334,7 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
     a.pool_cur = c->pool[cur]; a.m_cur = c->m[cur];
     a.pool_out = c->pool[tr]; a.m_out = c->m[tr]; a.v_out = c->v[tr]; a.lse_out = c->lse[tr];
     a.partials = c->snp_partials;
+    a.scal = c->scal; a.snapshot = c->snapshot; a.diff = 0;
     a.step = step;
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
 }
@@ -362,12 +363,14 @@ void side_end(vilma_ctx *c, hipStream_t s, hipStream_t used) {
     (void)hipStreamWaitEvent(s, c->ev_side, 0);
 }
 
-int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *totals_dev) {
+int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *totals_dev,
+             double *dsum_dev = nullptr, double *dmax_dev = nullptr) {
     if (ensure_ready(c)) return 1;
     if (blend && !c->have_moments)
         return fail(c, "vilma_trial_beta needs an accepted evaluation of the current state");
     SnpKernelArgs a;
     fill_snp_args(c, a, step);
+    a.diff = (!blend && dsum_dev && dmax_dev) ? 1 : 0;
     launch_snp_pass(a, blend, s);
     if (c->overlap && c->ev_snp) {
         (void)hipEventRecord(c->ev_snp, s);
@@ -375,7 +378,7 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     }
     run_ld(c, s, c->pool[1 - c->mom_cur], -1);
     launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start.data(),
-                    totals_dev, s);
+                    totals_dev, a.diff ? dsum_dev : nullptr, a.diff ? dmax_dev : nullptr, s);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -419,7 +422,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         rc |= dev_alloc(c, &c->lse[s], N);
     }
     rc |= dev_alloc(c, &c->snapshot, PN);
-    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * P + 2));
+    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * P + 2 + 6));
     // per-wave rows plus the scratch rows of every pass of the column reduction (exact)
     rc |= dev_alloc(c, &c->delta_partials,
                     std::max(delta_partial_rows(N), init_partial_rows(N)) * A * M);
@@ -701,6 +704,14 @@ int vilma_eval(vilma_ctx *c, void *stream, double *totals_dev) {
     return evaluate(c, (hipStream_t)stream, false, 0.0, totals_dev);
 }
 
+int vilma_eval_diff(vilma_ctx *c, void *stream, double *totals_dev, double *out_sum3_dev,
+                    double *out_max3_dev) {
+    if (!c) return 1;
+    if (!out_sum3_dev || !out_max3_dev) return fail(c, "vilma_eval_diff needs both outputs");
+    c->trial_tainted = false;
+    return evaluate(c, (hipStream_t)stream, false, 0.0, totals_dev, out_sum3_dev, out_max3_dev);
+}
+
 int vilma_eval_given_delta(vilma_ctx *c, void *stream, const double *delta_km_dev,
                            double *totals_dev) {
     if (!c) return 1;
@@ -714,7 +725,7 @@ int vilma_eval_given_delta(vilma_ctx *c, void *stream, const double *delta_km_de
                            totals_dev + VILMA_NTOTALS(c->P), s);
     run_ld(c, s, c->pool[1 - c->mom_cur], -1);
     launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start.data(),
-                    totals_dev, s);
+                    totals_dev, nullptr, nullptr, s);
     HIPCHK(c, hipGetLastError());
     c->trial_tainted = true;        // these moments belong to no state the line search may accept
     return 0;

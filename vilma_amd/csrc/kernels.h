@@ -58,7 +58,10 @@ struct SnpKernelArgs {
     double *pool_out;         // trial pool (x_ld written)
     double *m_out, *v_out;    // [P][N]
     double *lse_out;          // [N]
-    double *partials;         // [2P+2][grid] (column-major: finalize reads columns)
+    double *partials;         // [2P+2 (+6)][grid] (column-major: finalize reads columns)
+    const double *scal;       // [P][N] scalings            } used when diff != 0 (plain
+    double *snapshot;         // [P][N] real_posterior_mean } evaluations only)
+    int32_t diff;             // fuse the convergence statistics into this evaluation
     double step;
     TauArg tau;
 };
@@ -74,8 +77,11 @@ void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
                            const double *scratch, double *dot_partials, hipStream_t s);
 
 // totals[0..2P) and [3P..3P+3) from the per-SNP partials, totals[2P..3P) from the matvec dots
+// with dsum/dmax non-null also the six fused convergence statistics (columns 2P+2..2P+7 of the
+// per-SNP partials): three sums -> dsum[3], three maxima -> dmax[3]
 void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
-                     const int32_t *dot_start /*[P+1] host*/, double *totals, hipStream_t s);
+                     const int32_t *dot_start /*[P+1] host*/, double *totals, double *dsum,
+                     double *dmax, hipStream_t s);
 
 struct DeltaArgs {
     int32_t N, M, A, P;

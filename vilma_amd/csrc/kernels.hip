@@ -478,7 +478,7 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 template <int P, bool BLEND, bool ONE_ANNOT>
 __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
     constexpr int NT = 2 * P + 2;
-    __shared__ double red[SNP_THREADS / 64][NT];
+    __shared__ double red[SNP_THREADS / 64][NT < 6 ? 6 : NT];
     const int N = a.N, M = a.M;
     const int64_t N64 = N;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -631,11 +631,12 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     const bool owner = live;
     const double invZ = 1.0 / Z;
     const double lse = mx + log(Z);
-    double part[NT];
+    double part[NT], mpost[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const double m = Sm[p] * invZ;
         const double v = S2[p] * invZ - m * m;
+        mpost[p] = m;
         if (owner) {
             a.m_out[p * N64 + i] = m;
             a.v_out[p * N64 + i] = v;
@@ -659,6 +660,43 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
 #pragma unroll
         for (int ww = 1; ww < SNP_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
         a.partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+    }
+    // Convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
+    // fused into an evaluation the caller accepts unconditionally (the one after the M-step):
+    // the new posterior means are compared with the snapshot and become the snapshot, so no
+    // separate pass over [P][N] (mean_diff_kernel) and no second stream are needed per sweep.
+    if (!BLEND && a.diff) {                       // kernel-uniform
+        double dv[6] = {0, 0, 0, 0, 0, 0};
+        if (owner) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const double nw = mpost[p] * a.scal[p * N64 + i];
+                const double od = a.snapshot[p * N64 + i];
+                const double df = fabs(nw - od);
+                dv[0] += (df <= 1e-6 + 1e-6 * fabs(od)) ? 0.0 : 1.0;
+                dv[1] += df;
+                dv[2] += df * df;
+                dv[3] = fmax(dv[3], fabs(nw));
+                dv[4] = fmax(dv[4], df);
+                dv[5] = fmax(dv[5], fabs((nw - od) / (od + 1e-100)));
+                a.snapshot[p * N64 + i] = nw;
+            }
+        }
+        __syncthreads();                          // red[] is being reused
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double s = c < 3 ? wave_sum(dv[c]) : wave_max(dv[c]);
+            if (lane == 0) red[w][c] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const int c = threadIdx.x;
+            double s = red[0][c];
+#pragma unroll
+            for (int ww = 1; ww < SNP_THREADS / 64; ++ww)
+                s = c < 3 ? s + red[ww][c] : fmax(s, red[ww][c]);
+            a.partials[(int64_t)(NT + c) * gridDim.x + blockIdx.x] = s;
+        }
     }
 }
 
@@ -1215,43 +1253,61 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
                                                         int snp_rows, int P,
                                                         const double *__restrict__ dot_partials,
                                                         const DotStart dot_start,
-                                                        double *__restrict__ totals) {
+                                                        double *__restrict__ totals,
+                                                        double *__restrict__ dsum,
+                                                        double *__restrict__ dmax) {
     __shared__ double sh[4];
     const int NT = 2 * P + 2;
     const int c = blockIdx.x;
     const double *src;
-    int n, out;
+    double *dst;
+    int n;
+    bool is_max = false;
     if (c < NT) {
         src = snp_partials + (int64_t)c * snp_rows;
         n = snp_rows;
-        out = c < 2 * P ? c : 3 * P + (c - 2 * P);
-    } else {
+        dst = totals + (c < 2 * P ? c : 3 * P + (c - 2 * P));
+    } else if (c < NT + P) {
         const int p = c - NT;
         src = dot_partials + dot_start.v[p];
         n = dot_start.v[p + 1] - dot_start.v[p];
-        out = 2 * P + p;
+        dst = totals + 2 * P + p;
+    } else {                                    // the six convergence statistics (fused diff)
+        const int q = c - NT - P;
+        src = snp_partials + (int64_t)(NT + q) * snp_rows;
+        n = snp_rows;
+        is_max = q >= 3;
+        dst = q < 3 ? dsum + q : dmax + (q - 3);
     }
-    double acc = 0.0;
+    double acc = 0.0;                           // every maximum here is of non-negative numbers
     for (int r0 = threadIdx.x; r0 < n; r0 += 8 * 256) {
         double t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = src[min(r0 + u * 256, n - 1)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = (r0 + u * 256 < n) ? t[u] : 0.0;
-        acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        if (is_max)
+            acc = fmax(acc, fmax(fmax(fmax(t[0], t[1]), fmax(t[2], t[3])),
+                                 fmax(fmax(t[4], t[5]), fmax(t[6], t[7]))));
+        else
+            acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
-    acc = wave_sum(acc);
+    acc = is_max ? wave_max(acc) : wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) totals[out] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0)
+        *dst = is_max ? fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]))
+                      : (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
-                     const int32_t *dot_start, double *totals, hipStream_t s) {
+                     const int32_t *dot_start, double *totals, double *dsum, double *dmax,
+                     hipStream_t s) {
     DotStart ds;
     for (int p = 0; p <= VILMA_MAX_P; ++p) ds.v[p] = p <= P ? dot_start[p] : 0;
-    hipLaunchKernelGGL(finalize_kernel, dim3(3 * P + 2), dim3(256), 0, s, snp_partials, snp_rows, P,
-                       dot_partials, ds, totals);
+    const int extra = (dsum != nullptr && dmax != nullptr) ? 6 : 0;
+    hipLaunchKernelGGL(finalize_kernel, dim3(3 * P + 2 + extra), dim3(256), 0, s, snp_partials,
+                       snp_rows, P, dot_partials, ds, totals, dsum, dmax);
 }
 
 // --------------------------------------------------------------------------------------------

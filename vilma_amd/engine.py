@@ -242,8 +242,15 @@ class HipEngine:
         return mean, var
 
     # ------------------------------------------------------------------ evaluations
-    def eval(self):
-        self._check(self.lib.vilma_eval(self.ctx, self._stream_handle, self._p['totals']))
+    def eval(self, diff=False):
+        """Evaluate the current vi_mu; with diff=True the convergence statistics against the
+        snapshot ride in the same pass (results in the dsum / dmax slices) and the evaluated
+        means become the snapshot -- only for evaluations accepted unconditionally."""
+        if diff:
+            self._check(self.lib.vilma_eval_diff(self.ctx, self._stream_handle, self._p['totals'],
+                                                 self._p['dsum'], self._p['dmax']))
+        else:
+            self._check(self.lib.vilma_eval(self.ctx, self._stream_handle, self._p['totals']))
         return self._totals
 
     def trial(self, step):

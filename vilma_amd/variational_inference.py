@@ -374,10 +374,8 @@ class SweepDriver:
                 self.comm.allreduce_inplace(sums)
         # otherwise the sums of the accepted trial are still in the result vector (all-reduced)
         eng.mstep()
-        eng.eval()
+        eng.eval(diff=with_diff)        # the convergence statistics ride in the same pass
         eng.accept(False)
-        if with_diff:
-            eng.mean_diff()
         lo = L.dsum.start if with_diff else L.totals.start
         if next_step is not None:
             self._launch_trial(next_step)
