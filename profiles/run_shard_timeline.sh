@@ -21,6 +21,7 @@ VILMA_BENCH_FORCE_RCCL=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-for
     python3 "$ROOT/bench.py" --emulate-shard $K --steps 20 --warmup 3 --no-cpu-baseline \
     > "$OUT/${PFX}_shard${K}_bench_under_rocprof.json" 2>/dev/null || exit 1
 python3 "$ROOT/profiles/timeline_gaps.py" /tmp/rp_shard > "$OUT/${PFX}_shard${K}_timeline.txt" 2>&1
+python3 "$ROOT/profiles/sweep_sequence.py" /tmp/rp_shard 70 > "$OUT/${PFX}_shard${K}_sequence.txt" 2>&1
 rm -rf /tmp/rp_shard
 cd "$ROOT"
 python3 - "$OUT/${PFX}_shard${K}_bench.json" "$OUT/${PFX}_shard${K}_bench_rccl.json" <<'PY'
@@ -30,3 +31,4 @@ for f in sys.argv[1:]:
     print(f.split('/')[-1], 'ms_per_step %.4f' % d['ms_per_step'], 'ld avg ms %.4f' % d['roofline']['avg_launch_ms'])
 PY
 cat "$OUT/${PFX}_shard${K}_timeline.txt"
+cat "$OUT/${PFX}_shard${K}_sequence.txt"

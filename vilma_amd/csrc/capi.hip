@@ -58,6 +58,11 @@ inline int64_t sym_panel_elems(int n, int J) {
     return (int64_t)(n - 128 * J) * pad_ld(slab_width(n, J));
 }
 inline int n_slabs(int n) { return (n + 127) / 128; }
+// scratch of the symmetric product for one block: row sums S[slab][n] and the column-sum chunks
+// C[slab][chunk][128] (laid out for ceil(n / chunk_rows) chunks per slab)
+inline int32_t sym_scratch_elems(int n, int chunk_rows) {
+    return n_slabs(n) * (n + ((n + chunk_rows - 1) / chunk_rows) * 128);
+}
 
 }  // namespace
 
@@ -92,6 +97,8 @@ struct vilma_ctx {
     double *pinned = nullptr;       // host staging for vilma_fetch
     int64_t pinned_elems = 0;
     bool ready = false;
+    // rows per work item of the symmetric product (multiple of 32); VILMA_LD_CHUNK_ROWS overrides
+    int chunk_rows = 512;
 
     // Work that depends only on the per-SNP pass of an evaluation (responsibility sums of the
     // trial state, convergence statistics) runs on `side`, concurrently with that evaluation's LD
@@ -164,21 +171,29 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
         if (b.form == 0) {
             int64_t off = b.off_a;
             const int ns = n_slabs(b.n);
+            const int CH = c->chunk_rows;
+            const int nch_max = (b.n + CH - 1) / CH;
+            const int32_t c_base = s_off + ns * b.n;         // C[slab][chunk][128] behind S[slab][n]
             for (int J = 0; J < ns; ++J) {
-                SymItem it;
-                it.a = co.store + off; it.rows = b.n - 128 * J; it.w = slab_width(b.n, J);
-                it.ld = pad_ld(it.w); it.j0 = 128 * J; it.x_off = pN + b.start;
-                it.s_off = s_off + J * b.n; it.n = b.n; it.pad = 0;
-                H.sym.push_back(it);
+                const int rows = b.n - 128 * J, wJ = slab_width(b.n, J), ldJ = pad_ld(wJ);
+                for (int r0 = 0, ch = 0; r0 < rows; r0 += CH, ++ch) {
+                    SymItem it;
+                    it.a = co.store + off + (int64_t)r0 * ldJ;
+                    it.rows = std::min(CH, rows - r0); it.w = wJ; it.ld = ldJ; it.j0 = 128 * J;
+                    it.x_off = pN + b.start; it.s_off = s_off + J * b.n; it.r0 = r0;
+                    it.c_off = c_base + (J * nch_max + ch) * 128;
+                    H.sym.push_back(it);
+                }
                 off += sym_panel_elems(b.n, J);
             }
             for (int j0 = 0; j0 < b.n; j0 += 256) {         // one workgroup per 256 columns
                 SymCombItem cb;
                 cb.n = b.n; cb.s_base = s_off; cb.y_off = PN + pN + b.start;
                 cb.dot_off = pN + b.start; cb.dot_slot = slot++; cb.j0 = j0;
+                cb.c_base = c_base; cb.nch_max = nch_max; cb.chunk_rows = CH;
                 H.comb.push_back(cb);
             }
-            s_off += ns * b.n;
+            s_off += sym_scratch_elems(b.n, CH);
         } else {
             for (int c0 = 0; c0 < b.r; c0 += 128) {        // t = U^T x
                 LdItem it;
@@ -209,7 +224,7 @@ void sort_items(HostItems &H) {
                (int64_t)y.rows * std::min(128, y.ncols - y.col0);
     });
     std::stable_sort(H.sym.begin(), H.sym.end(), [](const SymItem &x, const SymItem &y) {
-        return (int64_t)x.rows * x.w > (int64_t)y.rows * y.w;
+        return (int64_t)x.rows * x.ld > (int64_t)y.rows * y.ld;
     });
 }
 
@@ -434,6 +449,10 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         return 1;
     }
     c->log_det_host.assign(M, 0.0);
+    if (const char *cr = std::getenv("VILMA_LD_CHUNK_ROWS")) {
+        const int v = std::atoi(cr);
+        if (v >= 128) c->chunk_rows = (v + 31) / 32 * 32;
+    }
     // VILMA_OVERLAP=0 keeps everything on the caller's stream (A/B measurements)
     const char *ov = std::getenv("VILMA_OVERLAP");
     c->overlap = !(ov && ov[0] == '0');
@@ -584,7 +603,7 @@ int vilma_ld_add_dense(vilma_ctx *c, int cohort, int n, const double *R) {
     co.store_used += need;
     co.next_start += n;
     co.alg_bytes += (int64_t)8 * n * n;
-    co.s_used += n_slabs(n) * n;
+    co.s_used += sym_scratch_elems(n, c->chunk_rows);
     return 0;
 }
 

@@ -21,24 +21,32 @@ struct LdItem {
 
 // One work item of the SYMMETRIC dense product: the panel of one block below (and including)
 // the diagonal tile of a 128-column slab, stored contiguously: rows j0..n-1, `ld` doubles each.
+// A panel is cut into chunks of at most `chunk_rows` rows (a multiple of 32), one work item each,
+// so no workgroup streams more than chunk_rows x 1 KiB: on a small shard (an 8-GPU rank holds
+// ~1000 panels for 2048 workgroup slots) the longest panel would otherwise set the kernel time.
 struct SymItem {
-    const double *a;     // panel base (row j0, first column of the slab), 128-byte aligned
-    int32_t rows;        // n - j0
+    const double *a;     // first row of this chunk (row j0 + r0 of the block, first column of the
+                         // slab), 128-byte aligned
+    int32_t rows;        // rows in this chunk
     int32_t ld;          // panel leading dimension (multiple of 16 doubles)
     int32_t w;           // columns in this slab (<= 128)
     int32_t j0;          // first row/column of the slab inside the block
     int32_t x_off;       // pool offset of x[0] of the block
-    int32_t s_off;       // scratch offset of S[slab][0] (n entries per slab)
-    int32_t n;           // block size
-    int32_t pad;
+    int32_t s_off;       // scratch offset of S[slab][0]: row sums, n entries per slab
+    int32_t r0;          // first row of this chunk inside the panel (0: it holds the diagonal tile)
+    int32_t c_off;       // scratch offset of C[slab][chunk][0]: this chunk's 128 column sums
 };
 
-// combine step of the symmetric product for one block: y[j] = sum_{J <= j/128} S[J][j]
+// combine step of the symmetric product for one block:
+//   y[j] = sum_{J < j/128} S[J][j] + sum_{chunks c of slab j/128} C[j/128][c][j%128]
 struct SymCombItem {
     int32_t n;                // block size
     int32_t s_base;           // scratch offset of S[0][0] of the block
     int32_t y_off, dot_off, dot_slot;
     int32_t j0;               // first of the (up to) 256 columns this workgroup combines
+    int32_t c_base;           // scratch offset of C[0][0][0] of the block
+    int32_t nch_max;          // chunks per slab the C region is laid out for: ceil(n / chunk_rows)
+    int32_t chunk_rows;
 };
 
 struct TauArg { double v[VILMA_MAX_P]; };

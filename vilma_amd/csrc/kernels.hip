@@ -280,17 +280,19 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     const bool active = cl < it.w;
     const int rows = it.rows;
     const int64_t ld = it.ld;
-    const double *__restrict__ xrow = xpool + it.x_off + it.j0;     // x of the panel's rows
+    const bool has_diag = it.r0 == 0;                                // chunk 0 holds the diagonal tile
+    const double *__restrict__ xcol = xpool + it.x_off + it.j0;     // x of the slab's columns
+    const double *__restrict__ xrow = xcol + it.r0;                 // x of this chunk's rows
     // x of this lane's two columns (the slab's columns are rows j0.. of the same vector)
-    const double xs0 = active ? xrow[cl] : 0.0;
-    const double xs1 = (cl + 1 < it.w) ? xrow[cl + 1] : 0.0;
+    const double xs0 = active ? xcol[cl] : 0.0;
+    const double xs1 = (cl + 1 < it.w) ? xcol[cl + 1] : 0.0;
     // loads are unconditional within a group (a select around a load makes hipcc branch and wait
     // per element): lanes beyond the slab read column 0 and are neutralised by xs = 0
     const double *ap = it.a + (active ? cl : 0);
-    double *__restrict__ srow = scratch + it.s_off + it.j0;
+    double *__restrict__ srow = scratch + it.s_off + it.j0 + it.r0;
     double acc0 = 0.0, acc1 = 0.0;
     const int ngroups = (rows + CS_ROWS - 1) / CS_ROWS;     // group g belongs to wave g % 4
-    const int ndiag = (it.w + CS_ROWS - 1) / CS_ROWS;       // groups inside the diagonal tile
+    const int ndiag = has_diag ? (it.w + CS_ROWS - 1) / CS_ROWS : 0;   // groups inside the diagonal tile
     const int nfull = rows / CS_ROWS;
     const int64_t gstride = (int64_t)CS_WAVES * CS_ROWS * ld;
     const double *rp = ap + (int64_t)w * CS_ROWS * ld;
@@ -321,12 +323,15 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
         double s = red[0][threadIdx.x];
 #pragma unroll
         for (int ww = 1; ww < CS_WAVES; ++ww) s += red[ww][threadIdx.x];
-        srow[threadIdx.x] = s + rs_diag[threadIdx.x];           // the slab's own (diagonal) entry
+        // this chunk's share of the slab's own entries: its column sums (+ the diagonal tile's
+        // row sums, which belong to the same entries)
+        scratch[it.c_off + threadIdx.x] = has_diag ? s + rs_diag[threadIdx.x] : s;
     }
 }
 
-// y[j] = sum_{J <= slab(j)} S[J][j] for 256 columns of one block per workgroup (slab order = fixed
-// order), with the chunk's y.z partial.  The slab index is wave-uniform; eight loads in flight.
+// y[j] for 256 columns of one block per workgroup: the row sums S[J][j] of the slabs to the left
+// (J < slab(j), slab order) then the column-sum chunks of j's own slab (chunk order) -- a fixed
+// order -- with the chunk's y.z partial.  The slab index is wave-uniform; eight loads in flight.
 __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
     const SymCombItem *__restrict__ items, const double *__restrict__ xpool,
     double *__restrict__ ypool, const double *__restrict__ scratch,
@@ -340,12 +345,21 @@ __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
     const double *sj = scratch + it.s_base + jj;
     const double xj = xpool[it.dot_off + jj];
     double s = 0.0;
-    for (int J = 0; J <= slab; J += 8) {
+    for (int J = 0; J < slab; J += 8) {
         double t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = sj[(int64_t)min(J + u, slab) * it.n];   // no branch
+        for (int u = 0; u < 8; ++u) t[u] = sj[(int64_t)min(J + u, slab - 1) * it.n];   // no branch
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += (J + u <= slab) ? t[u] : 0.0;
+        for (int u = 0; u < 8; ++u) s += (J + u < slab) ? t[u] : 0.0;
+    }
+    const int nch = (it.n - 128 * slab + it.chunk_rows - 1) / it.chunk_rows;
+    const double *cj = scratch + it.c_base + (int64_t)slab * it.nch_max * 128 + (jj & 127);
+    for (int c = 0; c < nch; c += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = cj[(int64_t)min(c + u, nch - 1) * 128];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (c + u < nch) ? t[u] : 0.0;
     }
     if (live) ypool[it.y_off + j] = s;
     double dv = wave_sum(live ? s * xj : 0.0);
