@@ -456,8 +456,16 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     // VILMA_OVERLAP=0 keeps everything on the caller's stream (A/B measurements)
     const char *ov = std::getenv("VILMA_OVERLAP");
     c->overlap = !(ov && ov[0] == '0');
+    // The side stream is created at HIGH priority: HIP maps streams onto a small pool of hardware
+    // queues per priority level, and two streams that land on the same queue serialise.  With
+    // RCCL / torch streams alive in the process that is what happened to a normal-priority side
+    // stream (its kernels ran after the LD product instead of beside it: +40 us per trial on an
+    // 8-GPU shard).  A different priority means a different queue pool, and the short
+    // responsibility kernels get their waves ahead of the long LD stream.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (c->overlap &&
-        (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
          hipEventCreateWithFlags(&c->ev_snp, hipEventDisableTiming) != hipSuccess ||
          hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess)) {
         g_create_error = "cannot create the side stream";
