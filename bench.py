@@ -46,9 +46,9 @@ def parse():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--ld-form', default='auto', choices=['auto', 'dense', 'eig'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-blocks', type=int, default=96,
-                    help='blocks of the workload in the CPU-baseline sample')
-    ap.add_argument('--cpu-sweeps', type=int, default=5)
+    ap.add_argument('--cpu-frac', type=float, default=0.25,
+                    help='fraction of the workload\'s LD blocks in the CPU-baseline sample')
+    ap.add_argument('--cpu-sweeps', type=int, default=2)
     ap.add_argument('--prof-every', type=int, default=0,
                     help='bracket every k-th LD product with HIP events (roofline.avg_launch_ms); '
                          'default: every product on 1 GPU, every 8th on a sharded run, where the '
@@ -59,36 +59,41 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(workload, seed, n_blocks, n_sweeps):
-    """The oracle (oracle/vi.py, reference schedule) on the first `n_blocks` blocks of the same
-    synthetic problem, on this host.  Returns the JSON object."""
+def cpu_baseline(workload, seed, block_frac, n_sweeps):
+    """The oracle (oracle/vi.py: the reference's operation schedule -- two GEMVs per LD block in
+    a serial block loop with threaded BLAS, 5-8 products per sweep, one pass per numerics
+    function) on the first `block_frac` of the blocks of the same synthetic problem, on this
+    host, with the per-SNP passes as compiled C / OpenMP loops over all cores (oracle/
+    numerics_omp.c: what numba `prange` gives the reference).  Returns the JSON object."""
+    from concurrent.futures import ThreadPoolExecutor
     from vilma_amd.synthetic import SyntheticShard, WORKLOADS, ar1_numpy
     from oracle.ldop import EigenBlock, BlockDiagonalLD
     from oracle.vi import MultiPopVIOracle
+    from oracle import native
+    from threadpoolctl import threadpool_limits
     cfg = dict(WORKLOADS[workload])
     full = SyntheticShard(seed=seed, **cfg)
-    n_blocks = min(n_blocks, len(full.sizes_all))
+    n_blocks = max(1, min(len(full.sizes_all), int(round(block_frac * len(full.sizes_all)))))
     sh = SyntheticShard(seed=seed, block_range=(0, n_blocks), **cfg).build(None)
     P = sh.P
-    ld = [BlockDiagonalLD([EigenBlock(ar1_numpy(b.n, b.rho[p]), 1.0) for b in sh.blocks],
-                          perm=sh.perm, missing=sh.missing) for p in range(P)]
-    annotations = np.ones((sh.N, 1))
-    vi = MultiPopVIOracle(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
-                          annotations=annotations, mixture_covs=list(sh.covs), checkpoint=False,
-                          checkpoint_freq=-1, scaled=False, scale_se=False, gwas_N=sh.gwas_N,
-                          init_hg=sh.init_hg, num_its=n_sweeps)
-    # the GPU box gives one GPU's share of the host (16 cores); keep BLAS inside it
+    # the GPU box gives one GPU's share of the host (16 cores); keep BLAS and OpenMP inside it
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     threads = max(1, min(16, avail))
-    from threadpoolctl import threadpool_limits
+    # setup (not timed): eigendecompose the sample's blocks, one LAPACK call per core
+    with threadpool_limits(limits=1), ThreadPoolExecutor(max_workers=threads) as pool:
+        ld = [BlockDiagonalLD(list(pool.map(lambda b: EigenBlock(ar1_numpy(b.n, b.rho[p]), 1.0),
+                                            sh.blocks)), perm=sh.perm, missing=sh.missing)
+              for p in range(P)]
+    annotations = np.ones((sh.N, 1))
+    vi = MultiPopVIOracle(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
+                          annotations=annotations, mixture_covs=list(sh.covs), checkpoint=False,
+                          checkpoint_freq=-1, scaled=False, scale_se=False, gwas_N=sh.gwas_N,
+                          init_hg=sh.init_hg, num_its=n_sweeps)
     cpu_elbos = []
-    # split the timed region into LD products and per-SNP passes: the reference threads its
-    # per-SNP loops (numba prange) while this port's numpy passes run on one core, so the
-    # baseline is also quoted with the per-SNP part divided by the core count (an upper bound
-    # on what a prange-threaded CPU path can reach on this host)
+    # the timed region is split into LD products and per-SNP passes (shares reported)
     ld_seconds = [0.0]
     for op in ld:
         def timed_dot(x, _dot=op.dot):
@@ -97,22 +102,25 @@ def cpu_baseline(workload, seed, n_blocks, n_sweeps):
             ld_seconds[0] += time.perf_counter() - t
             return y
         op.dot = timed_dot
-    with threadpool_limits(limits=threads):
-        np.random.seed(42)
-        params = vi._initialize()
-        elbo = vi.elbo(params)
-        cpu_elbos.append(elbo)
-        L, red = np.ones(5), None
-        params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)       # warm-up sweep
-        cpu_elbos.append(elbo)
-        ld_seconds[0] = 0.0
-        t0 = time.perf_counter()
-        for _ in range(n_sweeps):
-            params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
+    native.enable(threads=threads)
+    try:
+        with threadpool_limits(limits=threads):
+            np.random.seed(42)
+            params = vi._initialize()
+            elbo = vi.elbo(params)
             cpu_elbos.append(elbo)
-        dt = time.perf_counter() - t0
+            L, red = np.ones(5), None
+            params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)   # warm-up sweep
+            cpu_elbos.append(elbo)
+            ld_seconds[0] = 0.0
+            t0 = time.perf_counter()
+            for _ in range(n_sweeps):
+                params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
+                cpu_elbos.append(elbo)
+            dt = time.perf_counter() - t0
+    finally:
+        native.disable()
     t_ld = min(ld_seconds[0], dt)
-    dt_threaded = t_ld + (dt - t_ld) / threads
     frac = sh.N / full.N_global
     parity = None
     try:
@@ -149,13 +157,16 @@ def cpu_baseline(workload, seed, n_blocks, n_sweeps):
         'value': (n_sweeps / dt) * frac, 'unit': 'sweeps/s', 'cores': int(threads),
         'kind': 'port', 'parity_vs_cpu': parity,
         'ld_product_share_of_cpu_time': t_ld / dt,
-        'value_if_per_snp_passes_scaled_over_cores': (n_sweeps / dt_threaded) * frac,
-        'sample': ('oracle (numpy restatement of the reference schedule; BLAS gemv threaded on '
-                   '%d threads, per-SNP passes single-threaded) on the first %d of %d blocks '
-                   '(%d of %d SNPs, all %d cohorts, M=%d): %d sweeps in %.2f s after 1 warm-up; '
-                   'value = measured sample sweeps/s x SNP fraction %.5f'
-                   % (threads, n_blocks, len(full.sizes_all), sh.N, full.N_global, P, sh.M,
-                      n_sweeps, dt, frac)),
+        'sample_fraction_of_snps': frac,
+        'sample': ('oracle with the reference\'s schedule (per sweep 5-8 LD products per cohort as '
+                   'two BLAS GEMVs per block in a serial block loop, one pass per numerics '
+                   'function; per-SNP passes as compiled C/OpenMP loops) on %d threads, on the '
+                   'first %d of %d blocks (%d of %d SNPs = %.1f %%, all %d cohorts, M=%d): %d '
+                   'sweeps in %.2f s after 1 warm-up, %.0f %% of it in LD products; value = '
+                   'measured sample sweeps/s x SNP fraction (per-sweep cost is linear in SNPs '
+                   'for a fixed block-size law)'
+                   % (threads, n_blocks, len(full.sizes_all), sh.N, full.N_global, 100 * frac, P,
+                      sh.M, n_sweeps, dt, 100 * t_ld / dt)),
     }
 
 
@@ -354,7 +365,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, args.cpu_blocks,
+            out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, args.cpu_frac,
                                                args.cpu_sweeps)
         except Exception as exc:      # the GPU number stands on its own
             out['cpu_baseline'] = {'value': None, 'unit': 'sweeps/s', 'cores': 0,

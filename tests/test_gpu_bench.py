@@ -23,7 +23,7 @@ def _last_json(stdout):
 
 def test_bench_json_contract_one_gpu():
     out = subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '4',
-                          '--warmup', '1', '--cpu-blocks', '6', '--cpu-sweeps', '2'],
+                          '--warmup', '1', '--cpu-frac', '0.5', '--cpu-sweeps', '2'],
                          cwd=ROOT, capture_output=True, text=True, check=True)
     d = _last_json(out.stdout)
     for key in TOP + ('cpu_baseline',):
@@ -38,6 +38,8 @@ def test_bench_json_contract_one_gpu():
         assert key in r, key
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert r['launches'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert 0 < r['frac'] <= 1 and 'traffic_source' in r and 'basis' in r
+    assert r['algorithmic_bytes_per_launch'] < r['survey_8d_bytes_per_launch']
     c = d['cpu_baseline']
     for key in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert key in c, key
