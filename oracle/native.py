@@ -28,7 +28,7 @@ _ip = C.POINTER(C.c_int64)
 def build(force=False):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
         return LIB
-    subprocess.check_call(['gcc', '-O3', '-march=native', '-fopenmp', '-fPIC', '-shared',
+    subprocess.check_call(['gcc', '-O3', '-fopenmp', '-fPIC', '-shared',
                            '-o', LIB, SRC, '-lm'])
     return LIB
 
