@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Load-time linear algebra on the GPU through torch.linalg (rocSOLVER / rocBLAS), per block of an
+equal-size batch: Cholesky, triangular inverse (trsm against I), eigh, and the GEMMs of the
+reconstruction -- what a device-side LD loader would be built from.
+    python3 profiles/microbench_linalg.py [--sizes 200,588,1200,2431] [--batches 1,8,32]"""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+
+
+def ar1(n, rho):
+    i = np.arange(n)
+    return rho ** np.abs(i[:, None] - i[None, :])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--sizes', default='200,588,1200,2431')
+    ap.add_argument('--batches', default='1,8,32')
+    args = ap.parse_args()
+    import torch
+    dev = torch.device('cuda', 0)
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    for n in [int(v) for v in args.sizes.split(',')]:
+        for B in [int(v) for v in args.batches.split(',')]:
+            if B * n * n * 8 * 6 > 40e9:
+                continue
+            A = torch.as_tensor(np.stack([ar1(n, 0.5 + 0.4 * k / B) for k in range(B)]), device=dev)
+            eye = torch.eye(n, dtype=torch.float64, device=dev).expand(B, n, n).contiguous()
+            out = {'n': n, 'batch': B}
+            out['cholesky_ms'] = 1e3 * timed(lambda: torch.linalg.cholesky_ex(A)) / B
+            L = torch.linalg.cholesky_ex(A)[0]
+            out['trsm_inv_ms'] = 1e3 * timed(lambda: torch.linalg.solve_triangular(L, eye, upper=False)) / B
+            out['chol_solve_1rhs_ms'] = 1e3 * timed(lambda: torch.cholesky_solve(eye[:, :, :1], L)) / B
+            out['eigh_ms'] = 1e3 * timed(lambda: torch.linalg.eigh(A), reps=2) / B
+            w, Q = torch.linalg.eigh(A)
+            out['recon_gemm_ms'] = 1e3 * timed(lambda: (Q * w[:, None, :]) @ Q.transpose(1, 2)) / B
+            out['gemv_pair_ms'] = 1e3 * timed(lambda: Q @ (Q.transpose(1, 2) @ eye[:, :, :1])) / B
+            print(json.dumps(out))
+            sys.stdout.flush()
+
+
+if __name__ == '__main__':
+    main()

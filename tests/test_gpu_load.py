@@ -1,0 +1,112 @@
+"""GPU tests of the load-time path: blocks stream host -> device as they
+are decomposed; diag(R), R^+ z, chi, R R^+ z per block and the ridge start come from the device
+and must equal what the reference's per-block host formulas give (oracle/ldop.py,
+matrix_structures.py:159-196, 349-387, 426-447)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden, oracle_from_traj, product_vi_from_traj, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _rank_deficient(rng, n, r):
+    """A correlation-like PSD matrix of rank r < n (what a reference panel with few samples gives)."""
+    f = rng.normal(size=(n, r))
+    c = f @ f.T
+    d = 1.0 / np.sqrt(np.diag(c))
+    return c * np.outer(d, d)
+
+
+@pytest.mark.parametrize('form', ['auto', 'dense', 'eig'])
+def test_device_loader_matches_host_formulas(form):
+    from oracle.ldop import EigenBlock, BlockDiagonalLD
+    from vilma_amd.engine import HipEngine
+    from vilma_amd.matrix_structures import LowRankMatrix, BlockDiagonalMatrix
+    from vilma_amd import ld_device
+    rng = np.random.default_rng(11)
+    sizes = [1, 40, 257, 130, 600, 2]
+    mats = [np.ones((1, 1)), _rank_deficient(rng, 40, 12), _rank_deficient(rng, 257, 100),
+            0.7 ** np.abs(np.subtract.outer(np.arange(130), np.arange(130))),
+            _rank_deficient(rng, 600, 480), np.array([[1.0, 0.3], [0.3, 1.0]])]
+    n_ld = sum(sizes)
+    N = n_ld + 7
+    order = rng.permutation(N)
+    perm = np.concatenate([order[:n_ld], np.sort(order[n_ld:])]).astype(np.int64)
+    for t in (1.0, 0.6):
+        made = []
+
+        def thunk(X):
+            def make():
+                made.append(X.shape[0])
+                return X
+            return make
+        ld = BlockDiagonalMatrix([LowRankMatrix.deferred(thunk(X), X.shape[0], t) for X in mats],
+                                 perm=perm, missing=perm[n_ld:])
+        old = BlockDiagonalLD([EigenBlock(X, t) for X in mats], perm=perm, missing=perm[n_ld:])
+        z = rng.normal(size=N)
+        z[perm[n_ld:]] = 0.0
+        eng = HipEngine(1, N, 2, 1)
+        out = ld_device.stream_cohort(eng, 0, ld, form, z[perm[:n_ld]], workers=3)
+        assert sorted(made) == sorted(sizes)                     # every block decomposed exactly once
+        assert all(m.is_deferred() for m in ld.matrices)        # ... and dropped from host memory
+        diag, rmle = np.zeros(N), np.zeros(N)
+        diag[perm[:n_ld]], rmle[perm[:n_ld]] = out['diag'], out['rmle']
+        mle = old.inverse_dot(z)
+        np.testing.assert_allclose(diag, old.diag(), rtol=1e-11, atol=1e-13)
+        assert out['rank'] == old.get_rank()
+        np.testing.assert_allclose(out['chi'], z.dot(mle), rtol=1e-10)
+        np.testing.assert_allclose(rmle, old.dot(mle), rtol=1e-9, atol=1e-11)
+        x = rng.normal(size=N)
+        np.testing.assert_allclose(eng.ld_matvec(x[None])[0], old.dot(x), rtol=1e-10, atol=1e-11)
+        # ridge start: well conditioned (typical) and badly conditioned (tiny regulariser)
+        for scale in (30.0, 1e-4):
+            reg = scale * rng.uniform(0.5, 2.0, size=N)
+            want = old.ridge_inverse_dot(rmle, reg)
+            got = ld_device.ridge_start(eng, rmle[None], reg[None], diag[None])[0]
+            np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-10 * np.abs(want).max())
+        eng.close()
+
+
+def test_store_upper_bound_covers_every_rank():
+    from vilma_amd import _lib, ld_device
+    from vilma_amd.matrix_structures import dense_is_cheaper
+    lib = _lib.load()
+    for n in (1, 2, 15, 16, 17, 20, 33, 127, 128, 129, 300, 1000, 2431):
+        for form in ('auto', 'dense', 'eig'):
+            bound = ld_device.store_upper_bound(lib, [n], form)
+            for r in sorted({1, 2, n // 7 + 1, n // 3 + 1, n // 2 + 1, n}):
+                dense = form == 'dense' or (form == 'auto' and dense_is_cheaper(n, r))
+                need = lib.vilma_ld_dense_elems(n) if dense else lib.vilma_ld_lowrank_elems(n, r)
+                assert need <= bound, (n, r, form, need, bound)
+
+
+def test_lazy_schema_streams_to_the_device(tmp_path):
+    """The CLI's lazy schema loading (load.py) feeds the streaming loader: same constants and
+    the same fit as eager loading, and no block's factors are left on the host afterwards."""
+    from vilma_amd import load
+    from vilma_amd.variational_inference import MultiPopVI
+    ref = os.path.join(GOLDEN, 'refdata')
+    variants = load.load_variant_list(os.path.join(ref, 'good_variants.tsv'))
+    stats, _ = load.load_sumstats(os.path.join(ref, 'good_sumstats_beta.tsv'), variants)
+    beta, se = stats.BETA.to_numpy()[None], stats.SE.to_numpy()[None]
+    covs = [np.array([[v]]) for v in np.geomspace(1e-6, 1e-1, 8)]
+    fits = {}
+    for lazy in (False, True):
+        ld, _ = load.load_ld_from_schema(os.path.join(ref, 'ld_manifest.tsv'), variants, [], 0.8,
+                                         lazy=lazy)
+        vi = MultiPopVI(marginal_effects=beta, std_errs=se, ld_mats=[ld],
+                        annotations=np.ones((beta.shape[1], 1)), mixture_covs=covs,
+                        checkpoint=False, gwas_N=np.array([1e4]), init_hg=np.array([0.2]),
+                        num_its=5)
+        if lazy:
+            assert all(m.is_deferred() for m in ld.matrices)
+        np.random.seed(3)
+        params = vi.optimize()
+        fits[lazy] = (vi.ld_diags, vi.adj_marginal_effects, vi.chi_stat, vi.ld_ranks,
+                      vi.inverse_betas, vi.real_posterior_mean(params))
+        vi.engine.close()
+    for a, b in zip(fits[False], fits[True]):
+        np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-14)

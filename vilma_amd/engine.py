@@ -148,19 +148,31 @@ class HipEngine:
         for form, n, r in specs:
             total += (lib.vilma_ld_dense_elems(n) if form == 'dense'
                       else lib.vilma_ld_lowrank_elems(n, r))
+        self.ld_begin(cohort, len(specs), perm, n_ld, total)
+        for b in blocks:
+            self.ld_add(cohort, b)
+        self.ld_end(cohort)
+
+    def ld_begin(self, cohort, n_blocks, perm, n_ld, total_elems):
+        """Start a cohort's LD store with room for `total_elems` doubles (an upper bound is fine:
+        the streaming loader reserves before the ranks are known)."""
         perm = np.ascontiguousarray(perm, dtype=np.int64)
         assert perm.shape == (self.N,)
-        self._check(lib.vilma_ld_begin(self.ctx, cohort, len(specs), int(n_ld), _ptr(perm), total))
-        for b in blocks:
-            if b[0] == 'dense':
-                R = self._as_block(b[1])
-                self._check(lib.vilma_ld_add_dense(self.ctx, cohort, int(b[1].shape[0]), R[1]))
-            else:
-                U = self._as_block(b[1])
-                s = self._as_block(b[2])
-                self._check(lib.vilma_ld_add_lowrank(self.ctx, cohort, int(b[1].shape[0]),
-                                                     int(b[1].shape[1]), U[1], s[1]))
-        self._check(lib.vilma_ld_end(self.ctx, cohort))
+        self._check(self.lib.vilma_ld_begin(self.ctx, cohort, int(n_blocks), int(n_ld),
+                                            _ptr(perm), int(total_elems)))
+
+    def ld_add(self, cohort, b):
+        if b[0] == 'dense':
+            R = self._as_block(b[1])
+            self._check(self.lib.vilma_ld_add_dense(self.ctx, cohort, int(b[1].shape[0]), R[1]))
+        else:
+            U = self._as_block(b[1])
+            s = self._as_block(b[2])
+            self._check(self.lib.vilma_ld_add_lowrank(self.ctx, cohort, int(b[1].shape[0]),
+                                                      int(b[1].shape[1]), U[1], s[1]))
+
+    def ld_end(self, cohort):
+        self._check(self.lib.vilma_ld_end(self.ctx, cohort))
 
     def _as_block(self, a):
         if isinstance(a, np.ndarray):

@@ -1,0 +1,217 @@
+"""Load-time work of a fit on the GPU.
+
+The reference does all of this on the host, once per fit, block by block
+(/root/reference/src/vilma/variational_inference.py:189-252 calling matrix_structures.py:
+148-152 `dot`, 159-196 `inverse_dot`, 349-387 `ridge_inverse_dot`, 426-447 `diag` / `get_rank`).
+At 1 M SNPs x 2 cohorts that is minutes of host time against milliseconds of sweeps, so here
+only the eigendecomposition itself stays on the host -- LAPACK `eigh`, one call per core, the
+same routine the reference uses, so the kept ranks are the reference's by construction -- and
+everything that consumes the factors runs on the device while the next blocks decompose:
+
+  * `stream_cohort`: the factors (U, s) of each block travel through pinned staging buffers on
+    a copy stream (uploads overlap the host's decompositions and the device work of the block
+    before); on the device: diag(R) = (U*U) s, R^+ z = U ((U^T z) / s), chi = z^T R^+ z,
+    R R^+ z = U U^T z, and the operator itself -- the dense reconstruction U diag(s) U^T (one
+    rocBLAS GEMM, packed into the symmetric slab store by the library) or the eigen form.
+    The host never forms an n x n reconstruction and never holds more than a window of blocks.
+  * `ridge_start`: (R + diag(reg))^-1 b for ALL blocks of all cohorts at once by Jacobi-
+    preconditioned conjugate gradients on the LD store that is already resident -- each
+    iteration is one `vilma_ld_matvec` (the hand-written LD product, ~1 ms at 1 M SNPs x 2
+    cohorts) -- instead of one Woodbury solve with an r x r inverse per block.  reg =
+    se^2 / prior is of order N_snps / (2 N_gwas h^2) >> 0, so the system is well conditioned.
+"""
+import numpy as np
+
+from . import matrix_structures as ms
+
+
+def _factor_fields(block):
+    """(u, s) of a materialised block whose operator is u diag(s) u^T (D = 0, v = u^T)."""
+    if not np.allclose(block.D, 0):
+        raise NotImplementedError('device LD blocks must have a zero diagonal part')
+    u, s, v = block.u, block.s, block.v
+    if v.shape != u.T.shape or not (np.shares_memory(u, v) or np.array_equal(v, u.T)):
+        raise NotImplementedError('device LD blocks must be symmetric factorisations '
+                                  '(v == u^T), as LowRankMatrix(X, t) produces')
+    return u, s
+
+
+class _Staging:
+    """Pinned host buffers + a copy stream: numpy array -> device tensor without blocking the
+    compute stream.  `slots` uploads may be in flight."""
+
+    def __init__(self, torch, device, slots=3):
+        self.torch, self.device = torch, device
+        self.stream = torch.cuda.Stream(device=device)
+        self.slots = [{'buf': None, 'event': None} for _ in range(slots)]
+        self.turn = 0
+
+    def upload(self, array):
+        """Queue `array` (float64, any shape) for upload; returns (device tensor, event)."""
+        t = self.torch
+        slot = self.slots[self.turn]
+        self.turn = (self.turn + 1) % len(self.slots)
+        n = int(array.size)
+        if slot['event'] is not None:
+            slot['event'].synchronize()             # the buffer's previous upload has finished
+        if slot['buf'] is None or slot['buf'].numel() < n:
+            slot['buf'] = t.empty(max(n, 1 << 16), dtype=t.float64).pin_memory()
+        host = slot['buf'][:n].view(array.shape)
+        host.numpy()[...] = array                    # one host copy into pinned memory
+        dev = t.empty(array.shape, dtype=t.float64, device=self.device)
+        with t.cuda.stream(self.stream):
+            dev.copy_(host, non_blocking=True)
+            ev = t.cuda.Event()
+            ev.record(self.stream)
+        slot['event'] = ev
+        return dev, ev
+
+
+def store_upper_bound(lib, sizes, form):
+    """Elements to reserve for a cohort's LD store before the ranks are known."""
+    total = 0
+    for n in sizes:
+        n = int(n)
+        dense = lib.vilma_ld_dense_elems(n)
+        if form == 'dense':
+            total += dense
+            continue
+        if form == 'eig':
+            total += lib.vilma_ld_lowrank_elems(n, n)
+            continue
+        # auto: the eigen form is chosen only up to this rank
+        r_max = max(1, min(n, int(ms.dense_bytes_moved(n) / (ms.EIGEN_FORM_PENALTY * 2.0 * n))))
+        total += max(dense, lib.vilma_ld_lowrank_elems(n, r_max))
+    return total
+
+
+def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
+    """Decompose (host, thread pool) and install (device) the blocks of one cohort's local
+    BlockDiagonalMatrix `ld`, in LD order.  z_ld [n_ld]: z = beta-hat / se at the LD positions.
+
+    Returns dict(diag [n_ld], rmle [n_ld] = R R^+ z, chi = z^T R^+ z, rank) -- what
+    VIScheme.__init__ derives per cohort (variational_inference.py:189-192, 236-252)."""
+    from concurrent.futures import ThreadPoolExecutor
+    torch = engine.torch
+    dev = engine.device
+    mats = ld.matrices
+    sizes = [m.shape[0] for m in mats]
+    n_ld = int(np.sum(sizes)) if sizes else 0
+    perm = ld.perm.astype(np.int64)
+    engine.ld_begin(cohort, len(mats), perm, n_ld,
+                    store_upper_bound(engine.lib, sizes, form))
+    z_dev = torch.as_tensor(np.ascontiguousarray(z_ld, dtype=np.float64), device=dev)
+    diag = torch.zeros(n_ld, dtype=torch.float64, device=dev)
+    rmle = torch.zeros(n_ld, dtype=torch.float64, device=dev)
+    chi = torch.zeros((), dtype=torch.float64, device=dev)
+    rank = 0
+    staging = _Staging(torch, dev)
+    workers = ms._default_workers() if workers is None else workers
+    window = 2 * workers if window is None else window
+
+    def decompose(m):
+        m.materialize()                  # np.linalg.eigh + thresholding; releases the GIL
+        return m
+
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)        # one LAPACK thread per worker
+    except ImportError:
+        limiter = None
+    compute = torch.cuda.current_stream(dev)
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            pending = []
+            it = iter(mats)
+            start = 0
+
+            def refill():
+                while len(pending) < window:
+                    try:
+                        pending.append(pool.submit(decompose, next(it)))
+                    except StopIteration:
+                        return
+            refill()
+            while pending:
+                m = pending.pop(0).result()
+                refill()
+                u, s = _factor_fields(m)
+                n, r = u.shape
+                rank += m.get_rank()
+                dense = form == 'dense' or (form == 'auto' and ms.dense_is_cheaper(n, r))
+                Ud, ev_u = staging.upload(u)
+                sd, ev_s = staging.upload(s)
+                compute.wait_event(ev_u)
+                compute.wait_event(ev_s)
+                zb = z_dev[start:start + n]
+                inv_s = torch.where(sd != 0, 1.0 / sd, torch.zeros_like(sd))
+                proj = Ud.T @ zb                               # U^T z
+                chi += (proj * proj * inv_s).sum()             # z^T R^+ z
+                rmle[start:start + n] = Ud @ (proj * (sd * inv_s))   # R R^+ z
+                diag[start:start + n] = (Ud * Ud) @ sd
+                if dense:
+                    engine.ld_add(cohort, ('dense', (Ud * sd) @ Ud.T))
+                else:
+                    engine.ld_add(cohort, ('eig', Ud, sd))
+                if m.__dict__.get('_from_thunk'):
+                    m.forget()           # the factors live on the device now
+                start += n
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
+    engine.ld_end(cohort)
+    return {'diag': diag.cpu().numpy(), 'rmle': rmle.cpu().numpy(), 'chi': float(chi.item()),
+            'rank': float(rank)}
+
+
+def ridge_start(engine, b, reg, diag, rtol=1e-13, max_iter=20000):
+    """x = (R_p + diag(reg_p))^-1 b_p for every cohort p at once (b, reg, diag: [P, N] in SNP
+    order; reg > 0) by Jacobi-preconditioned conjugate gradients on the resident LD store --
+    the per-block ridge solve of reference matrix_structures.py:349-387, without factorising
+    anything.  Raises if the residual does not reach `rtol`."""
+    torch = engine.torch
+    dev = engine.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    b = torch.as_tensor(np.ascontiguousarray(b, dtype=np.float64), **f64)
+    reg = torch.as_tensor(np.ascontiguousarray(reg, dtype=np.float64), **f64)
+    minv = 1.0 / (torch.as_tensor(np.ascontiguousarray(diag, dtype=np.float64), **f64) + reg)
+    P = b.shape[0]
+    x = torch.zeros_like(b)
+    bnorm = torch.linalg.vector_norm(b, dim=1)
+    if float(bnorm.max().item()) == 0.0:
+        return x.cpu().numpy()
+    live = (bnorm > 0).to(torch.float64)             # a cohort with b = 0 stays at x = 0
+    safe = torch.where(bnorm > 0, bnorm, torch.ones_like(bnorm))
+    r = b.clone()
+    zv = minv * r
+    p = zv.clone()
+    rz = (r * zv).sum(dim=1)
+    Ap = torch.empty_like(b)
+    it, worst = 0, float('inf')
+    while it < max_iter:
+        for _ in range(8):                           # residual check (a host sync) every 8 steps
+            engine.ld_matvec_device(p, Ap)
+            Ap += reg * p
+            pAp = (p * Ap).sum(dim=1)
+            alpha = live * rz / torch.where(pAp != 0, pAp, torch.ones_like(pAp))
+            x += alpha[:, None] * p
+            r -= alpha[:, None] * Ap
+            zv = minv * r
+            rz_new = (r * zv).sum(dim=1)
+            beta = live * rz_new / torch.where(rz != 0, rz, torch.ones_like(rz))
+            p = zv + beta[:, None] * p
+            rz = rz_new
+            it += 1
+        worst = float((torch.linalg.vector_norm(r, dim=1) / safe).max().item())
+        if worst <= rtol:
+            break
+    else:
+        raise RuntimeError('ridge start: conjugate gradients stalled at relative residual '
+                           '%.3e after %d iterations' % (worst, it))
+    # the recurrence residual can drift from the true one: verify against the operator itself
+    engine.ld_matvec_device(x, Ap)
+    Ap += reg * x
+    true_res = float((torch.linalg.vector_norm(b - Ap, dim=1) / safe).max().item())
+    if not true_res <= 1e-9:
+        raise RuntimeError('ridge start: residual %.3e after %d iterations' % (true_res, it))
+    return x.cpu().numpy()

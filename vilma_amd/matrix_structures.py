@@ -100,6 +100,19 @@ class LowRankMatrix:
             make_matrix, t = thunk
             self._thunk = None
             self.__init__(make_matrix(), t)
+            self._from_thunk = thunk
+        return self
+
+    def forget(self):
+        """Drop the factors of a block that came from a thunk (they can be recomputed on
+        demand): the streaming device loader calls this once a block lives in HBM, so the host
+        never holds more than a window of decomposed blocks."""
+        thunk = self.__dict__.get('_from_thunk')
+        if thunk is not None:
+            for name in LowRankMatrix._LAZY_FIELDS:
+                self.__dict__.pop(name, None)
+            self._from_thunk = None
+            self._thunk = thunk
         return self
 
     def __getattr__(self, name):

@@ -663,41 +663,28 @@ class MultiPopVI(SweepDriver):
             _engine_factory = HipEngine
         self.engine = _engine_factory(P, n_loc, M, self.num_annotations)
 
-        # ---- one-time constants (variational_inference.py:189-252), host numpy per block: only
-        # this shard's blocks are eigendecomposed (deferred blocks, thread pool), the per-SNP
-        # results are gathered across ranks ----
+        # ---- one-time constants (variational_inference.py:189-252) for this shard's blocks;
+        # the per-SNP results are gathered across ranks ----
         loc = self._snps
-        local_lds = []
-        for p, ld in enumerate(ld_mats):
-            ld.materialize(mine['blocks'][p])
-            mats, perm, n_ld = local_ld(ld, loc, mine['blocks'][p], N)
-            sub = matrix_structures.BlockDiagonalMatrix(mats, perm=perm,
-                                                        missing=perm[n_ld:])
-            local_lds.append(sub)
-            self.engine.load_ld(p, sub.device_blocks(form), perm, n_ld)
-        self._local_lds = local_lds
-        self.ld_diags = self.comm.gather_snps(np.stack([sub.diag() for sub in local_lds]), loc, N)
-        self.scaled_ld_diags = self.std_errs ** -2 * self.ld_diags
-
-        mle = np.zeros((P, n_loc))
-        chi_loc, rank_loc = np.zeros(P), np.zeros(P)
         z_loc = self.marginal_effects[:, loc] / self.std_errs[:, loc]
-        for p in range(P):
-            mle[p] = local_lds[p].inverse.dot(z_loc[p])
-            chi_loc[p] = z_loc[p].dot(mle[p])
-            rank_loc[p] = local_lds[p].get_rank()
-        # adj = (R R^+ z) / se: the first product of the fit already runs on the GPU
-        adj_loc = self.engine.ld_matvec(mle) / self.std_errs[:, loc]
-        sums = self.comm.allreduce_np(np.concatenate([chi_loc, rank_loc]))
-        self.chi_stat, self.ld_ranks = sums[:P], sums[P:]
         inv_se2 = self.comm.allreduce_np((self.std_errs[:, loc] ** -2).sum(axis=1)) \
             if self.comm.active else (self.std_errs ** -2).sum(axis=1)
-        inverse_loc = np.zeros((P, n_loc))
-        for p in range(P):
-            prior = 2 * self.gwas_N[p] * self.init_hg[p] / inv_se2[p]
-            ridge = local_lds[p].ridge_inverse_dot(adj_loc[p] * self.std_errs[p, loc],
-                                                   self.std_errs[p, loc] ** 2 / prior)
-            inverse_loc[p] = ridge * self.std_errs[p, loc]
+        prior = 2 * self.gwas_N * self.init_hg / inv_se2
+        local_lds = []
+        for p, ld in enumerate(ld_mats):
+            mats, perm, n_ld = local_ld(ld, loc, mine['blocks'][p], N)
+            local_lds.append((matrix_structures.BlockDiagonalMatrix(mats, perm=perm,
+                                                                     missing=perm[n_ld:]),
+                              perm, n_ld))
+        if hasattr(self.engine, 'ld_begin'):
+            consts = self._load_on_device(local_lds, z_loc, prior, form)
+        else:
+            consts = self._load_on_host(local_lds, z_loc, prior, form)
+        diag_loc, adj_loc, inverse_loc, chi_loc, rank_loc = consts
+        self.ld_diags = self.comm.gather_snps(diag_loc, loc, N)
+        self.scaled_ld_diags = self.std_errs ** -2 * self.ld_diags
+        sums = self.comm.allreduce_np(np.concatenate([chi_loc, rank_loc]))
+        self.chi_stat, self.ld_ranks = sums[:P], sums[P:]
         self.adj_marginal_effects = self.comm.gather_snps(adj_loc, loc, N)
         self.inverse_betas = self.comm.gather_snps(inverse_loc, loc, N)
         if not np.allclose(self.adj_marginal_effects[np.isclose(self.ld_diags, 0)], 0):
@@ -713,6 +700,53 @@ class MultiPopVI(SweepDriver):
                            self.ld_ranks, self.annotation_counts, self.log_det, scale_se, num_its,
                            checkpoint=checkpoint, checkpoint_freq=checkpoint_freq,
                            checkpoint_path=self.checkpoint_path)
+
+    def _load_on_device(self, local_lds, z_loc, prior, form):
+        """Load-time constants with the GPU doing everything but `eigh` (ld_device.py): blocks
+        stream host -> device as they are decomposed; diag, R^+ z, chi, R R^+ z per block on the
+        device; the ridge start by conjugate gradients on the resident LD store."""
+        from . import ld_device
+        P = self.num_pops
+        loc = self._snps
+        n_loc = len(loc)
+        se = self.std_errs[:, loc]
+        diag_loc, rmle = np.zeros((P, n_loc)), np.zeros((P, n_loc))
+        chi_loc, rank_loc = np.zeros(P), np.zeros(P)
+        for p, (sub, perm, n_ld) in enumerate(local_lds):
+            out = ld_device.stream_cohort(self.engine, p, sub, form, z_loc[p][perm[:n_ld]])
+            diag_loc[p, perm[:n_ld]] = out['diag']
+            rmle[p, perm[:n_ld]] = out['rmle']
+            chi_loc[p], rank_loc[p] = out['chi'], out['rank']
+        adj_loc = rmle / se                                   # (R R^+ z) / se  (:243)
+        reg = se ** 2 / prior[:, None]
+        ridge = ld_device.ridge_start(self.engine, rmle, reg, diag_loc)   # rhs = adj * se
+        return diag_loc, adj_loc, ridge * se, chi_loc, rank_loc
+
+    def _load_on_host(self, local_lds, z_loc, prior, form):
+        """The same constants with the reference's own per-block formulas in host numpy
+        (matrix_structures.py) -- for engines without a device loader (the test engine)."""
+        P = self.num_pops
+        loc = self._snps
+        n_loc = len(loc)
+        se = self.std_errs[:, loc]
+        subs = []
+        for p, (sub, perm, n_ld) in enumerate(local_lds):
+            sub.materialize()
+            self.engine.load_ld(p, sub.device_blocks(form), perm, n_ld)
+            subs.append(sub)
+        diag_loc = np.stack([sub.diag() for sub in subs])
+        mle = np.zeros((P, n_loc))
+        chi_loc, rank_loc = np.zeros(P), np.zeros(P)
+        for p in range(P):
+            mle[p] = subs[p].inverse.dot(z_loc[p])
+            chi_loc[p] = z_loc[p].dot(mle[p])
+            rank_loc[p] = subs[p].get_rank()
+        adj_loc = self.engine.ld_matvec(mle) / se
+        inverse_loc = np.zeros((P, n_loc))
+        for p in range(P):
+            ridge = subs[p].ridge_inverse_dot(adj_loc[p] * se[p], se[p] ** 2 / prior[p])
+            inverse_loc[p] = ridge * se[p]
+        return diag_loc, adj_loc, inverse_loc, chi_loc, rank_loc
 
     @property
     def nat_grad_vi_delta(self):
