@@ -83,11 +83,12 @@ def main():
     print('vilma fit: %.1f s total' % (time.perf_counter() - t0))
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(
-        'vi_options|load.py|variational_inference|matrix_structures|engine')
+        'vi_options|load.py|variational_inference|matrix_structures|engine|ld_device|npyio|frame')
     for line in s.getvalue().splitlines():
         if any(k in line for k in ('load_ld_from_schema', 'load_sumstats', '__init__', 'optimize',
                                    'materialize', 'device_blocks', 'load_ld', '_initialize',
-                                   'ridge_inverse_dot', 'main')):
+                                   'ridge_inverse_dot', 'main', 'stream_cohort', 'ridge_start',
+                                   '_load_on_device', 'savez', 'vi_sigma', 'to_csv')):
             print(line[:150])
     out = np.load('%s/run.npz' % args.out)
     est = pd.read_csv('%s/run.estimates.tsv' % args.out, sep='\t')

@@ -161,3 +161,39 @@ def test_lazy_loading_is_equivalent_and_deferred():
     assert lazy.matrices[1].is_deferred()
     _ = lazy.matrices[1].s                      # touching a factor materialises just that block
     assert not lazy.matrices[1].is_deferred() and lazy.matrices[0].is_deferred()
+
+
+def test_store_upper_bound_covers_every_rank():
+    from vilma_amd import _lib, ld_device
+    from vilma_amd.matrix_structures import dense_is_cheaper
+    lib = _lib.load()
+    for n in (1, 2, 15, 16, 17, 20, 33, 127, 128, 129, 300, 1000, 2431):
+        for form in ('auto', 'dense', 'eig'):
+            bound = ld_device.store_upper_bound(lib, [n], form)
+            for r in sorted({min(n, v) for v in (1, 2, n // 7 + 1, n // 3 + 1, n // 2 + 1, n)}):
+                dense = form == 'dense' or (form == 'auto' and dense_is_cheaper(n, r))
+                need = lib.vilma_ld_dense_elems(n) if dense else lib.vilma_ld_lowrank_elems(n, r)
+                assert need <= bound, (n, r, form, need, bound)
+
+
+def test_select_eigenpairs_is_lowrankmatrix_selection():
+    """matrix_structures.select_eigenpairs (used when eigh runs on the GPU) == what
+    LowRankMatrix(X, t) keeps (reference matrix_structures.py:15-28, 136-146)."""
+    from vilma_amd.matrix_structures import LowRankMatrix, select_eigenpairs
+    rng = np.random.default_rng(0)
+    q, _ = np.linalg.qr(rng.normal(size=(9, 9)))
+    spectra = [np.linspace(0.01, 2, 9), np.r_[np.zeros(4), 1e-14, 1e-13, 0.2, 1, 3],
+               -np.ones(9), np.zeros(9), np.r_[-0.5, 0, 0, 1e-20, 1e-15, 1e-3, 0.1, 0.5, 4]]
+    for w in spectra:
+        X = (q * w) @ q.T
+        X = 0.5 * (X + X.T)
+        for t in (1.0, 0.8, 0.3):
+            host = LowRankMatrix(X, t)
+            ev = np.linalg.eigh(X)[0]
+            idx, degenerate = select_eigenpairs(ev, t)
+            if degenerate == 'ones':
+                assert host.s.shape == (1,) and host.s[0] == 0 and np.all(host.u == 1)
+            elif degenerate == 'zero':
+                assert host.s.shape == (1,) and host.s[0] == 0
+            else:
+                np.testing.assert_array_equal(ev[idx], host.s)

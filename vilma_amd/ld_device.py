@@ -4,8 +4,9 @@ The reference does all of this on the host, once per fit, block by block
 (/root/reference/src/vilma/variational_inference.py:189-252 calling matrix_structures.py:
 148-152 `dot`, 159-196 `inverse_dot`, 349-387 `ridge_inverse_dot`, 426-447 `diag` / `get_rank`).
 At 1 M SNPs x 2 cohorts that is minutes of host time against milliseconds of sweeps, so here
-only the eigendecomposition itself stays on the host -- LAPACK `eigh`, one call per core, the
-same routine the reference uses, so the kept ranks are the reference's by construction -- and
+the eigendecompositions are shared between the host cores (LAPACK `eigh`, one call per core:
+the routine the reference uses) and the GPU (rocSOLVER through torch.linalg.eigh, which takes
+the LARGEST blocks -- 19x a host thread at 2 400 SNPs, no better than one at 200), and
 everything that consumes the factors runs on the device while the next blocks decompose:
 
   * `stream_cohort`: the factors (U, s) of each block travel through pinned staging buffers on
@@ -20,6 +21,9 @@ everything that consumes the factors runs on the device while the next blocks de
     cohorts) -- instead of one Woodbury solve with an r x r inverse per block.  reg =
     se^2 / prior is of order N_snps / (2 N_gwas h^2) >> 0, so the system is well conditioned.
 """
+import logging
+import time
+
 import numpy as np
 
 from . import matrix_structures as ms
@@ -85,6 +89,70 @@ def store_upper_bound(lib, sizes, form):
     return total
 
 
+# Cost model of one block's eigh, seconds: LAPACK dsyevd on ONE host thread and rocSOLVER (one
+# matrix per call through torch.linalg.eigh) on the GPU, fitted to profiles/r01f_microbench_eigh.txt
+# (n = 200 / 588 / 1200 / 2431: host 3 / 23 / 335 / 1319 ms, GPU 4.5 / 13.5 / 28 / 69 ms).
+def _host_eigh_seconds(n):
+    return 23e-3 * (n / 588.0) ** 2.9
+
+
+def _gpu_eigh_seconds(n):
+    return 4e-3 + 2.7e-5 * n
+
+
+def plan_gpu_eigh(sizes, deferred, workers):
+    """Which blocks to eigendecompose on the GPU while the host pool does the rest: the GPU's
+    advantage over a host thread grows with n (1.5x at 200 SNPs, 19x at 2431), so it takes the
+    largest blocks, as many as keep its queue no longer than the pool's.  Returns a set of block
+    indices (empty when VILMA_GPU_EIGH=0)."""
+    import os
+    if os.environ.get('VILMA_GPU_EIGH', '1') == '0':
+        return set()
+    order = sorted((b for b in range(len(sizes)) if deferred[b]), key=lambda b: -sizes[b])
+    host = sum(_host_eigh_seconds(sizes[b]) for b in order)
+    gpu, chosen = 0.0, set()
+    for b in order:
+        tg, th = _gpu_eigh_seconds(sizes[b]), _host_eigh_seconds(sizes[b])
+        if tg >= th or gpu + tg > (host - th) / max(1, workers):
+            break
+        gpu += tg
+        host -= th
+        chosen.add(b)
+    return chosen
+
+
+def _gpu_factors(torch, staging, compute, X, t):
+    """eigh of one symmetric block on the GPU and the reference's selection of eigenpairs
+    (matrix_structures.select_eigenpairs on the eigenvalues, on the host: n doubles).
+    Returns (U [n,r] device, s [r] device, s on the host)."""
+    n = X.shape[0]
+    Xd, ev = staging.upload(X)
+    compute.wait_event(ev)
+    w, Q = torch.linalg.eigh(Xd)
+    w_host = w.cpu().numpy()
+    idx, degenerate = ms.select_eigenpairs(w_host, t)
+    f64 = dict(dtype=torch.float64, device=Xd.device)
+    if degenerate == 'ones':
+        return torch.ones((n, 1), **f64), torch.zeros(1, **f64), np.zeros(1)
+    lo, hi = int(idx[0]), int(idx[-1]) + 1
+    if hi - lo == idx.size:                          # a contiguous range of the ascending spectrum
+        Ud = Q[:, lo:hi].contiguous()
+    else:
+        Ud = Q[:, torch.as_tensor(idx, device=Xd.device)].contiguous()
+    if degenerate == 'zero':
+        return Ud, torch.zeros(1, **f64), np.zeros(1)
+    return Ud, w[torch.as_tensor(idx, device=Xd.device)].contiguous(), w_host[idx]
+
+
+def _load_symmetric(m):
+    """The dense matrix of a deferred block, checked like LowRankMatrix(X, t) checks it."""
+    make_matrix, t = m._thunk
+    X = np.ascontiguousarray(make_matrix(), dtype=np.float64)
+    if not np.allclose(X, X.T):
+        raise ValueError('Provided matrix is not symmetric')
+    return X, t
+
+
 def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
     """Decompose (host, thread pool) and install (device) the blocks of one cohort's local
     BlockDiagonalMatrix `ld`, in LD order.  z_ld [n_ld]: z = beta-hat / se at the LD positions.
@@ -109,9 +177,14 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
     workers = ms._default_workers() if workers is None else workers
     window = 2 * workers if window is None else window
 
-    def decompose(m):
+    on_gpu = plan_gpu_eigh(sizes, [m.is_deferred() for m in mats], workers)
+
+    def decompose(b):
+        m = mats[b]
+        if b in on_gpu:
+            return m, _load_symmetric(m)             # read + check only: the GPU decomposes it
         m.materialize()                  # np.linalg.eigh + thresholding; releases the GIL
-        return m
+        return m, None
 
     try:
         from threadpoolctl import threadpool_limits
@@ -122,7 +195,7 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
     try:
         with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
             pending = []
-            it = iter(mats)
+            it = iter(range(len(mats)))
             start = 0
 
             def refill():
@@ -132,17 +205,26 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
                     except StopIteration:
                         return
             refill()
+            t_wait = t_dev = 0.0
             while pending:
-                m = pending.pop(0).result()
+                t0 = time.perf_counter()
+                m, raw = pending.pop(0).result()
+                t_wait += time.perf_counter() - t0
+                t0 = time.perf_counter()
                 refill()
-                u, s = _factor_fields(m)
-                n, r = u.shape
-                rank += m.get_rank()
+                if raw is not None:
+                    Ud, sd, s = _gpu_factors(torch, staging, compute, raw[0], raw[1])
+                    n, r = Ud.shape
+                    rank += r if r > 1 else (0 if s[0] == 0 else 1)     # LowRankMatrix.get_rank
+                else:
+                    u, s = _factor_fields(m)
+                    n, r = u.shape
+                    rank += m.get_rank()
+                    Ud, ev_u = staging.upload(u)
+                    sd, ev_s = staging.upload(s)
+                    compute.wait_event(ev_u)
+                    compute.wait_event(ev_s)
                 dense = form == 'dense' or (form == 'auto' and ms.dense_is_cheaper(n, r))
-                Ud, ev_u = staging.upload(u)
-                sd, ev_s = staging.upload(s)
-                compute.wait_event(ev_u)
-                compute.wait_event(ev_s)
                 zb = z_dev[start:start + n]
                 inv_s = torch.where(sd != 0, 1.0 / sd, torch.zeros_like(sd))
                 proj = Ud.T @ zb                               # U^T z
@@ -156,12 +238,16 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
                 if m.__dict__.get('_from_thunk'):
                     m.forget()           # the factors live on the device now
                 start += n
+                t_dev += time.perf_counter() - t0
     finally:
         if limiter is not None:
             limiter.restore_original_limits()
     engine.ld_end(cohort)
+    logging.info('LD cohort %d: %d blocks streamed to the device (%d decomposed on the GPU); main '
+                 'thread waited %.2f s for the host pool, spent %.2f s on uploads and device '
+                 'work', cohort, len(mats), len(on_gpu), t_wait, t_dev)
     return {'diag': diag.cpu().numpy(), 'rmle': rmle.cpu().numpy(), 'chi': float(chi.item()),
-            'rank': float(rank)}
+            'rank': float(rank), 'wait_s': t_wait, 'device_s': t_dev, 'gpu_eigh': len(on_gpu)}
 
 
 def ridge_start(engine, b, reg, diag, rtol=1e-13, max_iter=20000):

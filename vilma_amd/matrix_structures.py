@@ -27,6 +27,22 @@ def _svd_threshold(matrix, ld_thresh):
     return u, np.array(w[sel]), np.array(u.T)
 
 
+def select_eigenpairs(w, ld_thresh):
+    """Which eigenpairs of a block the reference keeps, given ALL eigenvalues `w` (any order):
+    those >= 1 - sqrt(ld_thresh) (matrix_structures.py:15-28), then of these the ones
+    > 1e-12 x the largest kept (:136-146).  Returns (indices into w, degenerate) where
+    degenerate is None, or 'ones' (nothing passed the first rule: the rank-one zero operator
+    u = 1, s = 0) or 'zero' (nothing passed the second: first kept vector with s = 0)."""
+    sel = np.flatnonzero(w >= 1 - np.sqrt(ld_thresh))
+    if sel.size == 0:
+        return sel, 'ones'
+    s = w[sel]
+    big = s > 1e-12 * np.max(s)
+    if big.any():
+        return sel[big], None
+    return sel[:1], 'zero'
+
+
 def _default_workers():
     try:
         import os
