@@ -184,6 +184,42 @@ int vilma_snapshot_mean(vilma_ctx *ctx, void *stream);
  * (pinned staging + stream synchronise): the one blocking point of a decision. */
 int vilma_fetch(vilma_ctx *ctx, void *stream, const double *src_dev, double *dst_host, int64_t n);
 
+/* ---- decisions on the device, work queued ahead of them ----------------------------------- */
+
+/* The accept test of the beta line search (variational_inference.py:777-787),
+ *     new >= orig - rel_tol |orig| - abs_tol,
+ * evaluated on the device from the (all-reduced) sums of the current state (totals_dev) and of
+ * the trial (ttotals_dev) with the host's own formula (fast_likelihood - _beta_KL assembled as
+ * SweepDriver._objective_from does: same operations and order, no fused multiply-add), so host
+ * and device always agree.  chi = chi_stat [P]; half_rank_log_tau[p] = 0.5 ld_ranks[p] log tau_p
+ * (computed by the host).  With check_convergence != 0 the decision is also 0 when
+ * dsum_dev[0] == 0 (no posterior mean moved in the sweep just finished: optimize() stops there).
+ * The result goes to flag slot out_slot (0/1) of the context. */
+int vilma_decide(vilma_ctx *ctx, void *stream, const double *totals_dev, const double *ttotals_dev,
+                 const double *dsum_dev, const double *chi, const double *half_rank_log_tau,
+                 double rel_tol, double abs_tol, int check_convergence, int out_slot);
+
+/* Every kernel launched on this context by the calling thread while slot >= 0 first reads flag
+ * `slot` and exits if it is 0: the host can queue the M-step, re-evaluation and next trial of a
+ * sweep BEFORE it knows the line-search decision; mis-speculated work touches nothing.
+ * slot = -1 restores unconditional launches.  (vilma_decide under a predicate whose flag is 0
+ * writes 0 to its own slot.) */
+int vilma_set_predicate(vilma_ctx *ctx, int slot);
+
+/* Host-side buffer indices (which vi_mu / moment buffers are current) move at queue time
+ * (vilma_accept); save them before queuing predicated work and restore them if its flag was 0. */
+int vilma_spec_save(vilma_ctx *ctx);
+int vilma_spec_restore(vilma_ctx *ctx);
+
+/* vilma_fetch in two halves, so the host can queue more work between them: begin copies n
+ * doubles (+ both decision flags) into pinned landing buffer 0/1 behind everything queued on
+ * `stream` and records an event; end waits for that event only. */
+int vilma_fetch_begin(vilma_ctx *ctx, void *stream, const double *src_dev, int64_t n, int buffer);
+int vilma_fetch_end(vilma_ctx *ctx, int buffer, double *dst_host, int64_t n, int *flags2);
+
+/* Synchronous read of a flag slot and of {orig, new} of the last vilma_decide (tests). */
+int vilma_read_decision(vilma_ctx *ctx, int slot, int *flag, double *obj2);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 
 /* vilma_prof_enable(ctx, k): k = 0 off; k >= 1 brackets every k-th LD product's streaming kernels

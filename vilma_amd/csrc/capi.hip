@@ -99,6 +99,18 @@ struct vilma_ctx {
     hipEvent_t ev_snp = nullptr, ev_side = nullptr;
     bool overlap = true, snp_marked = false;
 
+    // Decisions taken on the device (vilma_decide) and work queued ahead of them: two flag slots
+    // (stage s is predicated on one while it writes the other), two pinned landing buffers for
+    // asynchronous result copies, and a snapshot of the host-side buffer indices to undo a stage
+    // whose flag turned out 0.
+    int *flags = nullptr;           // device [2]
+    double *decide_obj = nullptr;   // device [2]: {orig, new} objective of the last decision
+    int pred_slot = -1;             // -1: launches are unconditional
+    double *landing[2] = {nullptr, nullptr};
+    int64_t landing_elems[2] = {0, 0};
+    hipEvent_t landed[2] = {nullptr, nullptr};
+    struct Saved { int mu_cur, mom_cur; bool have_moments, snp_marked; } saved{0, 0, false, false};
+
     int prof = 0;                   // 0 off, k >= 1: bracket every k-th LD launch
     int64_t prof_tick = 0;
     bool prof_now = false;
@@ -429,6 +441,17 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         return 1;
     }
     c->log_det_host.assign(M, 0.0);
+    {
+        const int ones[2] = {1, 1};
+        if (dev_alloc(c, &c->flags, 2) || dev_alloc(c, &c->decide_obj, 2) ||
+            hipMemcpy(c->flags, ones, sizeof(ones), hipMemcpyHostToDevice) != hipSuccess ||
+            hipEventCreateWithFlags(&c->landed[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->landed[1], hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "cannot create the decision flags";
+            vilma_destroy(c);
+            return 1;
+        }
+    }
     // VILMA_OVERLAP=0 keeps everything on the caller's stream (A/B measurements)
     const char *ov = std::getenv("VILMA_OVERLAP");
     c->overlap = !(ov && ov[0] == '0');
@@ -452,6 +475,11 @@ void vilma_destroy(vilma_ctx *c) {
     for (auto &co : c->ld) dev_free(co.store);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    for (int b = 0; b < 2; ++b) {
+        if (c->landing[b]) (void)hipHostFree(c->landing[b]);
+        if (c->landed[b]) (void)hipEventDestroy(c->landed[b]);
+    }
+    dev_free(c->flags); dev_free(c->decide_obj);
     if (c->ev_snp) (void)hipEventDestroy(c->ev_snp);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -766,6 +794,82 @@ int vilma_fetch(vilma_ctx *c, void *stream, const double *src_dev, double *dst_h
     HIPCHK(c, hipMemcpyAsync(c->pinned, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     std::memcpy(dst_host, c->pinned, (size_t)n * sizeof(double));
+    return 0;
+}
+
+int vilma_set_predicate(vilma_ctx *c, int slot) {
+    if (!c) return 1;
+    if (slot < -1 || slot > 1) return fail(c, "predicate slot must be -1, 0 or 1");
+    c->pred_slot = slot;
+    set_launch_predicate(slot < 0 ? nullptr : c->flags + slot);
+    return 0;
+}
+
+int vilma_decide(vilma_ctx *c, void *stream, const double *totals_dev, const double *ttotals_dev,
+                 const double *dsum_dev, const double *chi, const double *half_rank_log_tau,
+                 double rel_tol, double abs_tol, int check_convergence, int out_slot) {
+    if (!c) return 1;
+    if (out_slot < 0 || out_slot > 1) return fail(c, "flag slot must be 0 or 1");
+    if (out_slot == c->pred_slot) return fail(c, "a stage cannot overwrite the flag it runs under");
+    launch_decide(c->P, check_convergence, totals_dev, ttotals_dev, dsum_dev, chi, c->tau,
+                  half_rank_log_tau, rel_tol, abs_tol, c->flags + out_slot, c->decide_obj,
+                  (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int vilma_read_decision(vilma_ctx *c, int slot, int *flag, double *obj2) {
+    if (!c) return 1;
+    if (slot < 0 || slot > 1) return fail(c, "flag slot must be 0 or 1");
+    HIPCHK(c, hipDeviceSynchronize());
+    if (flag) HIPCHK(c, hipMemcpy(flag, c->flags + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (obj2) HIPCHK(c, hipMemcpy(obj2, c->decide_obj, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int vilma_fetch_begin(vilma_ctx *c, void *stream, const double *src_dev, int64_t n, int buffer) {
+    if (!c) return 1;
+    if (buffer < 0 || buffer > 1) return fail(c, "landing buffer must be 0 or 1");
+    if (n <= 0) return fail(c, "nothing to fetch");
+    // the decision flags ride behind the doubles: [n doubles | 2 flags as doubles' worth of bytes]
+    const int64_t need = n + 1;
+    if (need > c->landing_elems[buffer]) {
+        if (c->landing[buffer]) (void)hipHostFree(c->landing[buffer]);
+        c->landing[buffer] = nullptr;
+        c->landing_elems[buffer] = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->landing[buffer], (size_t)need * sizeof(double),
+                                hipHostMallocDefault));
+        c->landing_elems[buffer] = need;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipMemcpyAsync(c->landing[buffer], src_dev, (size_t)n * sizeof(double),
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->landing[buffer] + n, c->flags, 2 * sizeof(int),
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->landed[buffer], s));
+    return 0;
+}
+
+int vilma_fetch_end(vilma_ctx *c, int buffer, double *dst_host, int64_t n, int *flags2) {
+    if (!c) return 1;
+    if (buffer < 0 || buffer > 1 || n + 1 > c->landing_elems[buffer])
+        return fail(c, "no copy in flight for this landing buffer");
+    HIPCHK(c, hipEventSynchronize(c->landed[buffer]));
+    std::memcpy(dst_host, c->landing[buffer], (size_t)n * sizeof(double));
+    if (flags2) std::memcpy(flags2, c->landing[buffer] + n, 2 * sizeof(int));
+    return 0;
+}
+
+int vilma_spec_save(vilma_ctx *c) {
+    if (!c) return 1;
+    c->saved = {c->mu_cur, c->mom_cur, c->have_moments, c->snp_marked};
+    return 0;
+}
+
+int vilma_spec_restore(vilma_ctx *c) {
+    if (!c) return 1;
+    c->mu_cur = c->saved.mu_cur; c->mom_cur = c->saved.mom_cur;
+    c->have_moments = c->saved.have_moments; c->snp_marked = c->saved.snp_marked;
     return 0;
 }
 

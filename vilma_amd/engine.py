@@ -231,6 +231,43 @@ class HipEngine:
                                          self._host_ptr, self.layout.size))
         return self._host.copy()
 
+    # ------------------------------------------------------------------ decisions on the device
+    def decide(self, chi, half_rank_log_tau, rel_tol, abs_tol, check_convergence, out_slot):
+        """Queue the line-search accept test on (totals, trial totals[, convergence statistic])
+        of the result vector; the outcome lands in flag slot `out_slot`."""
+        chi, hrl = _f64(chi), _f64(half_rank_log_tau)
+        self._check(self.lib.vilma_decide(self.ctx, self._stream_handle, self._p['totals'],
+                                          self._p['ttotals'], self._p['dsum'], _ptr(chi), _ptr(hrl),
+                                          float(rel_tol), float(abs_tol),
+                                          1 if check_convergence else 0, int(out_slot)))
+
+    def set_predicate(self, slot):
+        """slot 0/1: everything queued from now on runs only if that flag is 1; None: always."""
+        self._check(self.lib.vilma_set_predicate(self.ctx, -1 if slot is None else int(slot)))
+
+    def spec_save(self):
+        self._check(self.lib.vilma_spec_save(self.ctx))
+
+    def spec_restore(self):
+        self._check(self.lib.vilma_spec_restore(self.ctx))
+
+    def fetch_begin(self, buffer):
+        self._check(self.lib.vilma_fetch_begin(self.ctx, self._stream_handle, self._p['results'],
+                                               self.layout.size, int(buffer)))
+
+    def fetch_end(self, buffer):
+        """(host copy of the result vector, [flag0, flag1]) of a fetch_begin."""
+        flags = (C.c_int * 2)()
+        self._check(self.lib.vilma_fetch_end(self.ctx, int(buffer), self._host_ptr,
+                                             self.layout.size, flags))
+        return self._host.copy(), (flags[0], flags[1])
+
+    def read_decision(self, slot):
+        flag = C.c_int()
+        obj = (C.c_double * 2)()
+        self._check(self.lib.vilma_read_decision(self.ctx, int(slot), C.byref(flag), obj))
+        return flag.value, (obj[0], obj[1])
+
     def delta_sums(self, which=_lib.STATE_CURRENT):
         self._check(self.lib.vilma_delta_sums(self.ctx, self._stream_handle, self._p['sums'],
                                               which))
