@@ -186,18 +186,28 @@ int vilma_fetch(vilma_ctx *ctx, void *stream, const double *src_dev, double *dst
 
 /* ---- decisions on the device, work queued ahead of them ----------------------------------- */
 
-/* The accept test of the beta line search (variational_inference.py:777-787),
- *     new >= orig - rel_tol |orig| - abs_tol,
- * evaluated on the device from the (all-reduced) sums of the current state (totals_dev) and of
- * the trial (ttotals_dev) with the host's own formula (fast_likelihood - _beta_KL assembled as
- * SweepDriver._objective_from does: same operations and order, no fused multiply-add), so host
- * and device always agree.  chi = chi_stat [P]; half_rank_log_tau[p] = 0.5 ld_ranks[p] log tau_p
- * (computed by the host).  With check_convergence != 0 the decision is also 0 when
- * dsum_dev[0] == 0 (no posterior mean moved in the sweep just finished: optimize() stops there).
- * The result goes to flag slot out_slot (0/1) of the context. */
+/* Is the NEXT sweep a standard one?  Evaluated on the device, at the end of the sweep being
+ * closed, from the (all-reduced) sums of the state after its M-step (totals_dev), of the next
+ * sweep's first beta trial (ttotals_dev) and of the convergence statistic (dsum_dev), with the
+ * host's own arithmetic (SweepDriver._objective_from, _update_beta, _nat_grad_step,
+ * _optimize_step: same operations and order, no fused multiply-add), so host and device always
+ * agree.  Flag out_slot (0/1) = 1 iff
+ *   - the trial is accepted: new >= orig - rel_tol |orig| - abs_tol (variational_inference.py:
+ *     777-787), and
+ *   - the inner beta loop ends after it: loop_ends_anyway (L == 1 or L > L_MAX, known to the
+ *     host) or |new - orig| <= 0.1 running', running' = the running ELBO change updated with the
+ *     sweep being closed (:406-409, 432-435): change = delta_beta + (orig - obj_before_mstep);
+ *     running' = 0.5 (running_is_none ? change : running) + 0.5 max(change, 0), and
+ *   - not (check_convergence and dsum_dev[0] == 0): optimize() stops when no posterior mean moved.
+ * chi = chi_stat [P]; half_rank_log_tau[p] = 0.5 ld_ranks[p] log tau_p (computed by the host).
+ * With from_state != 0, delta_beta / obj_before_mstep / running are not taken from the
+ * arguments but from what the previous vilma_decide left on the device (a stage queued ahead of
+ * the host: the host does not know them yet). */
 int vilma_decide(vilma_ctx *ctx, void *stream, const double *totals_dev, const double *ttotals_dev,
                  const double *dsum_dev, const double *chi, const double *half_rank_log_tau,
-                 double rel_tol, double abs_tol, int check_convergence, int out_slot);
+                 double rel_tol, double abs_tol, int check_convergence, int from_state,
+                 int running_is_none, int loop_ends_anyway, double delta_beta,
+                 double obj_before_mstep, double running, int out_slot);
 
 /* Every kernel launched on this context by the calling thread while slot >= 0 first reads flag
  * `slot` and exits if it is 0: the host can queue the M-step, re-evaluation and next trial of a

@@ -79,6 +79,7 @@ def load():
         'vilma_snapshot_mean': (C.c_int, [vp, vp]),
         'vilma_fetch': (C.c_int, [vp, vp, vp, vp, C.c_int64]),
         'vilma_decide': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                    C.c_int]),
         'vilma_set_predicate': (C.c_int, [vp, C.c_int]),
         'vilma_spec_save': (C.c_int, [vp]),

@@ -105,6 +105,7 @@ struct vilma_ctx {
     // whose flag turned out 0.
     int *flags = nullptr;           // device [2]
     double *decide_obj = nullptr;   // device [2]: {orig, new} objective of the last decision
+    double *decide_state = nullptr; // device [3]: what one decision hands to the next (kernels.hip)
     int pred_slot = -1;             // -1: launches are unconditional
     double *landing[2] = {nullptr, nullptr};
     int64_t landing_elems[2] = {0, 0};
@@ -444,6 +445,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     {
         const int ones[2] = {1, 1};
         if (dev_alloc(c, &c->flags, 2) || dev_alloc(c, &c->decide_obj, 2) ||
+            dev_alloc(c, &c->decide_state, 3) ||
             hipMemcpy(c->flags, ones, sizeof(ones), hipMemcpyHostToDevice) != hipSuccess ||
             hipEventCreateWithFlags(&c->landed[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->landed[1], hipEventDisableTiming) != hipSuccess) {
@@ -479,7 +481,7 @@ void vilma_destroy(vilma_ctx *c) {
         if (c->landing[b]) (void)hipHostFree(c->landing[b]);
         if (c->landed[b]) (void)hipEventDestroy(c->landed[b]);
     }
-    dev_free(c->flags); dev_free(c->decide_obj);
+    dev_free(c->flags); dev_free(c->decide_obj); dev_free(c->decide_state);
     if (c->ev_snp) (void)hipEventDestroy(c->ev_snp);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -807,13 +809,16 @@ int vilma_set_predicate(vilma_ctx *c, int slot) {
 
 int vilma_decide(vilma_ctx *c, void *stream, const double *totals_dev, const double *ttotals_dev,
                  const double *dsum_dev, const double *chi, const double *half_rank_log_tau,
-                 double rel_tol, double abs_tol, int check_convergence, int out_slot) {
+                 double rel_tol, double abs_tol, int check_convergence, int from_state,
+                 int running_is_none, int loop_ends_anyway, double delta_beta,
+                 double obj_before_mstep, double running, int out_slot) {
     if (!c) return 1;
     if (out_slot < 0 || out_slot > 1) return fail(c, "flag slot must be 0 or 1");
     if (out_slot == c->pred_slot) return fail(c, "a stage cannot overwrite the flag it runs under");
     launch_decide(c->P, check_convergence, totals_dev, ttotals_dev, dsum_dev, chi, c->tau,
-                  half_rank_log_tau, rel_tol, abs_tol, c->flags + out_slot, c->decide_obj,
-                  (hipStream_t)stream);
+                  half_rank_log_tau, rel_tol, abs_tol, from_state, running_is_none,
+                  loop_ends_anyway, delta_beta, obj_before_mstep, running, c->decide_state,
+                  c->flags + out_slot, c->decide_obj, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

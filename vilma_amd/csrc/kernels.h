@@ -69,7 +69,9 @@ struct SnpKernelArgs {
 void set_launch_predicate(const int *flag);
 void launch_decide(int P, int check_convergence, const double *totals, const double *ttotals,
                    const double *dsum, const double *chi, const double *tau,
-                   const double *half_rank_log_tau, double rel_tol, double abs_tol, int *out_flag,
+                   const double *half_rank_log_tau, double rel_tol, double abs_tol,
+                   int from_state, int running_is_none, int loop_ends_anyway, double delta_beta,
+                   double obj_before_mstep, double running, double *state, int *out_flag,
                    double *out_obj, hipStream_t s);
 
 void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s);

@@ -232,14 +232,19 @@ class HipEngine:
         return self._host.copy()
 
     # ------------------------------------------------------------------ decisions on the device
-    def decide(self, chi, half_rank_log_tau, rel_tol, abs_tol, check_convergence, out_slot):
-        """Queue the line-search accept test on (totals, trial totals[, convergence statistic])
-        of the result vector; the outcome lands in flag slot `out_slot`."""
+    def decide(self, chi, half_rank_log_tau, rel_tol, abs_tol, check_convergence, out_slot,
+               from_state=False, running=None, loop_ends_anyway=True, delta_beta=0.0,
+               obj_before_mstep=0.0):
+        """Queue vilma_decide on (totals, trial totals, convergence statistic) of the result
+        vector; the outcome lands in flag slot `out_slot`.  The defaults reduce it to the plain
+        accept test of the trial."""
         chi, hrl = _f64(chi), _f64(half_rank_log_tau)
-        self._check(self.lib.vilma_decide(self.ctx, self._stream_handle, self._p['totals'],
-                                          self._p['ttotals'], self._p['dsum'], _ptr(chi), _ptr(hrl),
-                                          float(rel_tol), float(abs_tol),
-                                          1 if check_convergence else 0, int(out_slot)))
+        self._check(self.lib.vilma_decide(
+            self.ctx, self._stream_handle, self._p['totals'], self._p['ttotals'], self._p['dsum'],
+            _ptr(chi), _ptr(hrl), float(rel_tol), float(abs_tol), 1 if check_convergence else 0,
+            1 if from_state else 0, 1 if running is None else 0, 1 if loop_ends_anyway else 0,
+            float(delta_beta), float(obj_before_mstep), 0.0 if running is None else float(running),
+            int(out_slot)))
 
     def set_predicate(self, slot):
         """slot 0/1: everything queued from now on runs only if that flag is 1; None: always."""
