@@ -259,9 +259,12 @@ def main():
     setup_s = time.perf_counter() - t_setup
     elbo0 = driver._objective
 
+    # lookahead: the driver may queue the next sweep's M-step stage ahead of its line-search
+    # decision (taken on the device).  The last warm-up sweep and the last timed sweep do not
+    # look ahead, so exactly the K timed sweeps' work runs inside the timed region.
     state = None
-    for _ in range(args.warmup):
-        state, _ = driver.sweep(state)
+    for w in range(args.warmup):
+        state, _ = driver.sweep(state, lookahead=w + 1 < args.warmup)
     if state is None:
         engine.snapshot_mean()
         state = {'L': np.ones(5), 'elbo': driver._objective, 'running': None}
@@ -269,14 +272,14 @@ def main():
     prof_every = args.prof_every or (1 if (world == 1 and args.emulate_shard <= 1) else 8)
     engine.prof_enable(True, every=prof_every)
     engine.prof_read(reset=True)
-    ev0, tr0 = driver.n_evaluations, driver.n_trials
+    ev0, tr0, ah0 = driver.n_evaluations, driver.n_trials, driver.n_stages_ahead
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     elbos = []
-    for _ in range(args.steps):
-        state, _ = driver.sweep(state)
+    for k in range(args.steps):
+        state, _ = driver.sweep(state, lookahead=k + 1 < args.steps)
         elbos.append(state['elbo'])
     torch.cuda.synchronize()
     if world > 1:
@@ -344,6 +347,7 @@ def main():
             'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
             'points_evaluated_per_sweep': n_eval / args.steps,
             'beta_trials_per_sweep': (driver.n_trials - tr0) / args.steps,
+            'sweeps_queued_ahead_of_their_decision': driver.n_stages_ahead - ah0,
             'elbo_start': elbo0, 'elbo_end': elbos[-1] if elbos else elbo0,
             'setup_seconds': setup_s,
         },

@@ -82,6 +82,15 @@ def load():
         'vilma_mean_diff': (C.c_int, [vp, vp, vp, vp]),
         'vilma_snapshot_mean': (C.c_int, [vp, vp]),
         'vilma_fetch': (C.c_int, [vp, vp, vp, vp, C.c_int64]),
+        'vilma_decide': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                   C.c_int, vp, C.c_int64]),
+        'vilma_set_predicate': (C.c_int, [vp, C.c_int]),
+        'vilma_spec_save': (C.c_int, [vp]),
+        'vilma_spec_restore': (C.c_int, [vp]),
+        'vilma_fetch_begin': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
+        'vilma_fetch_end': (C.c_int, [vp, C.c_int, vp, C.c_int64, vp]),
+        'vilma_read_decision': (C.c_int, [vp, C.c_int, vp, vp]),
         'vilma_prof_enable': (C.c_int, [vp, C.c_int]),
         'vilma_prof_read': (C.c_int, [vp, _c_double_p, _c_i64_p, C.c_int]),
     }

@@ -72,7 +72,19 @@ struct SnpKernelArgs {
     int32_t diff;             // fuse the convergence statistics into this evaluation
     double step;
     TauArg tau;
+    const int *pred;          // filled by the launcher (set_launch_predicate)
 };
+
+// launch attribute of the calling thread: kernels launched while it is set exit at once when
+// *flag == 0 (work queued ahead of a device-side decision); nullptr = unconditional
+void set_launch_predicate(const int *flag);
+void launch_decide(int P, int check_convergence, const double *totals, const double *ttotals,
+                   const double *dsum, const double *chi, const double *tau,
+                   const double *half_rank_log_tau, double rel_tol, double abs_tol,
+                   int from_state, int running_is_none, int loop_ends_anyway, double delta_beta,
+                   double obj_before_mstep, double running, double *state, int *out_flag,
+                   double *out_obj, const double *results, int n_results, double *snap,
+                   const int *flags, hipStream_t s);
 
 void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s);
 int snp_pass_grid(int64_t N);
@@ -100,6 +112,7 @@ struct DeltaArgs {
     const double *lse;        // [N]
     double *out;              // mode 0: partial rows [grid*4][A*M]; mode 1: delta [M][N]
     TauArg tau;
+    const int *pred;          // filled by the launcher (set_launch_predicate)
 };
 void launch_delta_sums(const DeltaArgs &a, double *sums_out /*[A*M]*/, hipStream_t s);
 void launch_delta_write(const DeltaArgs &a, hipStream_t s);

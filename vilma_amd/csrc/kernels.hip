@@ -93,15 +93,23 @@ typedef const v2d __attribute__((address_space(1))) *gd2_ptr;
 #else
 #define MU_STORE(p, v) (*(p) = (v))
 #endif
+// Predicated launches: when the host queues work ahead of a decision that a device kernel takes
+// (decide_kernel), every kernel of that work starts by reading the decision's flag and exits if
+// it is 0 -- mis-speculated work costs a few microseconds of empty launches and touches nothing.
+// The flag pointer is a per-thread launch attribute (set_launch_predicate), nullptr = always run.
+static thread_local const int *g_pred = nullptr;
+void set_launch_predicate(const int *flag) { g_pred = flag; }
+#define PRED_EXIT(pred) do { if ((pred) != nullptr && *(pred) == 0) return; } while (0)
 
 typedef const double __attribute__((address_space(4))) *const_tab;
 static __device__ __forceinline__ const_tab as_table(const double *p) { return (const_tab)p; }
 
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
     const LdItem *__restrict__ items, const double *__restrict__ xpool, double *__restrict__ ypool,
-    const double *__restrict__ dpool, double *__restrict__ dot_partials) {
+    const double *__restrict__ dpool, double *__restrict__ dot_partials, const int *pred) {
     __shared__ double red[CS_WAVES][128];
     __shared__ double dred[2];
+    PRED_EXIT(pred);
     const LdItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -164,7 +172,7 @@ void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *do
     // x, y and the dot vector live in one pool; within a launch the regions read and written
     // are disjoint, so handing the same base to the three restrict parameters is sound
     hipLaunchKernelGGL(ld_colsum_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items,
-                       (const double *)pool, pool, (const double *)pool, dot_partials);
+                       (const double *)pool, pool, (const double *)pool, dot_partials, g_pred);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -270,9 +278,10 @@ static __device__ __forceinline__ void sym_group_diag(const double *__restrict__
 
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     const SymItem *__restrict__ items, const double *__restrict__ xpool,
-    double *__restrict__ scratch) {
+    double *__restrict__ scratch, const int *pred) {
     __shared__ double red[CS_WAVES][128];
     __shared__ double rs_diag[128];
+    PRED_EXIT(pred);
     const SymItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -335,8 +344,9 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
 __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
     const SymCombItem *__restrict__ items, const double *__restrict__ xpool,
     double *__restrict__ ypool, const double *__restrict__ scratch,
-    double *__restrict__ dot_partials) {
+    double *__restrict__ dot_partials, const int *pred) {
     __shared__ double dred[4];
+    PRED_EXIT(pred);
     const SymCombItem it = items[blockIdx.x];
     const int j = it.j0 + threadIdx.x;
     const bool live = j < it.n;
@@ -371,14 +381,15 @@ __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
 void launch_ld_sym(const SymItem *items, int n_items, const double *pool, double *scratch,
                    hipStream_t s) {
     if (n_items <= 0) return;
-    hipLaunchKernelGGL(ld_sym_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pool, scratch);
+    hipLaunchKernelGGL(ld_sym_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pool, scratch,
+                       g_pred);
 }
 
 void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
                            const double *scratch, double *dot_partials, hipStream_t s) {
     if (n_items <= 0) return;
     hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items), dim3(256), 0, s, items,
-                       (const double *)pool, pool, scratch, dot_partials);
+                       (const double *)pool, pool, scratch, dot_partials, g_pred);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -493,6 +504,7 @@ template <int P, bool BLEND, bool ONE_ANNOT>
 __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
     constexpr int NT = 2 * P + 2;
     __shared__ double red[SNP_THREADS / 64][NT < 6 ? 6 : NT];
+    PRED_EXIT(a.pred);
     const int N = a.N, M = a.M;
     const int64_t N64 = N;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -729,7 +741,9 @@ static void launch_snp_pass_p(const SnpKernelArgs &a, bool blend, hipStream_t s)
     }
 }
 
-void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s) {
+void launch_snp_pass(const SnpKernelArgs &args, bool blend, hipStream_t s) {
+    SnpKernelArgs a = args;
+    a.pred = g_pred;
     switch (a.P) {
         case 1: launch_snp_pass_p<1>(a, blend, s); break;
         case 2: launch_snp_pass_p<2>(a, blend, s); break;
@@ -750,6 +764,7 @@ void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s) {
 template <int P, bool ONE_ANNOT, bool WRITE, int KS>
 __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     constexpr int SPW = 64 / KS;
+    PRED_EXIT(a.pred);
     const int N = a.N, M = a.M, A = a.A;
     const int64_t N64 = N;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -851,8 +866,10 @@ int delta_grid(int64_t N) {
 // twice (rows -> RC_CHUNKS partial rows -> 1 row) so the long reduction is spread over the chip.
 #define RC_CHUNK_ROWS 256
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const double *__restrict__ in, int rows,
-                                                           int ncols, double *__restrict__ out) {
+                                                           int ncols, double *__restrict__ out,
+                                                           const int *pred) {
     __shared__ double red[4][64];
+    PRED_EXIT(pred);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * RC_CHUNK_ROWS;
@@ -897,12 +914,13 @@ static void reduce_cols(const double *in, int rows, int ncols, double *scratch, 
     while (rows > RC_CHUNK_ROWS) {
         const int chunks = (rows + RC_CHUNK_ROWS - 1) / RC_CHUNK_ROWS;
         hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, chunks), dim3(256), 0, s, in, rows,
-                           ncols, scratch);
+                           ncols, scratch, g_pred);
         in = scratch;
         scratch = scratch + (int64_t)chunks * ncols;
         rows = chunks;
     }
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, 1), dim3(256), 0, s, in, rows, ncols, out);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, 1), dim3(256), 0, s, in, rows, ncols, out,
+                       g_pred);
 }
 
 template <int P, bool WRITE, int KS>
@@ -919,7 +937,9 @@ static void launch_delta_p(const DeltaArgs &a, hipStream_t s) {
 }
 
 template <bool WRITE>
-static void launch_delta_any(const DeltaArgs &a, hipStream_t s) {
+static void launch_delta_any(const DeltaArgs &args, hipStream_t s) {
+    DeltaArgs a = args;
+    a.pred = g_pred;
     switch (a.P) {
         case 1: launch_delta_p<1, WRITE>(a, s); break;
         case 2: launch_delta_p<2, WRITE>(a, s); break;
@@ -1269,8 +1289,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
                                                         const DotStart dot_start,
                                                         double *__restrict__ totals,
                                                         double *__restrict__ dsum,
-                                                        double *__restrict__ dmax) {
+                                                        double *__restrict__ dmax, const int *pred) {
     __shared__ double sh[4];
+    PRED_EXIT(pred);
     const int NT = 2 * P + 2;
     const int c = blockIdx.x;
     const double *src;
@@ -1321,7 +1342,7 @@ void launch_finalize(const double *snp_partials, int snp_rows, int P, const doub
     for (int p = 0; p <= VILMA_MAX_P; ++p) ds.v[p] = p <= P ? dot_start[p] : 0;
     const int extra = (dsum != nullptr && dmax != nullptr) ? 6 : 0;
     hipLaunchKernelGGL(finalize_kernel, dim3(3 * P + 2 + extra), dim3(256), 0, s, snp_partials,
-                       snp_rows, P, dot_partials, ds, totals, dsum, dmax);
+                       snp_rows, P, dot_partials, ds, totals, dsum, dmax, g_pred);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1363,8 +1384,10 @@ void launch_scatter_y(const double *pool_y, const int32_t *invperm, double *y_sn
 __global__ __launch_bounds__(256) void mean_diff_kernel(const double *__restrict__ m_cur,
                                                          const double *__restrict__ scalings,
                                                          double *__restrict__ snapshot, int64_t PN,
-                                                         double *__restrict__ partials, int compare) {
+                                                         double *__restrict__ partials, int compare,
+                                                         const int *pred) {
     __shared__ double red[4][6];
+    PRED_EXIT(pred);
     double v[6] = {0, 0, 0, 0, 0, 0};
     const int64_t base = (int64_t)blockIdx.x * 256 * MD_PER_THREAD + threadIdx.x;
 #pragma unroll
@@ -1402,8 +1425,10 @@ __global__ __launch_bounds__(256) void mean_diff_kernel(const double *__restrict
 
 __global__ __launch_bounds__(1024) void mean_diff_final_kernel(const double *__restrict__ partials,
                                                                 int rows, double *__restrict__ out_sum,
-                                                                double *__restrict__ out_max) {
+                                                                double *__restrict__ out_max,
+                                                                const int *pred) {
     __shared__ double sh[16][6];
+    PRED_EXIT(pred);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int r = threadIdx.x; r < rows; r += 1024) {
@@ -1436,10 +1461,10 @@ void launch_mean_diff(const double *m_cur, const double *scalings, double *snaps
                       hipStream_t s) {
     const int grid = mean_diff_grid(PN);
     hipLaunchKernelGGL(mean_diff_kernel, dim3(grid), dim3(256), 0, s, m_cur, scalings, snapshot, PN,
-                       partials, compare ? 1 : 0);
+                       partials, compare ? 1 : 0, g_pred);
     if (compare)
         hipLaunchKernelGGL(mean_diff_final_kernel, dim3(1), dim3(1024), 0, s, partials, grid,
-                           out_sum3, out_max3);
+                           out_sum3, out_max3, g_pred);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1475,8 +1500,9 @@ __global__ __launch_bounds__(256) void mstep_kernel(const double *__restrict__ s
                                                      const double *__restrict__ counts,
                                                      const double *__restrict__ log_det, int M,
                                                      double *__restrict__ hyper,
-                                                     double *__restrict__ lh) {
+                                                     double *__restrict__ lh, const int *pred) {
     __shared__ double red[4];
+    PRED_EXIT(pred);
     const int a = blockIdx.x;
     const double inv = 1.0 / (counts[a] + 1e-100);
     double part = 0.0;
@@ -1494,5 +1520,119 @@ __global__ __launch_bounds__(256) void mstep_kernel(const double *__restrict__ s
 
 void launch_mstep(const double *sums, const double *counts, const double *log_det, int A, int M,
                   double *hyper, double *lh, hipStream_t s) {
-    hipLaunchKernelGGL(mstep_kernel, dim3(A), dim3(256), 0, s, sums, counts, log_det, M, hyper, lh);
+    hipLaunchKernelGGL(mstep_kernel, dim3(A), dim3(256), 0, s, sums, counts, log_det, M, hyper, lh,
+                       g_pred);
+}
+
+// --------------------------------------------------------------------------------------------
+// The line-search decision on the device (variational_inference.py:777-787): accept the beta
+// trial iff  new >= orig - 1e-6 |orig| - 1e-6,  both objectives assembled from the (all-reduced)
+// sums exactly as the host does (SweepDriver._objective_from: same operations, same order, no
+// fused multiply-add), so host and device can never disagree.  Optionally the previous sweep's
+// convergence statistic vetoes (optimize() stops when no posterior mean moved: nothing queued
+// behind that point may run).  Work queued behind this kernel is predicated on out_flag.
+// --------------------------------------------------------------------------------------------
+struct DecideArgs {
+    int32_t P, check_convergence, from_state, running_is_none, loop_ends_anyway;
+    const double *totals;        // [3P+2] of the state after the M-step of the sweep being closed
+    const double *ttotals;       // [3P+2] of the next sweep's first beta trial
+    const double *dsum;          // [3]; dsum[0] = number of posterior means that moved
+    double chi[VILMA_MAX_P], tau[VILMA_MAX_P], half_rank_log_tau[VILMA_MAX_P];
+    double rel_tol, abs_tol;
+    double delta_beta;           // host: objective gained by the beta stage of the sweep being closed
+    double obj_before_mstep;     // host: objective the M-step of that sweep started from
+    double running;              // host: running_elbo_delta at the start of that sweep
+    double *state;               // device [3] = {objective after the M-step, objective of the
+                                 //               accepted trial, running_elbo_delta}
+    const int *pred;             // the stage this decision belongs to may itself be mis-speculated
+    const double *results;       // result vector to snapshot for the host (with both flags behind
+    int32_t n_results;           // it), or snap == nullptr
+    double *snap;
+    const int *flags;            // [2]
+    int *out_flag;
+    double *out_obj;             // [2] = {orig, new} (for tests / host cross-check), may be null
+};
+
+static __device__ double objective_from(const DecideArgs &a, const double *t) {
+#pragma clang fp contract(off)
+    const int P = a.P;
+    double lik = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const double inner = ((-0.5 * (t[P + p] + t[2 * P + p]) + t[p]) - 0.5 * a.chi[p]) / a.tau[p];
+        lik = lik + (inner - a.half_rank_log_tau[p]);
+    }
+    return lik - (t[3 * P] + t[3 * P + 1]);
+}
+
+// flag = 1 iff the next sweep is a "standard" one as far as the device can tell: its first beta
+// trial is accepted AND the inner beta loop ends after it (variational_inference.py:432-435:
+// |new - orig| <= 0.1 running_elbo_delta, with the running value updated from the sweep being
+// closed exactly as _optimize_step does, :406-409) AND optimize() does not stop on convergence.
+__global__ __launch_bounds__(256) void decide_kernel(const DecideArgs a) {
+#pragma clang fp contract(off)
+    if (threadIdx.x == 0) {
+        if (a.pred != nullptr && *a.pred == 0) {
+            *a.out_flag = 0;
+        } else {
+            const double orig = objective_from(a, a.totals);
+            const double fresh = objective_from(a, a.ttotals);
+            double delta_beta = a.delta_beta, before = a.obj_before_mstep, running = a.running;
+            int running_is_none = a.running_is_none;
+            if (a.from_state) {
+                delta_beta = a.state[1] - a.state[0];
+                before = a.state[1];
+                running = a.state[2];
+                running_is_none = 0;
+            }
+            const double change = delta_beta + (orig - before);
+            double r = running_is_none ? change : running;
+            r = r * 0.5;
+            r = r + 0.5 * (change > 0.0 ? change : 0.0);
+            const double conv_tol = 0.1 * r;
+            const bool accept = fresh >= (orig - a.rel_tol * fabs(orig)) - a.abs_tol;
+            const bool ends = a.loop_ends_anyway || fabs(fresh - orig) <= conv_tol;
+            int ok = (accept && ends) ? 1 : 0;
+            if (a.check_convergence && a.dsum[0] == 0.0) ok = 0;
+            *a.out_flag = ok;
+            if (ok) { a.state[0] = orig; a.state[1] = fresh; a.state[2] = r; }
+            if (a.out_obj) { a.out_obj[0] = orig; a.out_obj[1] = fresh; }
+        }
+    }
+    // Snapshot of the result vector + both flags for the host, taken HERE, in stream order, so
+    // the device->host copy can run on its own stream while the next stage already overwrites the
+    // result vector.  (A dead stage still reports its flags; the rest of its snapshot is stale.)
+    if (a.snap == nullptr) return;
+    __syncthreads();
+    const bool dead = a.pred != nullptr && *a.pred == 0;
+    if (!dead)
+        for (int t = threadIdx.x; t < a.n_results; t += blockDim.x) a.snap[t] = a.results[t];
+    if (threadIdx.x == 0) {
+        a.snap[a.n_results] = (double)a.flags[0];
+        a.snap[a.n_results + 1] = (double)a.flags[1];
+    }
+}
+
+void launch_decide(int P, int check_convergence, const double *totals, const double *ttotals,
+                   const double *dsum, const double *chi, const double *tau,
+                   const double *half_rank_log_tau, double rel_tol, double abs_tol,
+                   int from_state, int running_is_none, int loop_ends_anyway, double delta_beta,
+                   double obj_before_mstep, double running, double *state, int *out_flag,
+                   double *out_obj, const double *results, int n_results, double *snap,
+                   const int *flags, hipStream_t s) {
+    DecideArgs a;
+    a.P = P; a.check_convergence = check_convergence;
+    a.from_state = from_state; a.running_is_none = running_is_none;
+    a.loop_ends_anyway = loop_ends_anyway;
+    a.totals = totals; a.ttotals = ttotals; a.dsum = dsum;
+    for (int p = 0; p < VILMA_MAX_P; ++p) {
+        a.chi[p] = p < P ? chi[p] : 0.0;
+        a.tau[p] = p < P ? tau[p] : 1.0;
+        a.half_rank_log_tau[p] = p < P ? half_rank_log_tau[p] : 0.0;
+    }
+    a.rel_tol = rel_tol; a.abs_tol = abs_tol;
+    a.delta_beta = delta_beta; a.obj_before_mstep = obj_before_mstep; a.running = running;
+    a.state = state;
+    a.pred = g_pred; a.out_flag = out_flag; a.out_obj = out_obj;
+    a.results = results; a.n_results = n_results; a.snap = snap; a.flags = flags;
+    hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, s, a);
 }

@@ -19,6 +19,7 @@ where the work happens:
     sums are all-reduced (RCCL) before every decision, so all ranks take the same branch.
 """
 import logging
+import os
 import math
 
 import numpy as np
@@ -141,19 +142,29 @@ class SweepDriver:
         self._verbose = False
         self._log_info = False
         self._views = {}            # slices of the engine's result vector handed to all-reduces
+        # decisions on the device (engine.decide): the stage queued ahead of its decision
+        self._look_ok = False       # the caller promises another standard sweep after this one
+        self._veto = self._veto_next = False    # convergence vetoes of this / the next sweep
+        self._ahead = None          # stage pre-queued for the NEXT sweep: {'pred','out'}
+        self._mine = None           # this sweep's stage when it was pre-queued and confirmed
+        self._pending_flag = None   # device decision that came with the pending trial
+        self._half_rank_log_tau = None
         self._version = 0           # bumped whenever the device state moves
         self._hyper = None
         self._totals = None         # all-reduced sums of the current (accepted) state
         self._objective = None
         self.n_evaluations = 0      # candidate points evaluated (= LD products per cohort)
         self.n_trials = 0           # beta line-search trials among them
+        self.n_stages_ahead = 0     # sweeps whose M-step stage ran ahead of the host's decision
         self.num_its_run = 0
 
     def start_from(self, vi_mu_local, hyper):
         """Make (vi_mu of this shard, hyper_delta) the current state and evaluate it.
         vi_mu_local = None: the device already holds vi_mu (engine.init_state)."""
+        self._drop_ahead()
         self._pending = None
         self._given = None
+        self._half_rank_log_tau = None
         self.engine.set_tau(self.error_scaling)
         self._set_hyper(hyper)
         if vi_mu_local is not None:
@@ -204,6 +215,7 @@ class SweepDriver:
         """Objective of the CURRENT vi_mu under the current hyper/tau.  The evaluated point
         stays on the device as the trial state."""
         L = self.engine.layout
+        self._drop_ahead()
         self._pending = None            # a queued trial's buffers are about to be overwritten
         self.engine.eval()
         host = self._fetch(L.totals.start, L.totals.stop)
@@ -227,9 +239,12 @@ class SweepDriver:
         the previous sweep's last evaluation if there is one for this step, else queue it now."""
         L = self.engine.layout
         pend, self._pending = self._pending, None
+        self._pending_flag = None
         if pend is not None and pend['step'] == step:
             host = pend['host']
+            self._pending_flag = pend.get('flag')
         else:
+            self._drop_ahead()
             self._launch_trial(step)
             host = self._fetch(L.ttotals.start, L.sums.stop)
         totals = host[L.ttotals]
@@ -238,8 +253,9 @@ class SweepDriver:
         self.n_trials += 1
         return self._objective_from(totals), totals
 
-    def _accept(self, take_mu, obj, totals):
-        self.engine.accept(take_mu)
+    def _accept(self, take_mu, obj, totals, already_flipped=False):
+        if not already_flipped:
+            self.engine.accept(take_mu)
         self._objective, self._totals = obj, totals
         # responsibility sums fetched with the candidate now describe the current state
         self._cur_sums, self._trial_sums = self._trial_sums, None
@@ -346,10 +362,23 @@ class SweepDriver:
                 logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
             # scalar arithmetic on Python floats: np.isclose & co cost ~20 us per call, which is
             # visible next to a 150 us evaluation on an 8-GPU shard
-            if new_obj >= orig_obj - REL_TOL * abs(orig_obj) - ABS_TOL:
+            accepted = new_obj >= orig_obj - REL_TOL * abs(orig_obj) - ABS_TOL
+            ahead, self._ahead = self._ahead, None
+            if ahead is not None:
+                # a stage was queued behind this trial, predicated on the device's own accept
+                # test (same arithmetic: the two can only differ through the convergence veto)
+                ran = bool(self._pending_flag)
+                if ran and not accepted:
+                    raise RuntimeError('device and host line-search decisions disagree')
+                if ran:
+                    self._mine = ahead
+                    self.n_stages_ahead += 1
+                else:
+                    self.engine.spec_restore()      # its kernels exited; undo its index flips
+            if accepted:
                 if L[idx] > L_MAX and not np.isclose(orig_obj, new_obj):
                     raise RuntimeError('Encountered a numerical error.')
-                self._accept(True, new_obj, totals)
+                self._accept(True, new_obj, totals, already_flipped=self._mine is not None)
                 return orig_obj, new_obj
             if L[idx] > L_MAX:
                 if not np.isclose(orig_obj, new_obj):
@@ -366,19 +395,49 @@ class SweepDriver:
         known from L alone) can be queued right behind it and fetched in the same round trip."""
         eng = self.engine
         L = eng.layout
-        if self._cur_sums is None:
-            # no accepted beta step since the last evaluation (line search gave up or resumed
-            # state): compute the statistic of the current state now
-            sums = eng.delta_sums()
-            if self.comm.active:
-                self.comm.allreduce_inplace(sums)
-        # otherwise the sums of the accepted trial are still in the result vector (all-reduced)
-        eng.mstep()
-        eng.eval(diff=with_diff)        # the convergence statistics ride in the same pass
-        eng.accept(False)
+        mine, self._mine = self._mine, None
+        look = self._may_look_ahead(with_diff, next_step)
         lo = L.dsum.start if with_diff else L.totals.start
-        if next_step is not None:
-            self._launch_trial(next_step)
+        flag = None
+        if mine is None:
+            if self._cur_sums is None:
+                # no accepted beta step since the last evaluation (line search gave up or
+                # resumed state): compute the statistic of the current state now
+                sums = eng.delta_sums()
+                if self.comm.active:
+                    self.comm.allreduce_inplace(sums)
+            # otherwise the sums of the accepted trial are still in the result vector
+            # (all-reduced)
+            self._queue_mstep_stage(with_diff, next_step)
+            if look:
+                out = 0
+                info = self._look
+                self._queue_decision(lo, self._veto, out, from_state=False,
+                                     running=info['running'], ends=info['ends_next'],
+                                     delta_beta=info['delta_beta'], before=orig_obj)
+        else:
+            # this sweep's stage was queued ahead of its decision and has run: M-step,
+            # re-evaluation, statistics, next trial, that trial's decision, result copy
+            if not (with_diff and next_step == mine['step']):
+                raise RuntimeError('a stage queued ahead does not match the sweep it belongs to')
+            out = mine['out']
+        if look:
+            # queue the NEXT sweep's stage behind the decision just queued, then collect this
+            # sweep's results: the device never waits for the host on an accepted trial
+            step_after = self._look['step_after']
+            eng.spec_save()
+            eng.set_predicate(out)
+            eng.accept(True)
+            self._queue_mstep_stage(True, step_after, launch_only=True)
+            self._queue_decision(lo, self._veto_next, 1 - out, from_state=True,
+                                 ends=self._look['ends_after'])
+            eng.set_predicate(None)
+            self._ahead = {'pred': out, 'out': 1 - out, 'step': step_after}
+        if look or mine is not None:
+            host, flags = eng.fetch_end(out)
+            flag = flags[out]
+            self._pending = {'step': next_step, 'host': host, 'flag': flag}
+        elif next_step is not None:
             host = self._fetch(lo, L.sums.stop, with_max=with_diff)
             self._pending = {'step': next_step, 'host': host}
         else:
@@ -395,6 +454,66 @@ class SweepDriver:
             logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
         return orig_obj, new_obj
 
+    def _queue_mstep_stage(self, with_diff, next_step, launch_only=False):
+        """The device work of one M-step: new hyper_delta from the sums in the result vector,
+        re-evaluation, convergence statistics and the next sweep's first beta trial."""
+        eng = self.engine
+        eng.mstep()
+        eng.eval(diff=with_diff)        # the convergence statistics ride in the same pass
+        eng.accept(False)
+        if next_step is not None:
+            if launch_only:
+                from . import _lib
+                eng.trial(next_step)
+                eng.delta_sums(_lib.STATE_TRIAL_BETA)
+            else:
+                self._launch_trial(next_step)
+
+    def _queue_decision(self, lo, veto, out_slot, from_state, ends, running=None, delta_beta=0.0,
+                        before=0.0):
+        """All-reduce what ranks must agree on, take the line-search decision of the trial
+        just queued on the device (flag `out_slot`) and start copying the results out."""
+        eng = self.engine
+        if self.comm.active:
+            L = eng.layout
+            view = self._views.get((lo, L.sums.stop))
+            if view is None:
+                view = self._views[(lo, L.sums.stop)] = eng.results[lo:L.sums.stop]
+            self.comm.allreduce_inplace(view)
+        if self._half_rank_log_tau is None:
+            self._half_rank_log_tau = np.array(
+                [0.5 * self.ld_ranks[p] * math.log(self.error_scaling[p])
+                 for p in range(self.num_pops)])
+        # with from_state the device takes the sweep's ELBO change and the running value from
+        # what the previous decision left there (the host does not know them yet)
+        eng.decide(self.chi_stat, self._half_rank_log_tau, REL_TOL, ABS_TOL, veto, out_slot,
+                   from_state=from_state, running=running if not from_state else 0.0,
+                   loop_ends_anyway=ends, delta_beta=delta_beta, obj_before_mstep=before,
+                   snapshot=True)
+        eng.fetch_begin(out_slot, snapshot=True)
+
+    def _may_look_ahead(self, with_diff, next_step):
+        """Queue the next sweep's stage ahead of its decision?  The device can tell a standard
+        sweep (first beta trial accepted, inner loop ends after it) on its own; not with an
+        error-scaling update or per-sweep logging in the sweep, and only if the caller has
+        promised that another sweep follows."""
+        return bool(self._look_ok and with_diff and next_step is not None and not self.scale_se
+                    and not self._verbose and hasattr(self.engine, 'decide')
+                    and 1. / next_step * 1.25 < L_MAX
+                    and os.environ.get('VILMA_LOOKAHEAD', '1') != '0')
+
+    def _drop_ahead(self):
+        """Forget a stage queued ahead whose decision is not going to be looked at through the
+        normal path (its trial is not the one wanted): wait for it and undo it if it did not
+        run."""
+        ahead, self._ahead = self._ahead, None
+        if ahead is None:
+            return
+        _, flags = self.engine.fetch_end(ahead['out'])
+        if flags[ahead['pred']]:
+            raise RuntimeError('a stage queued ahead ran although its sweep was abandoned')
+        self.engine.spec_restore()
+
     def _update_error_scaling(self):
         """EM update of the SE scaling (variational_inference.py:472-486, 735-738) from the
         sums of the current state; the sigma-dependent constants follow tau inside the kernels."""
@@ -402,6 +521,7 @@ class SweepDriver:
         t = self._totals
         lin, var, quad = t[:P], t[P:2 * P], t[2 * P:3 * P]
         self.error_scaling = (self.chi_stat - 2 * lin + quad + var) / self.ld_ranks
+        self._half_rank_log_tau = None
         self.engine.set_tau(self.error_scaling)
 
     def _nat_grad_step(self, L, line_search_rate, running_elbo_delta=None):
@@ -421,6 +541,8 @@ class SweepDriver:
             # == np.isclose(new_obj - orig_obj, 0, atol=conv_tol, rtol=0) for finite objectives
             if abs(new_obj - orig_obj) <= conv_tol or L[0] == 1 or L[0] > L_MAX:
                 break
+            if self._mine is not None:
+                raise RuntimeError('device and host disagree on the end of the beta loop')
             orig_obj = new_obj
         # ---- paramset 1: mixture weights (L[1] stays 1, so exactly one pass)
         L[1] = max([1., L[1] / 1.25])
@@ -429,7 +551,12 @@ class SweepDriver:
         # without --learn-scaling this is the last evaluation of the sweep: piggy-back the
         # convergence statistics on its download
         last = not self.scale_se
-        spec = 1. / max([1., L[0] / 1.25]) if (self._speculate and last) else None
+        next_L = max([1., L[0] / 1.25])          # L of the next sweep's first trial
+        spec = 1. / next_L if (self._speculate and last) else None
+        after_L = max([1., next_L / 1.25])       # ... and of the sweep after, if that one is accepted
+        self._look = {'delta_beta': delta_sum, 'running': running_elbo_delta,
+                      'ends_next': bool(next_L == 1), 'ends_after': bool(after_L == 1),
+                      'step_after': 1. / after_L}
         orig_obj, new_obj = self._update_hyper_delta(self._objective,
                                                      with_diff=self._want_diff and last,
                                                      next_step=spec)
@@ -478,13 +605,18 @@ class SweepDriver:
         host = self._fetch(L.dsum.start, L.dsum.stop, with_max=True)
         return np.concatenate([host[L.dsum], host[L.dmax]])
 
-    def sweep(self, state=None):
+    def sweep(self, state=None, lookahead=False):
         """One outer iteration as optimize() runs it: _optimize_step + convergence statistics.
-        `state` carries (L, elbo, running_elbo_delta) between calls; returns (state, stats)."""
+        `state` carries (L, elbo, running_elbo_delta) between calls; returns (state, stats).
+        lookahead=True promises that sweep() is called again: in the steady state the next
+        sweep's M-step stage is then queued ahead of its line-search decision, which the device
+        takes itself (the state reported by this call is still the state after THIS sweep; the
+        device may already be one sweep further)."""
         if state is None:
             self.engine.snapshot_mean()
             state = {'L': np.ones(5), 'elbo': self._objective, 'running': None}
         self._want_diff, self._last_diff, self._speculate = True, None, True
+        self._look_ok, self._veto, self._veto_next = bool(lookahead), False, False
         _, L, elbo, running = self._optimize_step(self._params(), L=state['L'],
                                                    curr_elbo=state['elbo'], line_search_rate=2.,
                                                    running_elbo_delta=state['running'])
@@ -527,6 +659,18 @@ class SweepDriver:
                     np.savez(fname, **dump)
                 if verbose:
                     ckp_mean = self.real_posterior_mean(params)
+            # May the device run ahead of the host through the NEXT sweep's decision?  Only if
+            # this sweep cannot end the loop on a criterion the device does not see: the sweep
+            # count and the running-ELBO rule (running_s >= MOMENTUM * running_{s-1}, so it
+            # stays above the tolerance whenever MOMENTUM * |running| does); "no posterior mean
+            # moved" is vetoed on the device itself; checkpoints need the state of their sweep.
+            fresh_start = num_its < 10 and loaded_checkpoint is None
+            self._veto = not fresh_start
+            self._veto_next = not (num_its + 1 < 10 and loaded_checkpoint is None)
+            self._look_ok = (num_its + 1 < self.num_its
+                             and (fresh_start or (running is not None and
+                                                  ELBO_MOMENTUM * abs(running) > ELBO_TOL))
+                             and not (self.checkpoint and (num_its + 1) % self.checkpoint_freq == 0))
             params, L, elbo, running = self._optimize_step(
                 params, L=L, curr_elbo=elbo, line_search_rate=2., running_elbo_delta=running)
             d = self._diff_stats()
@@ -537,6 +681,8 @@ class SweepDriver:
             if verbose:
                 self._dump_info(num_its, d, n_total, params, ckp_mean)
             num_its += 1
+        self._look_ok = False
+        self._drop_ahead()              # a stage vetoed by convergence: undo its bookkeeping
         self._speculate, self._pending = False, None
         if num_its == self.num_its:
             logging.warning('Failed to converge')
