@@ -32,10 +32,11 @@ struct CohortLd {
     int64_t n_ld = 0;
     double *store = nullptr;
     int64_t store_elems = 0, store_used = 0;
-    int32_t next_start = 0, t_used = 0;
+    int32_t next_start = 0;
+    int64_t t_used = 0;
     std::vector<BlockRec> blocks;
     int64_t alg_bytes = 0;
-    int32_t s_used = 0;                            // scratch entries of the symmetric product
+    int64_t s_used = 0;                            // scratch entries of the symmetric product
 };
 
 // device-resident work lists of one LD product (all cohorts, or one cohort)
@@ -270,6 +271,21 @@ int ensure_ready(vilma_ctx *c) {
     for (int p = 0; p < c->P; ++p)
         if (!c->ld[p].ended) return fail(c, "LD for cohort " + std::to_string(p) + " not loaded");
     free_ready(c);
+    // work items carry 32-bit offsets into the vector pool and the scratch: check the totals
+    // BEFORE any offset is formed
+    {
+        int64_t t_total = 0, s_total = 0;
+        for (int p = 0; p < c->P; ++p) { t_total += c->ld[p].t_used; s_total += c->ld[p].s_used; }
+        const int64_t pool_total = 2 * (int64_t)c->P * c->N + t_total + 2;
+        if (pool_total >= (int64_t)1 << 31)
+            return fail(c, "shard too large: the vector pool (2 P N + eigen-form scratch = " +
+                           std::to_string(pool_total) + " doubles) must stay below 2^31 because "
+                           "work items carry 32-bit offsets; shard the SNPs over more GPUs");
+        if (s_total >= (int64_t)1 << 31)
+            return fail(c, "shard too large: the scratch of the symmetric LD product (" +
+                           std::to_string(s_total) + " doubles) must stay below 2^31; shard the "
+                           "SNPs over more GPUs");
+    }
     HostItems all;
     std::vector<int32_t> dstart(c->P + 1, 0);
     int32_t slot = 0, t_base = 0, s_base = 0;
@@ -287,7 +303,6 @@ int ensure_ready(vilma_ctx *c) {
     dstart[c->P] = slot;
     if (upload_items(c, all, c->all)) return 1;
     const int64_t pool_elems = 2 * (int64_t)c->P * c->N + t_base + 2;
-    if (pool_elems >= (int64_t)1 << 31) return fail(c, "shard too large for 32-bit vector offsets");
     c->pool_elems = pool_elems;
     for (int s = 0; s < 2; ++s)
         if (dev_alloc(c, &c->pool[s], pool_elems)) return 1;
@@ -306,18 +321,24 @@ hipEvent_t prof_event(vilma_ctx *c) {
         c->event_pool.pop_back();
         return e;
     }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+        c->prof = 0;                // stop bracketing rather than record into a null event
+        c->prof_now = false;
+        return nullptr;
+    }
     return e;
 }
 void prof_begin(vilma_ctx *c, hipStream_t s, hipEvent_t &e0) {
+    e0 = nullptr;
     if (!c->prof_now) return;
     e0 = prof_event(c);
-    (void)hipEventRecord(e0, s);
+    if (e0) (void)hipEventRecord(e0, s);
 }
 void prof_end(vilma_ctx *c, hipStream_t s, hipEvent_t e0, int kind) {
-    if (!c->prof_now) return;
+    if (!c->prof_now || !e0) return;
     hipEvent_t e1 = prof_event(c);
+    if (!e1) { c->event_pool.push_back(e0); return; }
     (void)hipEventRecord(e1, s);
     c->pending.push_back({e0, e1, kind});
 }
@@ -687,7 +708,7 @@ int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U
     (void)hipFree(ds);
     if (e != hipSuccess) return fail(c, std::string("eigen-form upload: ") + hipGetErrorString(e));
     BlockRec b{1, n, r, co.store_used, co.store_used + (int64_t)n * pad_ld(r), co.next_start,
-               co.t_used};
+               (int32_t)co.t_used};
     co.blocks.push_back(b);
     co.store_used += need;
     co.next_start += n;

@@ -35,6 +35,8 @@ EM_TOL = 10
 ELBO_MOMENTUM = 0.5
 MAX_NUM_ITERS = 20
 EPSILON = 1e-100    # reference numerics.py:8
+# run ahead of a line-search decision only if its L exceeds the last rejected L by this factor
+LOOKAHEAD_MARGIN = float(os.environ.get('VILMA_LOOKAHEAD_MARGIN', '1.1'))
 
 def _inv_small(mats):
     """Inverse of [..., P, P] matrices; closed forms for P<=2 as the reference's helpers
@@ -384,6 +386,7 @@ class SweepDriver:
                 if not np.isclose(orig_obj, new_obj):
                     raise RuntimeError('Encountered a numerical error.')
                 return orig_obj, orig_obj
+            self._L_rejected = L[idx]           # the step 1/L was too long here (see _may_look_ahead)
             L[idx] *= lsr
 
     def _update_hyper_delta(self, orig_obj, with_diff=False, next_step=None):
@@ -497,10 +500,17 @@ class SweepDriver:
         sweep (first beta trial accepted, inner loop ends after it) on its own; not with an
         error-scaling update or per-sweep logging in the sweep, and only if the caller has
         promised that another sweep follows."""
-        return bool(self._look_ok and with_diff and next_step is not None and not self.scale_se
-                    and not self._verbose and hasattr(self.engine, 'decide')
-                    and 1. / next_step * 1.25 < L_MAX
-                    and os.environ.get('VILMA_LOOKAHEAD', '1') != '0')
+        if not (self._look_ok and with_diff and next_step is not None and not self.scale_se
+                and not self._verbose and hasattr(self.engine, 'decide')
+                and 1. / next_step * 1.25 < L_MAX
+                and os.environ.get('VILMA_LOOKAHEAD', '1') != '0'):
+            return False
+        # A stage queued ahead of a trial that is then rejected costs more (a dozen empty
+        # launches, then the slow path) than it saves when the trial is accepted, and rejections
+        # are predictable: L shrinks by 1.25 per sweep until the step 1/L is too long again, which
+        # happens near the L of the previous rejection.  Do not run ahead of such a trial.
+        rejected = getattr(self, '_L_rejected', None)
+        return rejected is None or 1. / next_step > LOOKAHEAD_MARGIN * rejected
 
     def _drop_ahead(self):
         """Forget a stage queued ahead whose decision is not going to be looked at through the
