@@ -15,7 +15,8 @@ import sys
 import pandas as pd
 
 OURS = ("ld_sym_combine_kernel", "ld_sym_kernel", "ld_colsum_kernel", 'snp_pass_kernel', 'delta_kernel', 'reduce_cols_kernel',
-        'finalize_kernel', 'mean_diff', 'gather_x_kernel', 'scatter_y_kernel')
+        'finalize_kernel', 'mean_diff', 'gather_x_kernel', 'scatter_y_kernel', 'decide_kernel', 'mstep_kernel',
+        'init_state_kernel', 'snp_given_delta_kernel')
 
 
 def short(name):
@@ -45,11 +46,14 @@ def main():
                       'min_us': float(grp.us.min()), 'max_us': float(grp.us.max()),
                       'total_ms': float(grp.us.sum() / 1e3)}
         # the dominant kernel's launches split by size: the big launches are the full LD product
-        ld = df[df.k == 'ld_sym_kernel']
-        if len(ld):
-            big = ld[ld.us > 0.5 * ld.us.max()]
-            out['ld_sym_kernel_full_product'] = {'calls': int(len(big)),
-                                                    'avg_us': float(big.us.mean())}
+        # (launches of a stage queued ahead of a line-search decision that then went the other way
+        # exit at once: a few microseconds each; they are not products)
+        for name in ('ld_sym_kernel', 'ld_colsum_kernel'):
+            ld = df[df.k == name]
+            if len(ld):
+                big = ld[ld.us > 0.5 * ld.us.max()]
+                out[name + '_full_product'] = {'calls': int(len(big)), 'avg_us': float(big.us.mean()),
+                                               'skipped_launches': int(len(ld) - len(big))}
         json.dump(out, open(prefix + '_vilma_kernels.json', 'w'), indent=1)
     for f in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
         df = pd.read_csv(f, usecols=['Kernel_Name', 'Counter_Name', 'Counter_Value',
