@@ -273,6 +273,7 @@ def main():
     engine.prof_enable(True, every=prof_every)
     engine.prof_read(reset=True)
     ev0, tr0, ah0 = driver.n_evaluations, driver.n_trials, driver.n_stages_ahead
+    sk0 = driver.n_stages_skipped
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -348,6 +349,9 @@ def main():
             'points_evaluated_per_sweep': n_eval / args.steps,
             'beta_trials_per_sweep': (driver.n_trials - tr0) / args.steps,
             'sweeps_queued_ahead_of_their_decision': driver.n_stages_ahead - ah0,
+            # each skipped stage = 2 LD launches (and ~10 others) that exit at once: they show up
+            # in a rocprofv3 --stats average as ~6 us launches, not in roofline.avg_launch_ms
+            'stages_queued_ahead_then_skipped': driver.n_stages_skipped - sk0,
             'elbo_start': elbo0, 'elbo_end': elbos[-1] if elbos else elbo0,
             'setup_seconds': setup_s,
         },

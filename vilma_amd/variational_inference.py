@@ -158,6 +158,8 @@ class SweepDriver:
         self.n_evaluations = 0      # candidate points evaluated (= LD products per cohort)
         self.n_trials = 0           # beta line-search trials among them
         self.n_stages_ahead = 0     # sweeps whose M-step stage ran ahead of the host's decision
+        self.n_stages_skipped = 0   # stages queued ahead whose decision went the other way: their
+                                    # kernels exited at once (a few microseconds each)
         self.num_its_run = 0
 
     def start_from(self, vi_mu_local, hyper):
@@ -377,6 +379,7 @@ class SweepDriver:
                     self.n_stages_ahead += 1
                 else:
                     self.engine.spec_restore()      # its kernels exited; undo its index flips
+                    self.n_stages_skipped += 1
             if accepted:
                 if L[idx] > L_MAX and not np.isclose(orig_obj, new_obj):
                     raise RuntimeError('Encountered a numerical error.')
@@ -523,6 +526,7 @@ class SweepDriver:
         if flags[ahead['pred']]:
             raise RuntimeError('a stage queued ahead ran although its sweep was abandoned')
         self.engine.spec_restore()
+        self.n_stages_skipped += 1
 
     def _update_error_scaling(self):
         """EM update of the SE scaling (variational_inference.py:472-486, 735-738) from the
