@@ -108,7 +108,8 @@ int64_t vilma_ld_lowrank_elems(int n, int r);
 int vilma_ld_add_dense(vilma_ctx *ctx, int cohort, int n, const double *R);
 
 /* Add the next block in eigen form: U [n*r] row-major, s [r]; dot = U (s * (U^T x))
- * (LowRankMatrix.dot, matrix_structures.py:148-152). */
+ * (LowRankMatrix.dot, matrix_structures.py:148-152).  Only U and s are stored; both passes of a
+ * product read the same row-major U (column sums, then row sums). */
 int vilma_ld_add_lowrank(vilma_ctx *ctx, int cohort, int n, int r, const double *U,
                          const double *s);
 
@@ -121,8 +122,8 @@ int vilma_ld_matvec(vilma_ctx *ctx, void *stream, int cohort, const double *x, d
 
 /* Algorithmic bytes one vilma_eval/vilma_trial_beta streams from the LD store (all cohorts):
  * 8 * sum_b n_b^2 (dense) or 8 * sum_b n_b r_b (eigen form, U counted once) -- SURVEY.md 8(d).
- * stored_bytes = bytes actually resident and streamed per product (dense symmetric blocks keep
- * ~n^2/2 + 64 n elements; eigen form stores U and diag(s)U^T). */
+ * stored_bytes = bytes actually resident (dense symmetric blocks keep ~n^2/2 + 64 n elements;
+ * the eigen form stores U and s, and reads U twice per product). */
 int vilma_ld_bytes(const vilma_ctx *ctx, int64_t *algorithmic_bytes, int64_t *stored_bytes);
 
 /* ---- variational state ---------------------------------------------------------------- */

@@ -21,7 +21,7 @@ struct BlockRec {
     int form;            // 0 dense, 1 eigen
     int n, r;
     int64_t off_a;       // element offset of R or U in the cohort store
-    int64_t off_v;       // element offset of diag(s)U^T (eigen form)
+    int64_t off_v;       // element offset of the eigenvalues s (eigen form)
     int32_t start;       // LD position of the block's first SNP
     int32_t t_off;       // offset in the cohort's t scratch (eigen form)
 };
@@ -40,11 +40,18 @@ struct CohortLd {
 };
 
 // device-resident work lists of one LD product (all cohorts, or one cohort)
+// Eigen-form blocks are processed in groups of <= eigen_group_bytes of U (default: one group):
+// first pass of the group (t' = s * U^T x), then the second pass on the SAME U (y = U t'), then
+// the combine -- three launches per group.
+struct EigenGroup { int a0, na, r0, nr, c0, nc; };
 struct ItemSet {
     SymItem *sym = nullptr;
     SymCombItem *comb = nullptr;
-    LdItem *a = nullptr, *b = nullptr;
-    int n_sym = 0, n_comb = 0, n_a = 0, n_b = 0;
+    LdItem *a = nullptr;
+    RowItem *row = nullptr;
+    RowCombItem *rcomb = nullptr;
+    int n_sym = 0, n_comb = 0, n_a = 0, n_row = 0, n_rcomb = 0;
+    std::vector<EigenGroup> groups;
 };
 
 // number of doubles a dense block occupies: per 128-column slab J the panel of rows >= 128 J
@@ -100,6 +107,13 @@ struct vilma_ctx {
     bool ready = false;
     // rows per work item of the symmetric product (multiple of 32); VILMA_LD_CHUNK_ROWS overrides
     int chunk_rows = 512;
+    // U bytes per eigen-form group.  Default: ONE group (first pass over every block, then the
+    // second).  Running both passes group by group so that the second finds U in the 256 MB
+    // Infinity Cache was measured and LOSES: 1.16 ms per product ungrouped, 1.50 / 1.76 / 2.32 ms
+    // with 320 / 160 / 96 MB groups at C4 (profiles/r02g_ab_eigen.txt) -- ~10 us of launch ramp
+    // and tail per extra kernel, no measurable gain from the cache.  VILMA_EIGEN_GROUP_MB keeps
+    // the experiment reproducible.
+    int64_t eigen_group_bytes = INT64_MAX;
 
     // Work that depends only on the per-SNP pass of an evaluation (responsibility sums of the
     // trial state, convergence statistics) runs on `side`, concurrently with that evaluation's LD
@@ -164,7 +178,7 @@ int dev_alloc(vilma_ctx *c, T **p, int64_t count, bool zero = true) {
 void dev_free(void *p) { if (p) (void)hipFree(p); }
 
 void free_items(ItemSet &it) {
-    dev_free(it.sym); dev_free(it.comb); dev_free(it.a); dev_free(it.b);
+    dev_free(it.sym); dev_free(it.comb); dev_free(it.a); dev_free(it.row); dev_free(it.rcomb);
     it = ItemSet();
 }
 
@@ -182,7 +196,11 @@ void free_ready(vilma_ctx *c) {
 struct HostItems {
     std::vector<SymItem> sym;
     std::vector<SymCombItem> comb;
-    std::vector<LdItem> a, b;
+    std::vector<LdItem> a;
+    std::vector<RowItem> row;
+    std::vector<RowCombItem> rcomb;
+    std::vector<EigenGroup> groups;
+    int64_t group_bytes = 0;          // U bytes in the group being filled
 };
 
 void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, int32_t s_base,
@@ -217,34 +235,60 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
             }
             s_off += sym_scratch_elems(b.n, CH);
         } else {
-            for (int c0 = 0; c0 < b.r; c0 += 128) {        // t = U^T x
+            // eigen form: U [n x ld(r)] then s [ld(r)].  New group when this block would push the
+            // group's U past the budget (a block larger than the budget gets a group of its own)
+            const int ldr = pad_ld(b.r), ns = (b.r + 127) / 128, CH = c->chunk_rows;
+            const int64_t ubytes = (int64_t)b.n * ldr * 8;
+            if (H.groups.empty() || H.group_bytes + ubytes > c->eigen_group_bytes) {
+                H.groups.push_back({(int)H.a.size(), 0, (int)H.row.size(), 0, (int)H.rcomb.size(), 0});
+                H.group_bytes = 0;
+            }
+            H.group_bytes += ubytes;
+            EigenGroup &g = H.groups.back();
+            const double *U = co.store + b.off_a, *sv = co.store + b.off_v;
+            const int32_t t_pool = 2 * PN + t_base + b.t_off;
+            for (int c0 = 0; c0 < b.r; c0 += 128) {        // t' = s * (U^T x)
                 LdItem it;
-                it.a = co.store + b.off_a; it.rows = b.n; it.ld = pad_ld(b.r); it.col0 = c0;
-                it.ncols = b.r; it.x_off = pN + b.start; it.y_off = 2 * PN + t_base + b.t_off;
-                it.dot_off = -1; it.dot_slot = -1;
+                it.a = U; it.rows = b.n; it.ld = ldr; it.col0 = c0;
+                it.ncols = b.r; it.x_off = pN + b.start; it.y_off = t_pool;
+                it.dot_off = -1; it.dot_slot = -1; it.scale = sv;
                 H.a.push_back(it);
+                ++g.na;
             }
-            for (int c0 = 0; c0 < b.n; c0 += 128) {        // y = (diag(s) U^T)^T t
-                LdItem it;
-                it.a = co.store + b.off_v; it.rows = b.r; it.ld = pad_ld(b.n); it.col0 = c0;
-                it.ncols = b.n; it.x_off = 2 * PN + t_base + b.t_off; it.y_off = PN + pN + b.start;
-                it.dot_off = pN + b.start; it.dot_slot = slot++;
-                H.b.push_back(it);
+            for (int J = 0; J < ns; ++J)                   // S[J][i] = sum_{c in slab J} U[i][c] t'[c]
+                for (int r0 = 0; r0 < b.n; r0 += CH) {
+                    RowItem it;
+                    it.a = U + (int64_t)r0 * ldr + 128 * J; it.rows = std::min(CH, b.n - r0);
+                    it.ld = ldr; it.w = std::min(128, b.r - 128 * J); it.t_off = t_pool + 128 * J;
+                    it.s_off = s_off + J * b.n + r0; it.pad = 0;
+                    H.row.push_back(it);
+                    ++g.nr;
+                }
+            for (int i0 = 0; i0 < b.n; i0 += 256) {        // y = sum_J S[J], and y.z
+                RowCombItem cb;
+                cb.n = b.n; cb.ns = ns; cb.s_base = s_off; cb.y_off = PN + pN + b.start;
+                cb.dot_off = pN + b.start; cb.dot_slot = slot++; cb.i0 = i0; cb.pad = 0;
+                H.rcomb.push_back(cb);
+                ++g.nc;
             }
+            s_off += ns * b.n;
         }
     }
 }
 
 void sort_items(HostItems &H) {
-    // longest first: workgroup run time ~ rows streamed
-    std::stable_sort(H.a.begin(), H.a.end(), [](const LdItem &x, const LdItem &y) {
-        return (int64_t)x.rows * std::min(128, x.ncols - x.col0) >
-               (int64_t)y.rows * std::min(128, y.ncols - y.col0);
-    });
-    std::stable_sort(H.b.begin(), H.b.end(), [](const LdItem &x, const LdItem &y) {
-        return (int64_t)x.rows * std::min(128, x.ncols - x.col0) >
-               (int64_t)y.rows * std::min(128, y.ncols - y.col0);
-    });
+    // longest first: workgroup run time ~ rows streamed (within each eigen group for its lists)
+    for (const EigenGroup &g : H.groups) {
+        std::stable_sort(H.a.begin() + g.a0, H.a.begin() + g.a0 + g.na,
+                         [](const LdItem &x, const LdItem &y) {
+            return (int64_t)x.rows * std::min(128, x.ncols - x.col0) >
+                   (int64_t)y.rows * std::min(128, y.ncols - y.col0);
+        });
+        std::stable_sort(H.row.begin() + g.r0, H.row.begin() + g.r0 + g.nr,
+                         [](const RowItem &x, const RowItem &y) {
+            return (int64_t)x.rows * x.w > (int64_t)y.rows * y.w;
+        });
+    }
     std::stable_sort(H.sym.begin(), H.sym.end(), [](const SymItem &x, const SymItem &y) {
         return (int64_t)x.rows * x.ld > (int64_t)y.rows * y.ld;
     });
@@ -262,8 +306,10 @@ int upload_vec(vilma_ctx *c, const std::vector<T> &v, T **dev, int *count) {
 
 int upload_items(vilma_ctx *c, HostItems &H, ItemSet &out) {
     sort_items(H);
+    out.groups = H.groups;
     return upload_vec(c, H.sym, &out.sym, &out.n_sym) || upload_vec(c, H.comb, &out.comb, &out.n_comb) ||
-           upload_vec(c, H.a, &out.a, &out.n_a) || upload_vec(c, H.b, &out.b, &out.n_b);
+           upload_vec(c, H.a, &out.a, &out.n_a) || upload_vec(c, H.row, &out.row, &out.n_row) ||
+           upload_vec(c, H.rcomb, &out.rcomb, &out.n_rcomb);
 }
 
 int ensure_ready(vilma_ctx *c) {
@@ -366,14 +412,16 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, int cohort) {
         launch_ld_sym(it.sym, it.n_sym, pl, c->sym_scratch, s);
         prof_end(c, s, e0, VILMA_PROF_LD_SYM);
     }
-    if (it.n_a > 0) {
+    // eigen-form blocks, group by group (one group unless VILMA_EIGEN_GROUP_MB says otherwise):
+    // both passes over the group's U back to back; one bracket around all = one product
+    if (!it.groups.empty()) {
         prof_begin(c, s, e0);
-        launch_ld_colsum(it.a, it.n_a, pl, c->dot_partials, s);
-        prof_end(c, s, e0, VILMA_PROF_LD_COLSUM);
-    }
-    if (it.n_b > 0) {
-        prof_begin(c, s, e0);
-        launch_ld_colsum(it.b, it.n_b, pl, c->dot_partials, s);
+        for (const EigenGroup &g : it.groups) {
+            launch_ld_colsum(it.a + g.a0, g.na, pl, c->dot_partials,
+                             /*keep=*/it.groups.size() > 1, s);
+            launch_ld_rowsum(it.row + g.r0, g.nr, pl, c->sym_scratch, s);
+            launch_ld_rowsum_combine(it.rcomb + g.c0, g.nc, pl, c->sym_scratch, c->dot_partials, s);
+        }
         prof_end(c, s, e0, VILMA_PROF_LD_COLSUM);
     }
     if (it.n_comb > 0)      // not bracketed: tiny, and every event pair costs host time
@@ -491,6 +539,10 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         return 1;
     }
     c->log_det_host.assign(M, 0.0);
+    if (const char *gm = std::getenv("VILMA_EIGEN_GROUP_MB")) {
+        const int v = std::atoi(gm);
+        if (v >= 1) c->eigen_group_bytes = (int64_t)v << 20;
+    }
     if (const char *cr = std::getenv("VILMA_LD_CHUNK_ROWS")) {
         const int v = std::atoi(cr);
         if (v >= 128) c->chunk_rows = (v + 31) / 32 * 32;
@@ -628,7 +680,7 @@ int64_t vilma_ld_dense_elems(int n) {
     return e;
 }
 int64_t vilma_ld_lowrank_elems(int n, int r) {
-    return (int64_t)n * pad_ld(r) + (int64_t)r * pad_ld(n);
+    return (int64_t)n * pad_ld(r) + pad_ld(r);          // U [n x ld(r)] then s [ld(r)]
 }
 
 int vilma_ld_begin(vilma_ctx *c, int cohort, int n_blocks, int64_t n_ld, const int64_t *perm,
@@ -694,25 +746,19 @@ int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U
     if (co.next_start + (int64_t)n > co.n_ld) return fail(c, "blocks exceed n_ld");
     const int64_t need = vilma_ld_lowrank_elems(n, r);
     if (co.store_used + need > co.store_elems) return fail(c, "LD store overflow (total_elems)");
+    // only U and s are stored: both passes of the product read the same row-major U
     double *dU = co.store + co.store_used;
-    double *dV = dU + (int64_t)n * pad_ld(r);
+    double *dS = dU + (int64_t)n * pad_ld(r);
     HIPCHK(c, hipMemcpy2D(dU, (size_t)pad_ld(r) * sizeof(double), U, (size_t)r * sizeof(double),
                           (size_t)r * sizeof(double), (size_t)n, hipMemcpyDefault));
-    double *ds = nullptr;
-    HIPCHK(c, hipMalloc((void **)&ds, (size_t)r * sizeof(double)));
-    hipError_t e = hipMemcpy(ds, s, (size_t)r * sizeof(double), hipMemcpyDefault);
-    if (e == hipSuccess) {
-        launch_scaled_transpose(dU, n, r, pad_ld(r), ds, dV, pad_ld(n), nullptr);
-        e = hipDeviceSynchronize();
-    }
-    (void)hipFree(ds);
-    if (e != hipSuccess) return fail(c, std::string("eigen-form upload: ") + hipGetErrorString(e));
+    HIPCHK(c, hipMemcpy(dS, s, (size_t)r * sizeof(double), hipMemcpyDefault));
     BlockRec b{1, n, r, co.store_used, co.store_used + (int64_t)n * pad_ld(r), co.next_start,
                (int32_t)co.t_used};
     co.blocks.push_back(b);
     co.store_used += need;
     co.next_start += n;
     co.t_used += pad_ld(r);
+    co.s_used += (int64_t)((r + 127) / 128) * n;         // partial row sums S[slab][n]
     co.alg_bytes += (int64_t)8 * n * r;
     return 0;
 }

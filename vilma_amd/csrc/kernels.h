@@ -17,6 +17,29 @@ struct LdItem {
     int32_t y_off;       // offset of out[0] (column 0) in the vector pool
     int32_t dot_off;     // offset in the pool of the vector to dot the output with, or -1
     int32_t dot_slot;    // where to store this item's partial of that dot product
+    const double *scale; // out[c] is multiplied by scale[c] (the eigenvalues), or nullptr
+};
+
+// Second pass of an eigen-form block, y = U t' with t' = s * (U^T x): one work item = a chunk of
+// rows of one 128-column slab of the SAME row-major U the first pass read (so it can still be in
+// the Infinity Cache): partial row sums S[slab][i] = sum_{c in slab} U[i][c] t'[c].
+struct RowItem {
+    const double *a;     // U + r0 * ld + c0 (128-byte aligned)
+    int32_t rows;        // rows in this chunk
+    int32_t ld;          // leading dimension of U (multiple of 16 doubles)
+    int32_t w;           // columns in this slab (<= 128)
+    int32_t t_off;       // pool offset of t'[c0]
+    int32_t s_off;       // scratch offset of S[slab][r0]
+    int32_t pad;
+};
+
+// y[i] = sum_{J < ns} S[J][i] for 256 rows of one eigen-form block, with the y.z partial
+struct RowCombItem {
+    int32_t n, ns;            // block size, number of 128-column slabs of U
+    int32_t s_base;           // scratch offset of S[0][0] (n entries per slab)
+    int32_t y_off, dot_off, dot_slot;
+    int32_t i0;               // first of the (up to) 256 rows this workgroup combines
+    int32_t pad;
 };
 
 // One work item of the SYMMETRIC dense product: the panel of one block below (and including)
@@ -89,8 +112,14 @@ void launch_decide(int P, int check_convergence, const double *totals, const dou
 void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s);
 int snp_pass_grid(int64_t N);
 
+// keep = true: default cache policy (the stream is read again by launch_ld_rowsum right after);
+// false: non-temporal
 void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *dot_partials,
+                      bool keep, hipStream_t s);
+void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool, double *scratch,
                       hipStream_t s);
+void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool,
+                              const double *scratch, double *dot_partials, hipStream_t s);
 void launch_ld_sym(const SymItem *items, int n_items, const double *pool, double *scratch,
                    hipStream_t s);
 void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
@@ -145,10 +174,6 @@ void launch_gather_x(const double *x_snp, const int32_t *invperm, double *pool_x
                      hipStream_t s);
 void launch_scatter_y(const double *pool_y, const int32_t *invperm, double *y_snp, int N, int P,
                       hipStream_t s);
-
-// V[c][i] = s[c] * U[i][c]  (U: n x ldu, V: r x ldv)
-void launch_scaled_transpose(const double *U, int n, int r, int ldu, const double *s, double *V,
-                             int ldv, hipStream_t st);
 
 void launch_mstep(const double *sums, const double *counts, const double *log_det, int A, int M,
                   double *hyper, double *lh, hipStream_t s);

@@ -104,6 +104,7 @@ void set_launch_predicate(const int *flag) { g_pred = flag; }
 typedef const double __attribute__((address_space(4))) *const_tab;
 static __device__ __forceinline__ const_tab as_table(const double *p) { return (const_tab)p; }
 
+template <bool KEEP>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
     const LdItem *__restrict__ items, const double *__restrict__ xpool, double *__restrict__ ypool,
     const double *__restrict__ dpool, double *__restrict__ dot_partials, const int *pred) {
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
                 v2d v[CS_ROWS];
 #pragma unroll
                 for (int u = 0; u < CS_ROWS; ++u)
-                    v[u] = LD_STREAM_LOAD(ap + (int64_t)(j + u) * ld);
+                    v[u] = KEEP ? *(gd2_ptr)(ap + (int64_t)(j + u) * ld)
+                                : LD_STREAM_LOAD(ap + (int64_t)(j + u) * ld);
 #pragma unroll
                 for (int u = 0; u < CS_ROWS; ++u) {
                     const double xv = xp[j + u];
@@ -134,7 +136,8 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
                 }
             } else {
                 for (int jj = j; jj < rows; ++jj) {
-                    const v2d v = LD_STREAM_LOAD(ap + (int64_t)jj * ld);
+                    const v2d v = KEEP ? *(gd2_ptr)(ap + (int64_t)jj * ld)
+                                       : LD_STREAM_LOAD(ap + (int64_t)jj * ld);
                     const double xv = xp[jj];
                     acc0 = fma(v.x, xv, acc0);
                     acc1 = fma(v.y, xv, acc1);
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
         for (int ww = 1; ww < CS_WAVES; ++ww) s += red[ww][threadIdx.x];
         double dv = 0.0;
         if (col < it.ncols) {
+            if (it.scale != nullptr) s *= it.scale[col];
             ypool[it.y_off + col] = s;
             if (it.dot_off >= 0) dv = s * dpool[it.dot_off + col];
         }
@@ -167,12 +171,16 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
 }
 
 void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *dot_partials,
-                      hipStream_t s) {
+                      bool keep, hipStream_t s) {
     if (n_items <= 0) return;
     // x, y and the dot vector live in one pool; within a launch the regions read and written
     // are disjoint, so handing the same base to the three restrict parameters is sound
-    hipLaunchKernelGGL(ld_colsum_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items,
-                       (const double *)pool, pool, (const double *)pool, dot_partials, g_pred);
+    if (keep)
+        hipLaunchKernelGGL(ld_colsum_kernel<true>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items,
+                           (const double *)pool, pool, (const double *)pool, dot_partials, g_pred);
+    else
+        hipLaunchKernelGGL(ld_colsum_kernel<false>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items,
+                           (const double *)pool, pool, (const double *)pool, dot_partials, g_pred);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -389,6 +397,86 @@ void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
                            const double *scratch, double *dot_partials, hipStream_t s) {
     if (n_items <= 0) return;
     hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items), dim3(256), 0, s, items,
+                       (const double *)pool, pool, scratch, dot_partials, g_pred);
+}
+
+// --------------------------------------------------------------------------------------------
+// Second pass of the eigen form on the same U: y = U t'.  Lanes along the (up to 128) columns of a
+// slab, 4 waves x interleaved 8-row groups, the row sums of each group by the halving butterfly
+// of the symmetric kernel; partial row sums per column slab go to scratch, the combine kernel
+// adds the slabs in order and forms the y.z partial.  Loads are non-temporal (last use).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CS_WAVES * 64) void ld_rowsum_kernel(
+    const RowItem *__restrict__ items, const double *__restrict__ pool,
+    double *__restrict__ scratch, const int *pred) {
+    PRED_EXIT(pred);
+    const RowItem it = items[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cl = 2 * lane;
+    const bool active = cl < it.w;
+    const int rows = it.rows;
+    const int64_t ld = it.ld;
+    const double *__restrict__ tp = pool + it.t_off;
+    const double ts0 = active ? tp[cl] : 0.0;
+    const double ts1 = (cl + 1 < it.w) ? tp[cl + 1] : 0.0;
+    const double *ap = it.a + (active ? cl : 0);          // idle lanes re-read column 0, times 0
+    double *__restrict__ srow = scratch + it.s_off;
+    const int ngroups = (rows + CS_ROWS - 1) / CS_ROWS;
+    for (int g = w; g < ngroups; g += CS_WAVES) {
+        const int r0 = g * CS_ROWS;
+        v2d v[CS_ROWS];
+        double p[CS_ROWS];
+#pragma unroll
+        for (int u = 0; u < CS_ROWS; ++u)
+            v[u] = LD_STREAM_LOAD(ap + (int64_t)min(r0 + u, rows - 1) * ld);
+#pragma unroll
+        for (int u = 0; u < CS_ROWS; ++u) p[u] = fma(v[u].x, ts0, v[u].y * ts1);
+        int rsub;
+        const double t1 = sym_rowsum8(p, lane, rsub);
+        const int rr = r0 + rsub;
+        if ((lane & 7) == 0 && rr < rows) srow[rr] = t1;
+    }
+}
+
+__global__ __launch_bounds__(256) void ld_rowsum_combine_kernel(
+    const RowCombItem *__restrict__ items, const double *__restrict__ xpool,
+    double *__restrict__ ypool, const double *__restrict__ scratch,
+    double *__restrict__ dot_partials, const int *pred) {
+    __shared__ double dred[4];
+    PRED_EXIT(pred);
+    const RowCombItem it = items[blockIdx.x];
+    const int i = it.i0 + threadIdx.x;
+    const bool live = i < it.n;
+    const int ii = live ? i : it.n - 1;
+    const double *si = scratch + it.s_base + ii;
+    const double xi = xpool[it.dot_off + ii];
+    double s = 0.0;
+    for (int J = 0; J < it.ns; J += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = si[(int64_t)min(J + u, it.ns - 1) * it.n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (J + u < it.ns) ? t[u] : 0.0;
+    }
+    if (live) ypool[it.y_off + i] = s;
+    double dv = wave_sum(live ? s * xi : 0.0);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = dv;
+    __syncthreads();
+    if (threadIdx.x == 0) dot_partials[it.dot_slot] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+}
+
+void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool, double *scratch,
+                      hipStream_t s) {
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(ld_rowsum_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pool,
+                       scratch, g_pred);
+}
+
+void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool,
+                              const double *scratch, double *dot_partials, hipStream_t s) {
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(ld_rowsum_combine_kernel, dim3(n_items), dim3(256), 0, s, items,
                        (const double *)pool, pool, scratch, dot_partials, g_pred);
 }
 
@@ -1465,30 +1553,6 @@ void launch_mean_diff(const double *m_cur, const double *scalings, double *snaps
     if (compare)
         hipLaunchKernelGGL(mean_diff_final_kernel, dim3(1), dim3(1024), 0, s, partials, grid,
                            out_sum3, out_max3, g_pred);
-}
-
-// --------------------------------------------------------------------------------------------
-// load-time helper for the eigen form: V = diag(s) U^T
-// --------------------------------------------------------------------------------------------
-__global__ void scaled_transpose_kernel(const double *__restrict__ U, int n, int r, int ldu,
-                                        const double *__restrict__ s, double *__restrict__ V,
-                                        int ldv) {
-    __shared__ double tile[32][33];
-    const int i0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
-        const int i = i0 + dy, c = c0 + threadIdx.x;
-        tile[dy][threadIdx.x] = (i < n && c < r) ? U[(int64_t)i * ldu + c] : 0.0;
-    }
-    __syncthreads();
-    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
-        const int c = c0 + dy, i = i0 + threadIdx.x;
-        if (c < r && i < n) V[(int64_t)c * ldv + i] = s[c] * tile[threadIdx.x][dy];
-    }
-}
-void launch_scaled_transpose(const double *U, int n, int r, int ldu, const double *s, double *V,
-                             int ldv, hipStream_t st) {
-    hipLaunchKernelGGL(scaled_transpose_kernel, dim3((n + 31) / 32, (r + 31) / 32), dim3(32, 8), 0,
-                       st, U, n, r, ldu, s, V, ldv);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -84,8 +84,7 @@ def store_upper_bound(lib, sizes, form):
             total += lib.vilma_ld_lowrank_elems(n, n)
             continue
         # auto: the eigen form is chosen only up to this rank
-        r_max = max(1, min(n, int(ms.dense_bytes_moved(n) / (ms.EIGEN_FORM_PENALTY * 2.0 * n))))
-        total += max(dense, lib.vilma_ld_lowrank_elems(n, r_max))
+        total += max(dense, lib.vilma_ld_lowrank_elems(n, ms.max_eigen_rank(n)))
     return total
 
 

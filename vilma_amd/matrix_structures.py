@@ -79,16 +79,27 @@ def dense_bytes_moved(n):
     return 0.5 * n * n + 32.0 * n
 
 
-# the two eigen-form passes (plus their extra launches, on the small blocks that would choose
-# them) run at about 3/4 of the dense kernel's rate per byte: workload C4 (kept rank 0.28 n) on
-# one box: all-dense 325 sweeps/s, by bytes alone 308, all-eigen 286 (another box)
-EIGEN_FORM_PENALTY = 1.3
+# Eigen form: the device stores U once and streams it twice per product -- t' = s * (U^T x), then
+# y = U t' on the same array -- at ~0.84 of the dense kernel's rate per element (workload C4, LD
+# alone: 5.8 TB/s against 6.9 TB/s, profiles/r02g_ab_eigen.txt; re-reading U from the Infinity
+# Cache group by group was measured and does not pay).
+EIGEN_FORM_PENALTY = 1.2
+
+
+def eigen_cost(n, r):
+    """Elements a product streams for an eigen-form block, in dense-kernel elements."""
+    return EIGEN_FORM_PENALTY * 2.0 * n * r
 
 
 def dense_is_cheaper(n, r):
-    """Dense symmetric form vs eigen form (U and diag(s)U^T, 2 n r elements per product), by
-    elements read weighted with the measured efficiency of the eigen-form passes."""
-    return dense_bytes_moved(n) <= EIGEN_FORM_PENALTY * 2.0 * n * r
+    """Dense symmetric form (lower triangle once, ~n^2/2 + 32 n elements) vs eigen form (U twice,
+    2 n r), by the measured cost of a product: eigen form only for r < (n/4 + 16) / 1.2."""
+    return dense_bytes_moved(n) <= eigen_cost(n, r)
+
+
+def max_eigen_rank(n):
+    """Largest rank for which `auto` keeps a block of n SNPs in eigen form (at least 1)."""
+    return max(1, min(n, int(dense_bytes_moved(n) / (EIGEN_FORM_PENALTY * 2.0 * n))))
 
 
 class LowRankMatrix:
@@ -260,8 +271,7 @@ class BlockDiagonalMatrix:
     def device_blocks(self, form='auto'):
         """Blocks in the form the HIP LD store takes, chosen by bytes streamed per product: the
         dense symmetric form reads the lower triangle once (~n^2/2 + 32 n elements), the eigen
-        form reads U and diag(s)U^T (2 n r) at ~3/4 of the rate -- so eigen form only when
-        r < (n/4 + 16) / 1.3."""
+        form reads U twice (dense_is_cheaper)."""
         def one(m):
             n, r = m.u.shape
             if not np.allclose(m.D, 0):

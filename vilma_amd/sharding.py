@@ -131,13 +131,13 @@ class Comm:
 
 def block_costs(ld):
     """Bytes one product with each block streams in the form the device will hold it."""
-    from .matrix_structures import dense_is_cheaper, dense_bytes_moved
+    from .matrix_structures import dense_is_cheaper, dense_bytes_moved, eigen_cost
     out = []
     for m in ld.matrices:
         n = m.shape[0]
         # a block that is not decomposed yet is costed as dense (its rank is unknown)
         r = n if m.is_deferred() else m.u.shape[1]
-        out.append(8.0 * (dense_bytes_moved(n) if dense_is_cheaper(n, r) else 2.0 * n * r))
+        out.append(8.0 * (dense_bytes_moved(n) if dense_is_cheaper(n, r) else eigen_cost(n, r)))
     return np.asarray(out)
 
 
