@@ -291,10 +291,8 @@ def main():
     # the dominant kernel = the LD-streaming kernel with the most accumulated time
     dom = max(('ld_sym_kernel', 'ld_colsum_kernel'), key=lambda k: prof[k][0])
     kernel_ms, launches = prof[dom]
-    if dom == 'ld_colsum_kernel':
-        # the eigen form takes two launches (U^T x, then diag(s)U^T transposed) per product:
-        # quote the pair as one launch of the product
-        launches //= 2
+    # (an eigen-form product = first pass, second pass and combine on the same U: the library
+    # brackets the three launches together, so a bracket is a product for either kernel)
     if world > 1:
         elapsed = float(comm.allreduce_np(np.array([elapsed]), op='max')[0])
 

@@ -80,10 +80,11 @@ def dense_bytes_moved(n):
 
 
 # Eigen form: the device stores U once and streams it twice per product -- t' = s * (U^T x), then
-# y = U t' on the same array -- at ~0.84 of the dense kernel's rate per element (workload C4, LD
-# alone: 5.8 TB/s against 6.9 TB/s, profiles/r02g_ab_eigen.txt; re-reading U from the Infinity
-# Cache group by group was measured and does not pay).
-EIGEN_FORM_PENALTY = 1.2
+# y = U t' on the same array -- at ~0.8 of the dense kernel's rate per element (workload C4: LD
+# alone 5.8 TB/s against 6.9 TB/s, inside the sweep 5.1 against 6.5; all-dense 338, all-eigen 296,
+# chosen per block with this weight 327 sweeps/s, profiles/r02g_*; re-reading U from the
+# Infinity Cache group by group was measured and does not pay).
+EIGEN_FORM_PENALTY = 1.3
 
 
 def eigen_cost(n, r):
@@ -93,7 +94,7 @@ def eigen_cost(n, r):
 
 def dense_is_cheaper(n, r):
     """Dense symmetric form (lower triangle once, ~n^2/2 + 32 n elements) vs eigen form (U twice,
-    2 n r), by the measured cost of a product: eigen form only for r < (n/4 + 16) / 1.2."""
+    2 n r), by the measured cost of a product: eigen form only for r < (n/4 + 16) / 1.3."""
     return dense_bytes_moved(n) <= eigen_cost(n, r)
 
 
