@@ -273,6 +273,7 @@ def main():
     engine.prof_enable(True, every=prof_every)
     engine.prof_read(reset=True)
     ev0, tr0, ah0 = driver.n_evaluations, driver.n_trials, driver.n_stages_ahead
+    pr0 = driver.n_products
     sk0 = driver.n_stages_skipped
     if world > 1:
         dist.barrier()
@@ -297,6 +298,7 @@ def main():
         elapsed = float(comm.allreduce_np(np.array([elapsed]), op='max')[0])
 
     n_eval = driver.n_evaluations - ev0
+    n_prod = driver.n_products - pr0
     # algorithmic bytes of ONE product on this rank (stated in DESIGN.md section 5): a dense
     # symmetric block needs its lower triangle once, an eigen-form block its U once
     specs = shard.block_specs(args.ld_form) if shard.kind == 'lowrank' else shard.block_specs()
@@ -345,6 +347,9 @@ def main():
                                              '8 n^2 as full matrices; the symmetric kernel needs the lower triangle, half of it' if shard.kind == 'ar1' else '8 n r, U counted once'),
             'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
             'points_evaluated_per_sweep': n_eval / args.steps,
+            # a beta trial evaluates the step the line search tries now and the one it would try
+            # next in ONE pass over the LD store: fewer passes than points
+            'ld_products_per_sweep': n_prod / args.steps,
             'beta_trials_per_sweep': (driver.n_trials - tr0) / args.steps,
             'sweeps_queued_ahead_of_their_decision': driver.n_stages_ahead - ah0,
             # each skipped stage = 2 LD launches (and ~10 others) that exit at once: they show up
@@ -366,7 +371,7 @@ def main():
             'avg_launch_ms': avg_ms, 'launches': int(launches), 'bracketed_every': prof_every,
             'stored_bytes_per_launch': float(engine.ld_bytes()[1]),
             'other_ld_kernels_ms': {k: v[0] / max(v[1], 1) for k, v in prof.items() if k != dom and v[1]},
-            'sweep_algorithmic_GBps': (n_eval * (alg_launch + state_bytes)) / elapsed / 1e9,
+            'sweep_algorithmic_GBps': (n_prod * (alg_launch + state_bytes)) / elapsed / 1e9,
         },
     }
     if world == 1 and not args.no_cpu_baseline:

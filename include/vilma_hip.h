@@ -181,8 +181,20 @@ int vilma_init_state(vilma_ctx *ctx, void *stream, const double *fake_mu, double
  * pieces of the candidate.  The candidate is held as the trial state. */
 int vilma_trial_beta(vilma_ctx *ctx, void *stream, double step, double *totals_dev);
 
-/* Make the trial state current.  take_mu != 0 after an accepted vilma_trial_beta; 0 after a
- * vilma_eval (vi_mu unchanged, only the moments / LD product move). */
+/* The same trial at TWO step sizes in one pass: step_a = 1/L, the step the line search tries now,
+ * and step_b = 1/(L * line_search_rate), the one it would try next if step_a is rejected
+ * (variational_inference.py:777-800).  vi_mu, the per-component matrices and -- the expensive
+ * part -- the LD store are read once for both candidates (the LD kernel is HBM-bound; the second
+ * right-hand side rides in the same loads), so a rejected first step no longer costs a second
+ * pass over the LD store.  Each candidate's sums are bit-identical to vilma_trial_beta's at its
+ * step.  Candidate A is held as the trial state exactly as after vilma_trial_beta(step_a);
+ * candidate B is accepted with vilma_accept(ctx, 2). */
+int vilma_trial_beta2(vilma_ctx *ctx, void *stream, double step_a, double step_b,
+                      double *totals_a_dev, double *totals_b_dev);
+
+/* Make a trial state current.  take_mu = 1 after an accepted vilma_trial_beta / candidate A of
+ * vilma_trial_beta2; 2 for candidate B; 0 after a vilma_eval (vi_mu unchanged, only the moments /
+ * LD product move).  Buffers swap roles; nothing is copied. */
 int vilma_accept(vilma_ctx *ctx, int take_mu);
 
 /* sums [A*M] = sum_annotations(vi_delta) (numerics.py:118-129), the M-step statistic and the
@@ -192,6 +204,7 @@ int vilma_accept(vilma_ctx *ctx, int take_mu);
 #define VILMA_STATE_CURRENT 0
 #define VILMA_STATE_TRIAL_BETA 1   /* trial of vilma_trial_beta (its own vi_mu) */
 #define VILMA_STATE_TRIAL_EVAL 2   /* trial of vilma_eval (shares the current vi_mu) */
+#define VILMA_STATE_TRIAL_BETA_B 3 /* candidate B of vilma_trial_beta2 */
 int vilma_delta_sums(vilma_ctx *ctx, void *stream, double *sums_dev, int which);
 
 /* The M-step of _update_hyper_delta on the device, without a host round trip: from the

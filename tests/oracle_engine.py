@@ -42,6 +42,7 @@ class OracleEngine:
         self.results = torch.zeros(L.size, dtype=torch.float64)
         self._dsum, self._totals = self.results[L.dsum], self.results[L.totals]
         self._ttotals = self.results[L.ttotals]
+        self._ttotals_b = self.results[L.ttotals_b]
         self._sums, self._dmax = self.results[L.sums], self.results[L.dmax]
         self._hyper_t = self.results[L.hyper]
         self._last_trial_kind = None
@@ -190,7 +191,17 @@ class OracleEngine:
                                                  out=self._ttotals)
         return totals
 
+    def trial2(self, step_a, step_b):
+        self.trial(step_b)
+        self._ttotals_b.copy_(self._ttotals)
+        self.mu_trial_b, self.trial_state_b = self.mu_trial, self.trial_state
+        self.trial(step_a)
+        return self._ttotals, self._ttotals_b
+
     def accept(self, take_mu):
+        if int(take_mu) == 2:
+            self.mu, self.cur = self.mu_trial_b, self.trial_state_b
+            return
         if take_mu:
             self.mu = self.mu_trial
         self.cur = self.trial_state

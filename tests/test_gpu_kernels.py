@@ -158,6 +158,58 @@ def test_eval_with_fused_convergence_statistics(name):
     assert a0[0] == 0 and a1[0] == 0 and a0[4] == 0 and a1[4] == 0
 
 
+@pytest.mark.parametrize('form', ['dense', 'eig'])
+@pytest.mark.parametrize('name', ['p2_bigblock', 'p2_bigblock_lr', 'p4_m81', 'p1_scaled', 'p2_scale_se'])
+def test_two_step_trial_equals_two_trials(name, form):
+    """vilma_trial_beta2 evaluates two step sizes in one pass over vi_mu and the LD store; each
+    candidate's sums, vi_mu and moments are bit-identical to a one-step trial at that step, and
+    either can be accepted (take_mu = 1 / 2)."""
+    g = golden('traj_%s.npz' % name)
+    vi, ld = oracle_from_traj(g)
+    np.random.seed(5)
+    vi_mu, vi_delta, hyper = vi._initialize()
+
+    def fresh():
+        eng = engine_from_oracle(vi, ld, form)
+        eng.set_hyper(hyper)
+        eng.set_mu(vi_mu)
+        eng.eval(); eng.accept(False)
+        return eng
+    sa, sb = 0.8, 0.4
+    single = {}
+    for step in (sa, sb):
+        eng = fresh()
+        tot = eng.trial(step).cpu().numpy().copy()
+        sums = eng.delta_sums(1).cpu().numpy().copy()
+        eng.accept(True)
+        single[step] = (tot, sums, eng.get_mu(), eng.get_moments(), eng.get_delta())
+        eng.close()
+    for take in (1, 2):
+        eng = fresh()
+        ta, tb = eng.trial2(sa, sb)
+        ta, tb = ta.cpu().numpy().copy(), tb.cpu().numpy().copy()
+        assert np.array_equal(ta, single[sa][0]) and np.array_equal(tb, single[sb][0])
+        sums = eng.delta_sums(1 if take == 1 else 3).cpu().numpy().copy()
+        eng.accept(take)
+        want = single[sa if take == 1 else sb]
+        assert np.array_equal(sums, want[1])
+        assert np.array_equal(eng.get_mu(), want[2])
+        m, v = eng.get_moments()
+        assert np.array_equal(m, want[3][0]) and np.array_equal(v, want[3][1])
+        assert np.array_equal(eng.get_delta(), want[4])
+        # the accepted candidate is a full state: the next trial starts from it
+        nxt = eng.trial(0.5).cpu().numpy().copy()
+        eng2 = fresh()
+        eng2.trial(sa if take == 1 else sb); eng2.accept(True)
+        assert np.array_equal(nxt, eng2.trial(0.5).cpu().numpy())
+        eng.close(); eng2.close()
+    eng = fresh()
+    eng.trial(sa)
+    with pytest.raises(Exception):
+        eng.accept(2)                       # no second candidate after a one-step trial
+    eng.close()
+
+
 def test_errors_are_loud():
     from vilma_amd import _lib
     from vilma_amd.engine import HipEngine

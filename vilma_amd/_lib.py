@@ -21,7 +21,7 @@ def ntotals(P):
     return 3 * P + 2
 
 
-STATE_CURRENT, STATE_TRIAL_BETA, STATE_TRIAL_EVAL = 0, 1, 2
+STATE_CURRENT, STATE_TRIAL_BETA, STATE_TRIAL_EVAL, STATE_TRIAL_BETA_B = 0, 1, 2, 3
 
 _c_double_p = C.POINTER(C.c_double)
 _c_i32_p = C.POINTER(C.c_int32)
@@ -77,6 +77,7 @@ def load():
         'vilma_get_trial_moments': (C.c_int, [vp, vp, vp]),
         'vilma_init_state': (C.c_int, [vp, vp, vp, vp]),
         'vilma_trial_beta': (C.c_int, [vp, vp, C.c_double, vp]),
+        'vilma_trial_beta2': (C.c_int, [vp, vp, C.c_double, C.c_double, vp, vp]),
         'vilma_accept': (C.c_int, [vp, C.c_int]),
         'vilma_delta_sums': (C.c_int, [vp, vp, vp, C.c_int]),
         'vilma_mean_diff': (C.c_int, [vp, vp, vp, vp]),

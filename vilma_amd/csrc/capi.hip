@@ -85,11 +85,16 @@ struct vilma_ctx {
     std::vector<double> log_det_host;
     double tau[VILMA_MAX_P];
 
-    double *mu[2] = {nullptr, nullptr};
-    int mu_cur = 0;
-    double *pool[2] = {nullptr, nullptr};
-    double *m[2] = {nullptr, nullptr}, *v[2] = {nullptr, nullptr}, *lse[2] = {nullptr, nullptr};
-    int mom_cur = 0;
+    // Three buffers of each kind, in the roles current / candidate A / candidate B: a beta trial
+    // may evaluate two step sizes at once (vilma_trial_beta2); plain evaluations and one-step
+    // trials use the A role.  Accepting swaps roles, never copies.
+    double *mu[3] = {nullptr, nullptr, nullptr};
+    int mu_cur = 0, mu_ta = 1, mu_tb = 2;
+    double *pool[3] = {nullptr, nullptr, nullptr};
+    double *m[3] = {nullptr, nullptr, nullptr}, *v[3] = {nullptr, nullptr, nullptr},
+           *lse[3] = {nullptr, nullptr, nullptr};
+    int mom_cur = 0, mom_ta = 1, mom_tb = 2;
+    bool have_b = false;            // candidate B holds the second step of the last trial
     int64_t pool_elems = 0;
     bool have_moments = false;
     bool trial_tainted = false;     // trial moments come from vilma_eval_given_delta
@@ -102,6 +107,8 @@ struct vilma_ctx {
     ItemSet all;
     std::vector<ItemSet> solo;      // per cohort (vilma_ld_matvec with cohort >= 0)
     double *sym_scratch = nullptr;
+    int dot_stride = 0;             // second right-hand side's y.z partials / scratch sit this far
+    int64_t s_stride = 0;           // behind the first one's
     double *pinned = nullptr;       // host staging for vilma_fetch
     int64_t pinned_elems = 0;
     bool ready = false;
@@ -141,7 +148,7 @@ struct vilma_ctx {
     hipEvent_t ev_decided[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     size_t prof_mark = 0;           // pending profiling brackets at the last vilma_spec_save
-    struct Saved { int mu_cur, mom_cur; bool have_moments, snp_marked; } saved{0, 0, false, false};
+    struct Saved { int mu[3], mom[3]; bool have_moments, snp_marked, have_b; } saved{{0, 1, 2}, {0, 1, 2}, false, false, false};
 
     int prof = 0;                   // 0 off, k >= 1: bracket every k-th LD launch
     int64_t prof_tick = 0;
@@ -183,7 +190,7 @@ void free_items(ItemSet &it) {
 }
 
 void free_ready(vilma_ctx *c) {
-    for (int s = 0; s < 2; ++s) { dev_free(c->pool[s]); c->pool[s] = nullptr; }
+    for (int s = 0; s < 3; ++s) { dev_free(c->pool[s]); c->pool[s] = nullptr; }
     dev_free(c->dot_partials); c->dot_partials = nullptr;
     dev_free(c->sym_scratch); c->sym_scratch = nullptr;
     free_items(c->all);
@@ -350,10 +357,13 @@ int ensure_ready(vilma_ctx *c) {
     if (upload_items(c, all, c->all)) return 1;
     const int64_t pool_elems = 2 * (int64_t)c->P * c->N + t_base + 2;
     c->pool_elems = pool_elems;
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 3; ++s)
         if (dev_alloc(c, &c->pool[s], pool_elems)) return 1;
-    if (dev_alloc(c, &c->dot_partials, slot)) return 1;
-    if (dev_alloc(c, &c->sym_scratch, s_base)) return 1;
+    // y.z partials and product scratch for two right-hand sides (a two-step beta trial)
+    c->dot_stride = slot;
+    c->s_stride = s_base;
+    if (dev_alloc(c, &c->dot_partials, 2 * (int64_t)slot)) return 1;
+    if (dev_alloc(c, &c->sym_scratch, 2 * (int64_t)s_base)) return 1;
     c->dot_start = dstart;
     c->ready = true;
     return 0;
@@ -403,37 +413,48 @@ void prof_resolve(vilma_ctx *c) {
 }
 
 // the LD product on pool `pl` (x_ld section -> y_ld section), all cohorts or one
-void run_ld(vilma_ctx *c, hipStream_t s, double *pl, int cohort) {
+// the LD product on pool `pl` (x_ld section -> y_ld section), all cohorts or one; with pl2 the
+// same product for a second right-hand side in the same pass over the LD store (dense blocks:
+// every element loaded once for both; eigen-form blocks: the passes are launched per side)
+void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
     const ItemSet &it = cohort < 0 ? c->all : c->solo[cohort];
     hipEvent_t e0;
     c->prof_now = c->prof > 0 && (c->prof_tick++ % c->prof) == 0;
     if (it.n_sym > 0) {
         prof_begin(c, s, e0);
-        launch_ld_sym(it.sym, it.n_sym, pl, c->sym_scratch, s);
+        launch_ld_sym(it.sym, it.n_sym, pl, pl2, c->sym_scratch, c->s_stride, s);
         prof_end(c, s, e0, VILMA_PROF_LD_SYM);
     }
     // eigen-form blocks, group by group (one group unless VILMA_EIGEN_GROUP_MB says otherwise):
     // both passes over the group's U back to back; one bracket around all = one product
     if (!it.groups.empty()) {
         prof_begin(c, s, e0);
-        for (const EigenGroup &g : it.groups) {
-            launch_ld_colsum(it.a + g.a0, g.na, pl, c->dot_partials,
-                             /*keep=*/it.groups.size() > 1, s);
-            launch_ld_rowsum(it.row + g.r0, g.nr, pl, c->sym_scratch, s);
-            launch_ld_rowsum_combine(it.rcomb + g.c0, g.nc, pl, c->sym_scratch, c->dot_partials, s);
+        for (int side = 0; side < (pl2 ? 2 : 1); ++side) {
+            double *pool = side ? pl2 : pl;
+            double *scratch = c->sym_scratch + side * c->s_stride;
+            double *dots = c->dot_partials + (int64_t)side * c->dot_stride;
+            for (const EigenGroup &g : it.groups) {
+                launch_ld_colsum(it.a + g.a0, g.na, pool, dots, /*keep=*/it.groups.size() > 1, s);
+                launch_ld_rowsum(it.row + g.r0, g.nr, pool, scratch, s);
+                launch_ld_rowsum_combine(it.rcomb + g.c0, g.nc, pool, scratch, dots, s);
+            }
         }
         prof_end(c, s, e0, VILMA_PROF_LD_COLSUM);
     }
     if (it.n_comb > 0)      // not bracketed: tiny, and every event pair costs host time
-        launch_ld_sym_combine(it.comb, it.n_comb, pl, c->sym_scratch, c->dot_partials, s);
+        launch_ld_sym_combine(it.comb, it.n_comb, pl, pl2, c->sym_scratch, c->s_stride,
+                              c->dot_partials, c->dot_stride, s);
     if (c->pending.size() > 8192) prof_resolve(c);
 }
 
 void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
-    const int cur = c->mom_cur, tr = 1 - cur;
+    const int cur = c->mom_cur, tr = c->mom_ta, tb = c->mom_tb;
     a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
     a.mu_in = c->mu[c->mu_cur];
-    a.mu_out = c->mu[1 - c->mu_cur];
+    a.mu_out = c->mu[c->mu_ta];
+    a.mu_out2 = c->mu[c->mu_tb];
+    a.pool_out2 = c->pool[tb]; a.m_out2 = c->m[tb]; a.v_out2 = c->v[tb]; a.lse_out2 = c->lse[tb];
+    a.step2 = 0.0;
     a.adj = c->adj; a.se = c->se; a.sld = c->sld; a.annot = c->annot; a.invperm = c->invperm;
     a.prec = c->prec; a.log_det = c->log_det; a.lh = c->lh;
     a.pool_cur = c->pool[cur]; a.m_cur = c->m[cur];
@@ -444,12 +465,13 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
 }
 
-void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out, bool trial_mu = false,
-                     bool trial_mom = false) {
+// trial_mu / trial_mom: 0 = current, 1 = candidate A, 2 = candidate B
+void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out, int trial_mu = 0, int trial_mom = 0) {
     a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
-    a.mu = c->mu[trial_mu ? 1 - c->mu_cur : c->mu_cur]; a.sld = c->sld; a.annot = c->annot;
+    a.mu = c->mu[trial_mu == 2 ? c->mu_tb : trial_mu == 1 ? c->mu_ta : c->mu_cur];
+    a.sld = c->sld; a.annot = c->annot;
     a.prec = c->prec; a.log_det = c->log_det; a.lh = c->lh;
-    a.lse = c->lse[trial_mom ? 1 - c->mom_cur : c->mom_cur];
+    a.lse = c->lse[trial_mom == 2 ? c->mom_tb : trial_mom == 1 ? c->mom_ta : c->mom_cur];
     a.out = out;
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
 }
@@ -468,22 +490,32 @@ void side_end(vilma_ctx *c, hipStream_t s, hipStream_t used) {
     (void)hipStreamWaitEvent(s, c->ev_side, 0);
 }
 
+// blend: a beta trial at `step`; with totals2_dev also at `step2` in the same pass (candidate B)
 int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *totals_dev,
-             double *dsum_dev = nullptr, double *dmax_dev = nullptr) {
+             double *dsum_dev = nullptr, double *dmax_dev = nullptr, double step2 = 0.0,
+             double *totals2_dev = nullptr) {
     if (ensure_ready(c)) return 1;
     if (blend && !c->have_moments)
         return fail(c, "vilma_trial_beta needs an accepted evaluation of the current state");
+    const bool two = blend && totals2_dev != nullptr;
     SnpKernelArgs a;
     fill_snp_args(c, a, step);
+    a.step2 = step2;
     a.diff = (!blend && dsum_dev && dmax_dev) ? 1 : 0;
-    launch_snp_pass(a, blend, s);
+    launch_snp_pass(a, blend, two ? 2 : 1, s);
     if (c->overlap && c->ev_snp) {
         (void)hipEventRecord(c->ev_snp, s);
         c->snp_marked = true;
     }
-    run_ld(c, s, c->pool[1 - c->mom_cur], -1);
-    launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start.data(),
+    run_ld(c, s, c->pool[c->mom_ta], two ? c->pool[c->mom_tb] : nullptr, -1);
+    const int grid = snp_pass_grid(c->N);
+    launch_finalize(c->snp_partials, grid, c->P, c->dot_partials, c->dot_start.data(),
                     totals_dev, a.diff ? dsum_dev : nullptr, a.diff ? dmax_dev : nullptr, s);
+    if (two)        // candidate B: its partial columns sit behind A's and the statistics columns
+        launch_finalize(c->snp_partials + (int64_t)(2 * c->P + 2 + 6) * grid, grid, c->P,
+                        c->dot_partials + c->dot_stride, c->dot_start.data(), totals2_dev, nullptr,
+                        nullptr, s);
+    c->have_b = two;
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -521,13 +553,13 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     rc |= dev_alloc(c, &c->prec, (int64_t)M * P * P); rc |= dev_alloc(c, &c->log_det, M);
     rc |= dev_alloc(c, &c->lh, (int64_t)A * M);
     rc |= dev_alloc(c, &c->counts, A);
-    for (int s = 0; s < 2 && !rc; ++s) {
+    for (int s = 0; s < 3 && !rc; ++s) {
         rc |= dev_alloc(c, &c->mu[s], (int64_t)M * PN);
         rc |= dev_alloc(c, &c->m[s], PN); rc |= dev_alloc(c, &c->v[s], PN);
         rc |= dev_alloc(c, &c->lse[s], N);
     }
     rc |= dev_alloc(c, &c->snapshot, PN);
-    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * P + 2 + 6));
+    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * (2 * P + 2) + 6));
     // per-wave rows plus the scratch rows of every pass of the column reduction (exact)
     rc |= dev_alloc(c, &c->delta_partials,
                     std::max(delta_partial_rows(N), init_partial_rows(N)) * A * M);
@@ -609,8 +641,8 @@ void vilma_destroy(vilma_ctx *c) {
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->side) (void)hipStreamDestroy(c->side);
     void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
-                    c->lh, c->counts, c->mu[0], c->mu[1], c->m[0], c->m[1], c->v[0], c->v[1], c->lse[0],
-                    c->lse[1], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials};
+                    c->lh, c->counts, c->mu[0], c->mu[1], c->mu[2], c->m[0], c->m[1], c->m[2], c->v[0],
+                    c->v[1], c->v[2], c->lse[0], c->lse[1], c->lse[2], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials};
     for (void *p : ptrs) dev_free(p);
     delete c;
 }
@@ -788,9 +820,9 @@ int vilma_ld_matvec(vilma_ctx *c, void *stream, int cohort, const double *x, dou
     if (cohort >= c->P) return fail(c, "cohort out of range");
     if (ensure_ready(c)) return 1;
     hipStream_t s = (hipStream_t)stream;
-    double *pl = c->pool[1 - c->mom_cur];     // the trial pool doubles as workspace
+    double *pl = c->pool[c->mom_ta];          // the trial pool doubles as workspace
     launch_gather_x(x, c->invperm, pl, (int)c->N, c->P, s);
-    run_ld(c, s, pl, cohort);
+    run_ld(c, s, pl, nullptr, cohort);
     launch_scatter_y(pl + (int64_t)c->P * c->N, c->invperm, y, (int)c->N, c->P, s);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -818,7 +850,7 @@ int vilma_get_delta(vilma_ctx *c, double *vi_delta) {
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     HIPCHK(c, hipDeviceSynchronize());
     // the trial vi_mu buffer ([M][P][N] >= [M][N]) is free between evaluations: use it as scratch
-    double *scratch = c->mu[1 - c->mu_cur];
+    double *scratch = c->mu[c->mu_ta];
     DeltaArgs a;
     fill_delta_args(c, a, scratch);
     launch_delta_write(a, nullptr);
@@ -865,7 +897,7 @@ int vilma_eval_given_delta(vilma_ctx *c, void *stream, const double *delta_km_de
     c->snp_marked = false;          // nothing of this evaluation may overlap on the side stream
     launch_snp_given_delta(a, delta_km_dev, c->lse[c->mom_cur], c->diff_partials,
                            totals_dev + VILMA_NTOTALS(c->P), s);
-    run_ld(c, s, c->pool[1 - c->mom_cur], -1);
+    run_ld(c, s, c->pool[c->mom_ta], nullptr, -1);
     launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start.data(),
                     totals_dev, nullptr, nullptr, s);
     HIPCHK(c, hipGetLastError());
@@ -878,8 +910,8 @@ int vilma_get_trial_moments(vilma_ctx *c, double *mean, double *var) {
     if (!c->ready) return fail(c, "no trial state");
     HIPCHK(c, hipDeviceSynchronize());
     const size_t b = (size_t)c->P * c->N * sizeof(double);
-    if (mean) HIPCHK(c, hipMemcpy(mean, c->m[1 - c->mom_cur], b, hipMemcpyDefault));
-    if (var) HIPCHK(c, hipMemcpy(var, c->v[1 - c->mom_cur], b, hipMemcpyDefault));
+    if (mean) HIPCHK(c, hipMemcpy(mean, c->m[c->mom_ta], b, hipMemcpyDefault));
+    if (var) HIPCHK(c, hipMemcpy(var, c->v[c->mom_ta], b, hipMemcpyDefault));
     return 0;
 }
 
@@ -908,14 +940,31 @@ int vilma_trial_beta(vilma_ctx *c, void *stream, double step, double *totals_dev
     return evaluate(c, (hipStream_t)stream, true, step, totals_dev);
 }
 
+int vilma_trial_beta2(vilma_ctx *c, void *stream, double step_a, double step_b,
+                      double *totals_a_dev, double *totals_b_dev) {
+    if (!c) return 1;
+    if (!totals_a_dev || !totals_b_dev) return fail(c, "vilma_trial_beta2 needs both outputs");
+    c->trial_tainted = false;
+    return evaluate(c, (hipStream_t)stream, true, step_a, totals_a_dev, nullptr, nullptr, step_b,
+                    totals_b_dev);
+}
+
 int vilma_accept(vilma_ctx *c, int take_mu) {
     if (!c) return 1;
     if (!c->ready) return fail(c, "nothing to accept");
+    if (take_mu < 0 || take_mu > 2) return fail(c, "vilma_accept: take_mu must be 0, 1 or 2");
     if (c->trial_tainted)
         return fail(c, "the trial state was evaluated with a caller-supplied vi_delta and cannot "
                        "be accepted");
-    c->mom_cur = 1 - c->mom_cur;
-    if (take_mu) c->mu_cur = 1 - c->mu_cur;
+    if (take_mu == 2) {
+        if (!c->have_b) return fail(c, "no second candidate: the last trial was not vilma_trial_beta2");
+        std::swap(c->mom_cur, c->mom_tb);
+        std::swap(c->mu_cur, c->mu_tb);
+    } else {
+        std::swap(c->mom_cur, c->mom_ta);
+        if (take_mu) std::swap(c->mu_cur, c->mu_ta);
+    }
+    c->have_b = false;
     c->have_moments = true;
     return 0;
 }
@@ -926,9 +975,11 @@ int vilma_delta_sums(vilma_ctx *c, void *stream, double *sums_dev, int which) {
         return fail(c, "no accepted evaluation of the current state");
     if (which != VILMA_STATE_CURRENT && !c->ready) return fail(c, "no trial state");
     DeltaArgs a;
+    if (which == VILMA_STATE_TRIAL_BETA_B && !c->have_b) return fail(c, "no second candidate");
     // the trial of a beta step has its own vi_mu; the trial of a plain evaluation shares it
-    fill_delta_args(c, a, c->delta_partials, which == VILMA_STATE_TRIAL_BETA,
-                    which != VILMA_STATE_CURRENT);
+    fill_delta_args(c, a, c->delta_partials,
+                    which == VILMA_STATE_TRIAL_BETA ? 1 : which == VILMA_STATE_TRIAL_BETA_B ? 2 : 0,
+                    which == VILMA_STATE_CURRENT ? 0 : which == VILMA_STATE_TRIAL_BETA_B ? 2 : 1);
     // a trial state's sums depend on its per-SNP pass alone: overlap them with its LD product
     hipStream_t s = (hipStream_t)stream;
     hipStream_t q = which == VILMA_STATE_CURRENT ? s : side_begin(c, s);
@@ -1083,15 +1134,18 @@ int vilma_fetch_end(vilma_ctx *c, int buffer, double *dst_host, int64_t n, int *
 
 int vilma_spec_save(vilma_ctx *c) {
     if (!c) return 1;
-    c->saved = {c->mu_cur, c->mom_cur, c->have_moments, c->snp_marked};
+    c->saved = {{c->mu_cur, c->mu_ta, c->mu_tb}, {c->mom_cur, c->mom_ta, c->mom_tb},
+                c->have_moments, c->snp_marked, c->have_b};
     c->prof_mark = c->pending.size();
     return 0;
 }
 
 int vilma_spec_restore(vilma_ctx *c) {
     if (!c) return 1;
-    c->mu_cur = c->saved.mu_cur; c->mom_cur = c->saved.mom_cur;
+    c->mu_cur = c->saved.mu[0]; c->mu_ta = c->saved.mu[1]; c->mu_tb = c->saved.mu[2];
+    c->mom_cur = c->saved.mom[0]; c->mom_ta = c->saved.mom[1]; c->mom_tb = c->saved.mom[2];
     c->have_moments = c->saved.have_moments; c->snp_marked = c->saved.snp_marked;
+    c->have_b = c->saved.have_b;
     // the launches of a stage that did not run were bracketed like any other: drop them, or the
     // average LD-product time would include empty kernels
     while (c->pending.size() > c->prof_mark) {

@@ -89,11 +89,15 @@ struct SnpKernelArgs {
     double *pool_out;         // trial pool (x_ld written)
     double *m_out, *v_out;    // [P][N]
     double *lse_out;          // [N]
-    double *partials;         // [2P+2 (+6)][grid] (column-major: finalize reads columns)
+    double *partials;         // [2P+2 | 6 | 2P+2][grid] (column-major: finalize reads columns):
+                              // candidate sums, fused statistics, second candidate's sums
     const double *scal;       // [P][N] scalings            } used when diff != 0 (plain
     double *snapshot;         // [P][N] real_posterior_mean } evaluations only)
     int32_t diff;             // fuse the convergence statistics into this evaluation
     double step;
+    // second candidate of a two-step beta trial (launch_snp_pass with ns = 2)
+    double step2;
+    double *mu_out2, *pool_out2, *m_out2, *v_out2, *lse_out2;
     TauArg tau;
     const int *pred;          // filled by the launcher (set_launch_predicate)
 };
@@ -109,7 +113,8 @@ void launch_decide(int P, int check_convergence, const double *totals, const dou
                    double *out_obj, const double *results, int n_results, double *snap,
                    const int *flags, hipStream_t s);
 
-void launch_snp_pass(const SnpKernelArgs &a, bool blend, hipStream_t s);
+// ns = 2: a beta trial at the two step sizes a.step / a.step2, second candidate into the *2 outputs
+void launch_snp_pass(const SnpKernelArgs &a, bool blend, int ns, hipStream_t s);
 int snp_pass_grid(int64_t N);
 
 // keep = true: default cache policy (the stream is read again by launch_ld_rowsum right after);
@@ -120,10 +125,13 @@ void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool, dou
                       hipStream_t s);
 void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool,
                               const double *scratch, double *dot_partials, hipStream_t s);
-void launch_ld_sym(const SymItem *items, int n_items, const double *pool, double *scratch,
-                   hipStream_t s);
-void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
-                           const double *scratch, double *dot_partials, hipStream_t s);
+// pool1 != nullptr: two right-hand sides in one pass over the LD store; the second one's scratch
+// sits s_stride doubles, its y.z partials dot_stride slots behind the first one's
+void launch_ld_sym(const SymItem *items, int n_items, const double *pool0, const double *pool1,
+                   double *scratch, int64_t s_stride, hipStream_t s);
+void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0, double *pool1,
+                           const double *scratch, int64_t s_stride, double *dot_partials,
+                           int dot_stride, hipStream_t s);
 
 // totals[0..2P) and [3P..3P+3) from the per-SNP partials, totals[2P..3P) from the matvec dots
 // with dsum/dmax non-null also the six fused convergence statistics (columns 2P+2..2P+7 of the

@@ -250,12 +250,8 @@ static __device__ __forceinline__ void sym_group(const v2d (&v)[CS_ROWS], const 
 // the 128-byte lines up to the diagonal are loaded at all (lanes past them are masked off):
 // 56 % of a 128 x 128 tile.  Row sums of the tile go to LDS (they belong to the same output
 // entries as the tile's column sums).
-static __device__ __forceinline__ void sym_group_diag(const double *__restrict__ rp, int64_t ld,
-                                                      const double *__restrict__ xrow, int r0,
-                                                      int rows, int cl, double xs0, double xs1,
-                                                      double &acc0, double &acc1, int lane,
-                                                      double *__restrict__ rs_lds) {
-    v2d v[CS_ROWS];
+static __device__ __forceinline__ void sym_load_diag(v2d (&v)[CS_ROWS], const double *__restrict__ rp,
+                                                     int64_t ld, int r0, int rows, int lane) {
     // columns needed by rows r0..r0+7: c <= r0+7, rounded up to whole 16-double lines
     const int lim = 8 * ((r0 + CS_ROWS - 1) / 16 + 1);           // lanes (2 columns each)
     if (lane < lim) {
@@ -266,6 +262,12 @@ static __device__ __forceinline__ void sym_group_diag(const double *__restrict__
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u) v[u] = v2d{0.0, 0.0};
     }
+}
+static __device__ __forceinline__ void sym_group_diag(const v2d (&v)[CS_ROWS],
+                                                      const double *__restrict__ xrow, int r0,
+                                                      int rows, int cl, double xs0, double xs1,
+                                                      double &acc0, double &acc1, int lane,
+                                                      double *__restrict__ rs_lds) {
     double p[CS_ROWS];
 #pragma unroll
     for (int u = 0; u < CS_ROWS; ++u) {
@@ -284,11 +286,18 @@ static __device__ __forceinline__ void sym_group_diag(const double *__restrict__
     if ((lane & 7) == 0 && rr < rows) rs_lds[rr] = t1;
 }
 
+// NR right-hand sides per pass over the panel (1, or 2 for the two candidates of a beta trial):
+// every element is loaded once and used for each of them -- the kernel is HBM-bound with the
+// vector ALUs a few percent busy, so the second product is free.  Right-hand side r reads its x
+// from pool r and writes its partials at scratch + r * s_stride; each goes through exactly the
+// arithmetic of the NR = 1 kernel.
+struct PoolPair { const double *p[2]; };
+template <int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
-    const SymItem *__restrict__ items, const double *__restrict__ xpool,
-    double *__restrict__ scratch, const int *pred) {
-    __shared__ double red[CS_WAVES][128];
-    __shared__ double rs_diag[128];
+    const SymItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred) {
+    __shared__ double red[NR][CS_WAVES][128];
+    __shared__ double rs_diag[NR][128];
     PRED_EXIT(pred);
     const SymItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
@@ -298,63 +307,92 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     const int rows = it.rows;
     const int64_t ld = it.ld;
     const bool has_diag = it.r0 == 0;                                // chunk 0 holds the diagonal tile
-    const double *__restrict__ xcol = xpool + it.x_off + it.j0;     // x of the slab's columns
-    const double *__restrict__ xrow = xcol + it.r0;                 // x of this chunk's rows
-    // x of this lane's two columns (the slab's columns are rows j0.. of the same vector)
-    const double xs0 = active ? xcol[cl] : 0.0;
-    const double xs1 = (cl + 1 < it.w) ? xcol[cl + 1] : 0.0;
+    const double *xrow[NR];
+    double *srow[NR];
+    double xs0[NR], xs1[NR], acc0[NR], acc1[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double *xcol = pools.p[r] + it.x_off + it.j0;          // x of the slab's columns
+        xrow[r] = xcol + it.r0;                                      // x of this chunk's rows
+        // x of this lane's two columns (the slab's columns are rows j0.. of the same vector)
+        xs0[r] = active ? xcol[cl] : 0.0;
+        xs1[r] = (cl + 1 < it.w) ? xcol[cl + 1] : 0.0;
+        srow[r] = scratch + r * s_stride + it.s_off + it.j0 + it.r0;
+        acc0[r] = 0.0;
+        acc1[r] = 0.0;
+    }
     // loads are unconditional within a group (a select around a load makes hipcc branch and wait
     // per element): lanes beyond the slab read column 0 and are neutralised by xs = 0
     const double *ap = it.a + (active ? cl : 0);
-    double *__restrict__ srow = scratch + it.s_off + it.j0 + it.r0;
-    double acc0 = 0.0, acc1 = 0.0;
     const int ngroups = (rows + CS_ROWS - 1) / CS_ROWS;     // group g belongs to wave g % 4
     const int ndiag = has_diag ? (it.w + CS_ROWS - 1) / CS_ROWS : 0;   // groups inside the diagonal tile
     const int nfull = rows / CS_ROWS;
     const int64_t gstride = (int64_t)CS_WAVES * CS_ROWS * ld;
     const double *rp = ap + (int64_t)w * CS_ROWS * ld;
     int g = w;
+    v2d v[CS_ROWS];
     // (1) the diagonal tile: lower triangle only
-    for (; g < ndiag && g < ngroups; g += CS_WAVES, rp += gstride)
-        sym_group_diag(rp, ld, xrow, g * CS_ROWS, rows, active ? cl : 2 * 64, xs0, xs1, acc0, acc1,
-                       lane, rs_diag);
+    for (; g < ndiag && g < ngroups; g += CS_WAVES, rp += gstride) {
+        sym_load_diag(v, rp, ld, g * CS_ROWS, rows, lane);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            sym_group_diag(v, xrow[r], g * CS_ROWS, rows, active ? cl : 2 * 64, xs0[r], xs1[r],
+                           acc0[r], acc1[r], lane, rs_diag[r]);
+    }
     // (2) the rows below it: plain loop, 8 x 1 KiB loads in flight per wave, latency hidden by
     // occupancy (a manually software-pipelined version measured the same, 1.20 ms @C3)
-    v2d v[CS_ROWS];
     for (; g < nfull; g += CS_WAVES, rp += gstride) {
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u) v[u] = LD_STREAM_LOAD(rp + (int64_t)u * ld);
-        sym_group<true>(v, xrow, g * CS_ROWS, rows, xs0, xs1, acc0, acc1, lane, srow);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            sym_group<true>(v, xrow[r], g * CS_ROWS, rows, xs0[r], xs1[r], acc0[r], acc1[r], lane,
+                            srow[r]);
     }
     if (g == nfull && g < ngroups) {                        // the one partial group, below the tile
         const int r0 = nfull * CS_ROWS;
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u)     // rows past the end re-read the last row
             v[u] = LD_STREAM_LOAD(ap + (int64_t)min(r0 + u, rows - 1) * ld);
-        sym_group<false>(v, xrow, r0, rows, xs0, xs1, acc0, acc1, lane, srow);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            sym_group<false>(v, xrow[r], r0, rows, xs0[r], xs1[r], acc0[r], acc1[r], lane, srow[r]);
     }
-    red[w][2 * lane] = acc0;
-    red[w][2 * lane + 1] = acc1;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        red[r][w][2 * lane] = acc0[r];
+        red[r][w][2 * lane + 1] = acc1[r];
+    }
     __syncthreads();
     if ((int)threadIdx.x < it.w) {
-        double s = red[0][threadIdx.x];
 #pragma unroll
-        for (int ww = 1; ww < CS_WAVES; ++ww) s += red[ww][threadIdx.x];
-        // this chunk's share of the slab's own entries: its column sums (+ the diagonal tile's
-        // row sums, which belong to the same entries)
-        scratch[it.c_off + threadIdx.x] = has_diag ? s + rs_diag[threadIdx.x] : s;
+        for (int r = 0; r < NR; ++r) {
+            double s = red[r][0][threadIdx.x];
+#pragma unroll
+            for (int ww = 1; ww < CS_WAVES; ++ww) s += red[r][ww][threadIdx.x];
+            // this chunk's share of the slab's own entries: its column sums (+ the diagonal
+            // tile's row sums, which belong to the same entries)
+            scratch[r * s_stride + it.c_off + threadIdx.x] = has_diag ? s + rs_diag[r][threadIdx.x] : s;
+        }
     }
 }
 
 // y[j] for 256 columns of one block per workgroup: the row sums S[J][j] of the slabs to the left
 // (J < slab(j), slab order) then the column-sum chunks of j's own slab (chunk order) -- a fixed
 // order -- with the chunk's y.z partial.  The slab index is wave-uniform; eight loads in flight.
+// blockIdx.y = right-hand side (its own pool, scratch and partials behind the first one's).
+struct PoolPairRW { double *p[2]; };
 __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
-    const SymCombItem *__restrict__ items, const double *__restrict__ xpool,
-    double *__restrict__ ypool, const double *__restrict__ scratch,
-    double *__restrict__ dot_partials, const int *pred) {
+    const SymCombItem *__restrict__ items, const PoolPairRW pools,
+    const double *__restrict__ scratch0, int64_t s_stride, double *__restrict__ dot_partials0,
+    int dot_stride, const int *pred) {
     __shared__ double dred[4];
     PRED_EXIT(pred);
+    const int rhs = blockIdx.y;
+    const double *__restrict__ xpool = pools.p[rhs];
+    double *__restrict__ ypool = pools.p[rhs];
+    const double *__restrict__ scratch = scratch0 + rhs * s_stride;
+    double *__restrict__ dot_partials = dot_partials0 + (int64_t)rhs * dot_stride;
     const SymCombItem it = items[blockIdx.x];
     const int j = it.j0 + threadIdx.x;
     const bool live = j < it.n;
@@ -386,18 +424,30 @@ __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
     if (threadIdx.x == 0) dot_partials[it.dot_slot] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
-void launch_ld_sym(const SymItem *items, int n_items, const double *pool, double *scratch,
-                   hipStream_t s) {
+// pool1 == nullptr: one right-hand side; else two (pool0 and pool1 hold the two candidates' x)
+void launch_ld_sym(const SymItem *items, int n_items, const double *pool0, const double *pool1,
+                   double *scratch, int64_t s_stride, hipStream_t s) {
     if (n_items <= 0) return;
-    hipLaunchKernelGGL(ld_sym_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pool, scratch,
-                       g_pred);
+    PoolPair pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    if (pool1)
+        hipLaunchKernelGGL(ld_sym_kernel<2>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pp,
+                           scratch, s_stride, g_pred);
+    else
+        hipLaunchKernelGGL(ld_sym_kernel<1>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pp,
+                           scratch, s_stride, g_pred);
 }
 
-void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool,
-                           const double *scratch, double *dot_partials, hipStream_t s) {
+void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0, double *pool1,
+                           const double *scratch, int64_t s_stride, double *dot_partials,
+                           int dot_stride, hipStream_t s) {
     if (n_items <= 0) return;
-    hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items), dim3(256), 0, s, items,
-                       (const double *)pool, pool, scratch, dot_partials, g_pred);
+    PoolPairRW pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items, pool1 ? 2 : 1), dim3(256), 0, s, items,
+                       pp, scratch, s_stride, dot_partials, dot_stride, g_pred);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -588,8 +638,14 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 // (Splitting the components of one SNP over 4 lanes to get 4x the waves on small shards was
 // measured and rejected for this kernel: 63 vs 52 us per evaluation at 131 k SNPs -- the
 // per-component tables stop being wave-uniform.  It does pay for delta_kernel below.)
-template <int P, bool BLEND, bool ONE_ANNOT>
+// NS = candidates evaluated in one pass: 1, or 2 for a beta trial at the step sizes `step` and
+// `step2` (the line search's current L and the L it would try next, variational_inference.py:
+// 777-800) -- vi_mu, Lam_k, Sig_k and the per-component tables are loaded / formed once and shared,
+// so the second candidate costs its own blend, softmax and stores only.  Each candidate goes
+// through exactly the arithmetic of the NS = 1 kernel, in the same order.
+template <int P, bool BLEND, bool ONE_ANNOT, int NS>
 __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
+    static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
     constexpr int NT = 2 * P + 2;
     __shared__ double red[SNP_THREADS / 64][NT < 6 ? 6 : NT];
     PRED_EXIT(a.pred);
@@ -620,7 +676,11 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
         }
     }
     const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
-    const double step = a.step;
+    double step[NS];
+    double *mu_out[NS];
+    step[0] = a.step;
+    mu_out[0] = a.mu_out;
+    if (NS == 2) { step[NS - 1] = a.step2; mu_out[NS - 1] = a.mu_out2; }
 
     // Responsibilities delta_k ~ exp(u_k), u_k = 0.5 (quad_k - log det Lam_k) + lh_k, are
     // accumulated as w_k exp(a_k - max a) with a_k = 0.5 quad_k + lh_k and w_k = det^-1/2: an
@@ -628,10 +688,13 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     // fast_delta_kl and fast_beta_kl cancel, so their sum needs only quad_k and tr(Prec_k Sig_k).
     // Online softmax with ONE exp per component: with d = a_k - max, t = exp(-|d|) is the weight
     // of the new term when d <= 0 and the rescale factor of the running sums when d > 0.
-    double mx = NEG_INF, Z = 0.0, Skl = 0.0, Sip = 0.0;
-    double Sm[P], S2[P];
+    double mx[NS], Z[NS], Skl[NS], Sip[NS], Sm[NS][P], S2[NS][P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) { Sm[p] = 0.0; S2[p] = 0.0; }
+    for (int c = 0; c < NS; ++c) {
+        mx[c] = NEG_INF; Z[c] = 0.0; Skl[c] = 0.0; Sip[c] = 0.0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { Sm[c][p] = 0.0; S2[c][p] = 0.0; }
+    }
 
     // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
     // buffered: the loads of batch b+1 are issued BEFORE batch b is folded in and its new vi_mu
@@ -671,7 +734,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
         for (int kk = 0; kk < KB; ++kk) {
             const int k = k0 + kk;
             if (k >= M) break;
-            double pr[P][P], lam[P][P], sig[P][P], nat[P], mun[P];
+            double pr[P][P], lam[P][P], sig[P][P], told[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
 #pragma unroll
@@ -684,51 +747,58 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
             const double lhk = TAB_AHEAD ? lht[kk] : (ONE_ANNOT ? lh_tab[k] : lhv[kk]);
             const double wk = spd_inverse<P>(lam, sig);
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
+            for (int p = 0; p < P; ++p) {              // Lam_k mu_k: the old natural parameter
                 double t = 0.0;
 #pragma unroll
                 for (int q = 0; q < P; ++q) t += lam[p][q] * mul[kk][q];
-                nat[p] = BLEND ? (step * g[p] + (1.0 - step) * t) : t;
+                told[p] = t;
             }
-            double quad = 0.0;
+            // tr(Prec Sig) = tr(I) - tr(D Sig) = P - sum_p d_p Sig_pp: the same for every candidate
+            double tr = (double)P;
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                double t = mul[kk][p];
-                if (BLEND) {
-                    t = 0.0;
+            for (int p = 0; p < P; ++p) tr = fma(-d[p], sig[p][p], tr);
 #pragma unroll
-                    for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
-                    if (live) MU_STORE(&a.mu_out[((int64_t)k * P + p) * N64 + i], t);
+            for (int c = 0; c < NS; ++c) {
+                double nat[P], mun[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    nat[p] = BLEND ? (step[c] * g[p] + (1.0 - step[c]) * told[p]) : told[p];
+                double quad = 0.0;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double t = mul[kk][p];
+                    if (BLEND) {
+                        t = 0.0;
+#pragma unroll
+                        for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+                        if (live) MU_STORE(&mu_out[c][((int64_t)k * P + p) * N64 + i], t);
+                    }
+                    mun[p] = t;
+                    quad += t * nat[p];
                 }
-                mun[p] = t;
-                quad += t * nat[p];
-            }
-            // mu^T Prec mu and tr(Prec Sig) through Lam = Prec + D (D diagonal), Sig = Lam^-1:
-            //   mu^T Prec mu = mu^T Lam mu - sum_p d_p mu_p^2 = quad - sum_p d_p mu_p^2
-            //   tr(Prec Sig) = tr(I) - tr(D Sig)              = P    - sum_p d_p Sig_pp
-            // 2P+1 operations instead of 3P^2 (the double sums were a fifth of the P = 4 pass);
-            // the cancellation costs at most ~P eps absolute per (component, SNP) in terms that
-            // enter the ELBO additively next to O(1) neighbours.
-            double ip = quad, tr = (double)P;
+                // mu^T Prec mu through Lam = Prec + D (D diagonal), Sig = Lam^-1:
+                //   mu^T Prec mu = mu^T Lam mu - sum_p d_p mu_p^2 = quad - sum_p d_p mu_p^2
+                // (2P+1 operations with tr above instead of 3P^2; the cancellation costs at most
+                // ~P eps absolute per (component, SNP) in terms that enter the ELBO additively
+                // next to O(1) neighbours)
+                double ip = quad;
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                ip = fma(-d[p] * mun[p], mun[p], ip);
-                tr = fma(-d[p], sig[p][p], tr);
-            }
-            const double ak = 0.5 * quad + lhk;
-            const double dk = ak - mx;
-            const double t = exp(-fabs(dk));
-            const bool up = dk > 0.0;
-            const double sc = up ? t : 1.0;
-            const double e = wk * (up ? 1.0 : t);
-            mx = up ? ak : mx;
-            Z = fma(Z, sc, e);
-            Skl = fma(Skl, sc, e * (0.5 * (quad + tr)));
-            Sip = fma(Sip, sc, e * ip);
+                for (int p = 0; p < P; ++p) ip = fma(-d[p] * mun[p], mun[p], ip);
+                const double ak = 0.5 * quad + lhk;
+                const double dk = ak - mx[c];
+                const double t = exp(-fabs(dk));
+                const bool up = dk > 0.0;
+                const double sc = up ? t : 1.0;
+                const double e = wk * (up ? 1.0 : t);
+                mx[c] = up ? ak : mx[c];
+                Z[c] = fma(Z[c], sc, e);
+                Skl[c] = fma(Skl[c], sc, e * (0.5 * (quad + tr)));
+                Sip[c] = fma(Sip[c], sc, e * ip);
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                Sm[p] = fma(Sm[p], sc, e * mun[p]);
-                S2[p] = fma(S2[p], sc, e * (sig[p][p] + mun[p] * mun[p]));
+                for (int p = 0; p < P; ++p) {
+                    Sm[c][p] = fma(Sm[c][p], sc, e * mun[p]);
+                    S2[c][p] = fma(S2[c][p], sc, e * (sig[p][p] + mun[p] * mun[p]));
+                }
             }
         }
     };
@@ -743,37 +813,46 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
         fold(bufB, lhB, k0 + KB);
     }
     const bool owner = live;
-    const double invZ = 1.0 / Z;
-    const double lse = mx + log(Z);
-    double part[NT], mpost[P];
+    double mpost[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const double m = Sm[p] * invZ;
-        const double v = S2[p] * invZ - m * m;
-        mpost[p] = m;
-        if (owner) {
-            a.m_out[p * N64 + i] = m;
-            a.v_out[p * N64 + i] = v;
-            a.pool_out[p * N64 + a.invperm[p * N64 + i]] = m / se[p];
+    for (int c = 0; c < NS; ++c) {
+        double *m_out = c == 0 ? a.m_out : a.m_out2, *v_out = c == 0 ? a.v_out : a.v_out2;
+        double *pool_out = c == 0 ? a.pool_out : a.pool_out2;
+        double *lse_out = c == 0 ? a.lse_out : a.lse_out2;
+        const double invZ = 1.0 / Z[c];
+        const double lse = mx[c] + log(Z[c]);
+        double part[NT];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const double m = Sm[c][p] * invZ;
+            const double v = S2[c][p] * invZ - m * m;
+            if (c == 0) mpost[p] = m;
+            if (owner) {
+                m_out[p * N64 + i] = m;
+                v_out[p * N64 + i] = v;
+                pool_out[p * N64 + a.invperm[p * N64 + i]] = m / se[p];
+            }
+            part[p] = owner ? m * adj[p] : 0.0;
+            part[P + p] = owner ? sld[p] * v : 0.0;
         }
-        part[p] = owner ? m * adj[p] : 0.0;
-        part[P + p] = owner ? sld[p] * v : 0.0;
-    }
-    if (owner) a.lse_out[i] = lse;
-    part[2 * P] = owner ? (Skl * invZ - lse) : 0.0;
-    part[2 * P + 1] = owner ? 0.5 * Sip * invZ : 0.0;
+        if (owner) lse_out[i] = lse;
+        part[2 * P] = owner ? (Skl[c] * invZ - lse) : 0.0;
+        part[2 * P + 1] = owner ? 0.5 * Sip[c] * invZ : 0.0;
 
+        if (c > 0) __syncthreads();               // red[] is being reused
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const double s = wave_sum(part[t]);
-        if (lane == 0) red[w][t] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < NT) {
-        double s = red[0][threadIdx.x];
+        for (int t = 0; t < NT; ++t) {
+            const double s = wave_sum(part[t]);
+            if (lane == 0) red[w][t] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < NT) {
+            double s = red[0][threadIdx.x];
 #pragma unroll
-        for (int ww = 1; ww < SNP_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
-        a.partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+            for (int ww = 1; ww < SNP_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
+            // candidate c's columns sit behind the first candidate's (and the 6 statistics columns)
+            a.partials[(int64_t)(c * (NT + 6) + threadIdx.x) * gridDim.x + blockIdx.x] = s;
+        }
     }
     // Convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
     // fused into an evaluation the caller accepts unconditionally (the one after the M-step):
@@ -817,26 +896,30 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
 int snp_pass_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
 
 template <int P>
-static void launch_snp_pass_p(const SnpKernelArgs &a, bool blend, hipStream_t s) {
+static void launch_snp_pass_p(const SnpKernelArgs &a, bool blend, int ns, hipStream_t s) {
     const dim3 grid(snp_pass_grid(a.N)), block(SNP_THREADS);
     const bool one = a.A == 1;
-    if (blend) {
-        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((snp_pass_kernel<P, true, false>), grid, block, 0, s, a);
+    if (blend && ns == 2) {
+        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, true, true, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((snp_pass_kernel<P, true, false, 2>), grid, block, 0, s, a);
+    } else if (blend) {
+        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, true, true, 1>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((snp_pass_kernel<P, true, false, 1>), grid, block, 0, s, a);
     } else {
-        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((snp_pass_kernel<P, false, false>), grid, block, 0, s, a);
+        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, false, true, 1>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((snp_pass_kernel<P, false, false, 1>), grid, block, 0, s, a);
     }
 }
 
-void launch_snp_pass(const SnpKernelArgs &args, bool blend, hipStream_t s) {
+// ns = 1: one candidate (or a plain evaluation); ns = 2: a beta trial at a.step and a.step2
+void launch_snp_pass(const SnpKernelArgs &args, bool blend, int ns, hipStream_t s) {
     SnpKernelArgs a = args;
     a.pred = g_pred;
     switch (a.P) {
-        case 1: launch_snp_pass_p<1>(a, blend, s); break;
-        case 2: launch_snp_pass_p<2>(a, blend, s); break;
-        case 3: launch_snp_pass_p<3>(a, blend, s); break;
-        case 4: launch_snp_pass_p<4>(a, blend, s); break;
+        case 1: launch_snp_pass_p<1>(a, blend, ns, s); break;
+        case 2: launch_snp_pass_p<2>(a, blend, ns, s); break;
+        case 3: launch_snp_pass_p<3>(a, blend, ns, s); break;
+        case 4: launch_snp_pass_p<4>(a, blend, ns, s); break;
         default: break;   // rejected in vilma_create
     }
 }

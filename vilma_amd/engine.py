@@ -26,11 +26,12 @@ class ResultLayout:
         self.nt, self.am = nt, am
         self.dsum = slice(0, 3)                        # convergence statistics, additive part
         self.totals = slice(3, 3 + nt)                 # sums of a plain evaluation (vilma_eval)
-        self.ttotals = slice(3 + nt, 3 + 2 * nt)       # sums of a beta trial (vilma_trial_beta)
-        self.sums = slice(3 + 2 * nt, 3 + 2 * nt + am)  # responsibility sums
-        self.dmax = slice(3 + 2 * nt + am, 6 + 2 * nt + am)
-        self.hyper = slice(6 + 2 * nt + am, 6 + 2 * nt + 2 * am)
-        self.size = 6 + 2 * nt + 2 * am
+        self.ttotals = slice(3 + nt, 3 + 2 * nt)       # sums of a beta trial (candidate A)
+        self.ttotals_b = slice(3 + 2 * nt, 3 + 3 * nt)  # ... of the second step of a two-step trial
+        self.sums = slice(3 + 3 * nt, 3 + 3 * nt + am)  # responsibility sums
+        self.dmax = slice(3 + 3 * nt + am, 6 + 3 * nt + am)
+        self.hyper = slice(6 + 3 * nt + am, 6 + 3 * nt + 2 * am)
+        self.size = 6 + 3 * nt + 2 * am
 
 
 class HipEngine:
@@ -54,8 +55,8 @@ class HipEngine:
         self.refresh_stream()
         # One device tensor for every small result, so a decision needs a single D2H copy and the
         # parts that are summed over ranks are contiguous:
-        #   [diff sums (3) | eval totals (3P+2) | trial totals (3P+2) | delta sums (A*M) |
-        #    diff maxima (3) | hyper (A*M)]
+        #   [diff sums (3) | eval totals (3P+2) | trial totals A (3P+2) | trial totals B (3P+2) |
+        #    delta sums (A*M) | diff maxima (3) | hyper (A*M)]
         nt, am = _lib.ntotals(self.P), self.A * self.M
         self.layout = ResultLayout(nt, am)
         self.results = torch.zeros(self.layout.size, dtype=torch.float64, device=self.device)
@@ -63,6 +64,7 @@ class HipEngine:
         self._dsum = self.results[L.dsum]
         self._totals = self.results[L.totals]
         self._ttotals = self.results[L.ttotals]
+        self._ttotals_b = self.results[L.ttotals_b]
         self._sums = self.results[L.sums]
         self._dmax = self.results[L.dmax]
         self._hyper = self.results[L.hyper]
@@ -70,7 +72,7 @@ class HipEngine:
         # launch costs about a microsecond of host time on the decision path)
         self._p = {name: C.c_void_p(t.data_ptr()) for name, t in (
             ('results', self.results), ('dsum', self._dsum), ('totals', self._totals),
-            ('ttotals', self._ttotals), ('sums', self._sums), ('dmax', self._dmax),
+            ('ttotals', self._ttotals), ('ttotals_b', self._ttotals_b), ('sums', self._sums), ('dmax', self._dmax),
             ('hyper', self._hyper))}
         self.n_totals = nt
         self._host = np.zeros(L.size)
@@ -270,8 +272,17 @@ class HipEngine:
                                               self._p['ttotals']))
         return self._ttotals
 
+    def trial2(self, step_a, step_b):
+        """A beta trial at two step sizes in one pass over vi_mu and the LD store (candidates A
+        and B; accept(1) / accept(2))."""
+        self._check(self.lib.vilma_trial_beta2(self.ctx, self._stream_handle, float(step_a),
+                                               float(step_b), self._p['ttotals'],
+                                               self._p['ttotals_b']))
+        return self._ttotals, self._ttotals_b
+
     def accept(self, take_mu):
-        self._check(self.lib.vilma_accept(self.ctx, 1 if take_mu else 0))
+        """0 / False: the last eval's moments; 1 / True: trial candidate A; 2: candidate B."""
+        self._check(self.lib.vilma_accept(self.ctx, int(take_mu)))
 
     def fetch(self):
         """The whole result vector on the host (one pinned D2H copy behind the current stream)."""

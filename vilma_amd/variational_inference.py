@@ -155,7 +155,14 @@ class SweepDriver:
         self._hyper = None
         self._totals = None         # all-reduced sums of the current (accepted) state
         self._objective = None
-        self.n_evaluations = 0      # candidate points evaluated (= LD products per cohort)
+        self.n_evaluations = 0      # candidate points whose objective was looked at
+        self.n_products = 0         # passes over the LD store (a two-step trial is one)
+        self._alt = None            # second candidate of the last two-step trial, not looked at yet
+        self._candidate = 1
+        self._lsr = 2.
+        # two-step beta trials need vilma_trial_beta2 (VILMA_TWO_STEP=0: one step per pass)
+        self._two_step = (hasattr(self.engine, 'trial2')
+                          and os.environ.get('VILMA_TWO_STEP', '1') != '0')
         self.n_trials = 0           # beta line-search trials among them
         self.n_stages_ahead = 0     # sweeps whose M-step stage ran ahead of the host's decision
         self.n_stages_skipped = 0   # stages queued ahead whose decision went the other way: their
@@ -225,39 +232,65 @@ class SweepDriver:
         host = self._fetch(L.totals.start, L.totals.stop)
         totals = host[L.totals]
         self._trial_sums = None
+        self._alt = None
         self.n_evaluations += 1
+        self.n_products += 1
         return self._objective_from(totals), totals
 
-    def _launch_trial(self, step):
+    def _launch_trial(self, step, alt_step=None, keep_sums=False):
         """Queue one natural-gradient trial at `step` plus the responsibility sums of the
         candidate (the M-step statistic), so an accepted candidate needs no second round trip.
-        This overwrites the device copy of the sums: whatever was there (the current state's,
-        from the accepted trial before) is gone until this candidate is accepted."""
+        With `alt_step` -- the step the line search would try next if `step` is rejected -- both
+        candidates are evaluated in the same pass over vi_mu and the LD store (the LD kernel is
+        HBM-bound: the second right-hand side rides in the same loads), so a rejection no
+        longer costs a second LD product.  This overwrites the device copy of the sums."""
         from . import _lib
-        self._cur_sums = None
-        self.engine.trial(step)
+        if not keep_sums:
+            self._cur_sums = None
+        if alt_step is not None and self._two_step:
+            self.engine.trial2(step, alt_step)
+        else:
+            self.engine.trial(step)
         self.engine.delta_sums(_lib.STATE_TRIAL_BETA)
 
-    def _trial(self, step):
-        """Objective of the candidate at `step`: the result of the trial already queued behind
-        the previous sweep's last evaluation if there is one for this step, else queue it now."""
+    def _trial(self, step, alt_step=None):
+        """Objective of the candidate at `step`: the second candidate of the pair evaluated last
+        if that is this step; else the result of the trial already queued behind the previous
+        sweep's last evaluation if there is one for this step; else queue it now."""
         L = self.engine.layout
+        alt, self._alt = self._alt, None
+        if alt is not None and alt['step'] == step:
+            self._candidate = 2
+            self._trial_sums = None         # sums ride with candidate A only
+            self._pending_flag = None
+            self.n_evaluations += 1
+            self.n_trials += 1
+            return alt['obj'], alt['totals']
         pend, self._pending = self._pending, None
         self._pending_flag = None
         if pend is not None and pend['step'] == step:
             host = pend['host']
             self._pending_flag = pend.get('flag')
+            alt_step = pend.get('alt_step')
         else:
             self._drop_ahead()
-            self._launch_trial(step)
+            if not self._two_step:
+                alt_step = None
+            self._launch_trial(step, alt_step)
             host = self._fetch(L.ttotals.start, L.sums.stop)
         totals = host[L.ttotals]
         self._trial_sums = host[L.sums]
+        self._candidate = 1
+        if alt_step is not None:
+            tb = host[L.ttotals_b]
+            self._alt = {'step': alt_step, 'obj': self._objective_from(tb), 'totals': tb}
         self.n_evaluations += 1
         self.n_trials += 1
+        self.n_products += 1
         return self._objective_from(totals), totals
 
     def _accept(self, take_mu, obj, totals, already_flipped=False):
+        self._alt = None                    # whatever second candidate there was is gone now
         if not already_flipped:
             self.engine.accept(take_mu)
         self._objective, self._totals = obj, totals
@@ -360,8 +393,10 @@ class SweepDriver:
         if self._hyper is None:
             raise RuntimeError('nat_grad_vi_delta must always be set prior to running '
                                '_update_beta')
+        self._lsr = lsr
         while True:
-            new_obj, totals = self._trial(1. / L[idx])
+            # the step the search would try next rides along (see _launch_trial)
+            new_obj, totals = self._trial(1. / L[idx], 1. / (L[idx] * lsr))
             if self._log_info:
                 logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
             # scalar arithmetic on Python floats: np.isclose & co cost ~20 us per call, which is
@@ -383,7 +418,8 @@ class SweepDriver:
             if accepted:
                 if L[idx] > L_MAX and not np.isclose(orig_obj, new_obj):
                     raise RuntimeError('Encountered a numerical error.')
-                self._accept(True, new_obj, totals, already_flipped=self._mine is not None)
+                self._accept(self._candidate, new_obj, totals,
+                             already_flipped=self._mine is not None)
                 return orig_obj, new_obj
             if L[idx] > L_MAX:
                 if not np.isclose(orig_obj, new_obj):
@@ -392,7 +428,7 @@ class SweepDriver:
             self._L_rejected = L[idx]           # the step 1/L was too long here (see _may_look_ahead)
             L[idx] *= lsr
 
-    def _update_hyper_delta(self, orig_obj, with_diff=False, next_step=None):
+    def _update_hyper_delta(self, orig_obj, with_diff=False, next_step=None, next_alt=None):
         """Closed-form M-step for the mixture weights (variational_inference.py:825-860), all on
         the device: responsibility sums (already all-reduced if they came with the accepted beta
         trial) -> new hyper_delta and its table -> re-evaluation, then ONE download.
@@ -414,7 +450,7 @@ class SweepDriver:
                     self.comm.allreduce_inplace(sums)
             # otherwise the sums of the accepted trial are still in the result vector
             # (all-reduced)
-            self._queue_mstep_stage(with_diff, next_step)
+            self._queue_mstep_stage(with_diff, next_step, next_alt=next_alt)
             if look:
                 out = 0
                 info = self._look
@@ -434,18 +470,20 @@ class SweepDriver:
             eng.spec_save()
             eng.set_predicate(out)
             eng.accept(True)
-            self._queue_mstep_stage(True, step_after, launch_only=True)
+            self._queue_mstep_stage(True, step_after, launch_only=True,
+                                    next_alt=self._look['alt_after'])
             self._queue_decision(lo, self._veto_next, 1 - out, from_state=True,
                                  ends=self._look['ends_after'])
             eng.set_predicate(None)
             self._ahead = {'pred': out, 'out': 1 - out, 'step': step_after}
+        alt = next_alt if self._two_step else None
         if look or mine is not None:
             host, flags = eng.fetch_end(out)
             flag = flags[out]
-            self._pending = {'step': next_step, 'host': host, 'flag': flag}
+            self._pending = {'step': next_step, 'alt_step': alt, 'host': host, 'flag': flag}
         elif next_step is not None:
             host = self._fetch(lo, L.sums.stop, with_max=with_diff)
-            self._pending = {'step': next_step, 'host': host}
+            self._pending = {'step': next_step, 'alt_step': alt, 'host': host}
         else:
             host = self._fetch(lo, L.totals.stop, with_max=with_diff)
         totals = host[L.totals]
@@ -453,6 +491,7 @@ class SweepDriver:
         self._last_diff = np.concatenate([host[L.dsum], host[L.dmax]]) if with_diff else None
         new_obj = self._objective_from(totals)
         self.n_evaluations += 1
+        self.n_products += 1
         self._objective, self._totals = new_obj, totals
         self._cur_sums = self._trial_sums = None
         self._version += 1
@@ -460,7 +499,7 @@ class SweepDriver:
             logging.info('...Old objective = %f, new objective = %f', orig_obj, new_obj)
         return orig_obj, new_obj
 
-    def _queue_mstep_stage(self, with_diff, next_step, launch_only=False):
+    def _queue_mstep_stage(self, with_diff, next_step, launch_only=False, next_alt=None):
         """The device work of one M-step: new hyper_delta from the sums in the result vector,
         re-evaluation, convergence statistics and the next sweep's first beta trial."""
         eng = self.engine
@@ -468,12 +507,7 @@ class SweepDriver:
         eng.eval(diff=with_diff)        # the convergence statistics ride in the same pass
         eng.accept(False)
         if next_step is not None:
-            if launch_only:
-                from . import _lib
-                eng.trial(next_step)
-                eng.delta_sums(_lib.STATE_TRIAL_BETA)
-            else:
-                self._launch_trial(next_step)
+            self._launch_trial(next_step, next_alt, keep_sums=launch_only)
 
     def _queue_decision(self, lo, veto, out_slot, from_state, ends, running=None, delta_beta=0.0,
                         before=0.0):
@@ -568,12 +602,13 @@ class SweepDriver:
         next_L = max([1., L[0] / 1.25])          # L of the next sweep's first trial
         spec = 1. / next_L if (self._speculate and last) else None
         after_L = max([1., next_L / 1.25])       # ... and of the sweep after, if that one is accepted
+        lsr = line_search_rate
         self._look = {'delta_beta': delta_sum, 'running': running_elbo_delta,
                       'ends_next': bool(next_L == 1), 'ends_after': bool(after_L == 1),
-                      'step_after': 1. / after_L}
-        orig_obj, new_obj = self._update_hyper_delta(self._objective,
-                                                     with_diff=self._want_diff and last,
-                                                     next_step=spec)
+                      'step_after': 1. / after_L, 'alt_after': 1. / (after_L * lsr)}
+        orig_obj, new_obj = self._update_hyper_delta(
+            self._objective, with_diff=self._want_diff and last, next_step=spec,
+            next_alt=None if spec is None else 1. / (next_L * lsr))
         delta_sum += new_obj - orig_obj
         # ---- paramset 2: annotations -- nothing to do in this scheme (:862-866)
         L[2] = max([1., L[2] / 1.25])
