@@ -160,9 +160,13 @@ class SweepDriver:
         self._alt = None            # second candidate of the last two-step trial, not looked at yet
         self._candidate = 1
         self._lsr = 2.
-        # two-step beta trials need vilma_trial_beta2 (VILMA_TWO_STEP=0: one step per pass)
-        self._two_step = (hasattr(self.engine, 'trial2')
-                          and os.environ.get('VILMA_TWO_STEP', '1') != '0')
+        # Two-step beta trials (vilma_trial_beta2): measured +6...8 % sweeps/s at C3 and +2.5 % at
+        # C2 (P = 2 / 1: the second candidate's per-SNP work is cheap next to the LD product it
+        # saves on every rejected step), -2 % at C5 (P = 4: there the per-SNP pass is the larger
+        # half of a trial) -- profiles/r02h_ab_twostep.txt.  VILMA_TWO_STEP=0/1 overrides.
+        two = os.environ.get('VILMA_TWO_STEP')
+        self._two_step = hasattr(self.engine, 'trial2') and (
+            two == '1' if two in ('0', '1') else num_pops <= 2)
         self.n_trials = 0           # beta line-search trials among them
         self.n_stages_ahead = 0     # sweeps whose M-step stage ran ahead of the host's decision
         self.n_stages_skipped = 0   # stages queued ahead whose decision went the other way: their
