@@ -193,33 +193,64 @@ void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *do
 // 8 KiB streamed).  Both kinds of partial go to a scratch S[slab][j]; ld_sym_combine_kernel adds
 // them in slab order (fixed order => deterministic) and forms the y.z partials.
 // --------------------------------------------------------------------------------------------
+// Cross-lane moves without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 (two per
+// double, each a round trip through the LDS); gfx950 can do what the butterfly below needs in the
+// vector ALU: v_permlane32_swap / v_permlane16_swap exchange halves of two registers, DPP moves
+// permute within a row of 16 lanes.  (Semantics checked on the device: profiles/README.md.)
+static __device__ __forceinline__ void swap_halves32(double &a, double &b) {
+    // a' = {a[0:31], b[0:31]}, b' = {a[32:63], b[32:63]}
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a);
+    const unsigned blo = __double2loint(b), bhi = __double2hiint(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
+}
+static __device__ __forceinline__ void swap_rows16(double &a, double &b) {
+    // per 32 lanes: a' = {a[0:15], b[0:15]}, b' = {a[16:31], b[16:31]}
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a);
+    const unsigned blo = __double2loint(b), bhi = __double2hiint(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
+}
+#define DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i within 8 lanes
+#define DPP_ROR8 0x128         // row_ror:8 = lane ^ 8 within 16 lanes
+template <int CTRL>
+static __device__ __forceinline__ double dpp_move(double v) {
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2loint(v), CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // halving butterfly over 8 row partials: after the three exchange steps lane l holds row
 // (bit5*4 + bit4*2 + bit3) summed over the 8 lanes that differ from it in bits 5,4,3; three
 // plain steps finish bits 2..0.  Returns the total of that row in every lane of its group.
 static __device__ __forceinline__ double sym_rowsum8(const double (&p)[CS_ROWS], int lane, int &row) {
-    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-    double q[4], r2[2], t1;
+    double q[4], r2[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const double send = h5 ? p[u] : p[u + 4];
-        const double keep = h5 ? p[u + 4] : p[u];
-        q[u] = keep + __shfl_xor(send, 32);
+    for (int u = 0; u < 4; ++u) {           // bit 5: lanes < 32 end up with rows u, the others u + 4
+        double a = p[u], b = p[u + 4];
+        swap_halves32(a, b);
+        q[u] = a + b;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const double send = h4 ? q[u] : q[u + 2];
-        const double keep = h4 ? q[u + 2] : q[u];
-        r2[u] = keep + __shfl_xor(send, 16);
+    for (int u = 0; u < 2; ++u) {           // bit 4: odd rows of 16 lanes take rows u + 2
+        double a = q[u], b = q[u + 2];
+        swap_rows16(a, b);
+        r2[u] = a + b;
     }
-    {
-        const double send = h3 ? r2[0] : r2[1];
-        const double keep = h3 ? r2[1] : r2[0];
-        t1 = keep + __shfl_xor(send, 8);
-    }
-    t1 += __shfl_xor(t1, 4);
-    t1 += __shfl_xor(t1, 2);
-    t1 += __shfl_xor(t1, 1);
-    row = (h5 ? 4 : 0) | (h4 ? 2 : 0) | (h3 ? 1 : 0);
+    const bool h3 = lane & 8;               // bit 3: the upper 8 lanes of a row take row + 1
+    const double send = h3 ? r2[0] : r2[1];
+    const double keep = h3 ? r2[1] : r2[0];
+    double t1 = keep + dpp_move<DPP_ROR8>(send);
+    t1 += dpp_move<DPP_XOR1>(t1);           // bits 0, 1, then 2 (the quad is uniform by then, so
+    t1 += dpp_move<DPP_XOR2>(t1);           // the mirror within 8 lanes pairs the two quads)
+    t1 += dpp_move<DPP_HALF_MIRROR>(t1);
+    row = ((lane & 32) ? 4 : 0) | ((lane & 16) ? 2 : 0) | (h3 ? 1 : 0);
     return t1;
 }
 
