@@ -414,8 +414,8 @@ void prof_resolve(vilma_ctx *c) {
 
 // the LD product on pool `pl` (x_ld section -> y_ld section), all cohorts or one
 // the LD product on pool `pl` (x_ld section -> y_ld section), all cohorts or one; with pl2 the
-// same product for a second right-hand side in the same pass over the LD store (dense blocks:
-// every element loaded once for both; eigen-form blocks: the passes are launched per side)
+// same product for a second right-hand side in the same pass over the LD store (every element is
+// loaded once for both)
 void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
     const ItemSet &it = cohort < 0 ? c->all : c->solo[cohort];
     hipEvent_t e0;
@@ -429,15 +429,11 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
     // both passes over the group's U back to back; one bracket around all = one product
     if (!it.groups.empty()) {
         prof_begin(c, s, e0);
-        for (int side = 0; side < (pl2 ? 2 : 1); ++side) {
-            double *pool = side ? pl2 : pl;
-            double *scratch = c->sym_scratch + side * c->s_stride;
-            double *dots = c->dot_partials + (int64_t)side * c->dot_stride;
-            for (const EigenGroup &g : it.groups) {
-                launch_ld_colsum(it.a + g.a0, g.na, pool, dots, /*keep=*/it.groups.size() > 1, s);
-                launch_ld_rowsum(it.row + g.r0, g.nr, pool, scratch, s);
-                launch_ld_rowsum_combine(it.rcomb + g.c0, g.nc, pool, scratch, dots, s);
-            }
+        for (const EigenGroup &g : it.groups) {
+            launch_ld_colsum(it.a + g.a0, g.na, pl, pl2, /*keep=*/it.groups.size() > 1, s);
+            launch_ld_rowsum(it.row + g.r0, g.nr, pl, pl2, c->sym_scratch, c->s_stride, s);
+            launch_ld_rowsum_combine(it.rcomb + g.c0, g.nc, pl, pl2, c->sym_scratch, c->s_stride,
+                                     c->dot_partials, c->dot_stride, s);
         }
         prof_end(c, s, e0, VILMA_PROF_LD_COLSUM);
     }

@@ -118,13 +118,15 @@ void launch_snp_pass(const SnpKernelArgs &a, bool blend, int ns, hipStream_t s);
 int snp_pass_grid(int64_t N);
 
 // keep = true: default cache policy (the stream is read again by launch_ld_rowsum right after);
-// false: non-temporal
-void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *dot_partials,
-                      bool keep, hipStream_t s);
-void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool, double *scratch,
+// false: non-temporal.  pool1 != nullptr: two right-hand sides per pass over U.
+void launch_ld_colsum(const LdItem *items, int n_items, double *pool0, double *pool1, bool keep,
                       hipStream_t s);
-void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool,
-                              const double *scratch, double *dot_partials, hipStream_t s);
+void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool0, const double *pool1,
+                      double *scratch, int64_t s_stride, hipStream_t s);
+void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool0, double *pool1,
+                              const double *scratch, int64_t s_stride, double *dot_partials,
+                              int dot_stride, hipStream_t s);
+
 // pool1 != nullptr: two right-hand sides in one pass over the LD store; the second one's scratch
 // sits s_stride doubles, its y.z partials dot_stride slots behind the first one's
 void launch_ld_sym(const SymItem *items, int n_items, const double *pool0, const double *pool1,

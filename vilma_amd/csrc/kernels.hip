@@ -104,12 +104,15 @@ void set_launch_predicate(const int *flag) { g_pred = flag; }
 typedef const double __attribute__((address_space(4))) *const_tab;
 static __device__ __forceinline__ const_tab as_table(const double *p) { return (const_tab)p; }
 
-template <bool KEEP>
+struct PoolPair { const double *p[2]; };
+struct PoolPairRW { double *p[2]; };
+
+// NR right-hand sides per pass over U (1, or 2 for the two candidates of a beta trial): x of side r
+// is read from pool r and its t' written there; every element of U is loaded once for both.
+template <bool KEEP, int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
-    const LdItem *__restrict__ items, const double *__restrict__ xpool, double *__restrict__ ypool,
-    const double *__restrict__ dpool, double *__restrict__ dot_partials, const int *pred) {
-    __shared__ double red[CS_WAVES][128];
-    __shared__ double dred[2];
+    const LdItem *__restrict__ items, const PoolPairRW pools, const int *pred) {
+    __shared__ double red[NR][CS_WAVES][128];
     PRED_EXIT(pred);
     const LdItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
@@ -117,8 +120,10 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
     const int c = it.col0 + 2 * lane;
     const int rows = it.rows;
     const int64_t ld = it.ld;
-    const double *__restrict__ xp = xpool + it.x_off;
-    double acc0 = 0.0, acc1 = 0.0;
+    const double *xp[NR];
+    double acc0[NR], acc1[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { xp[r] = pools.p[r] + it.x_off; acc0[r] = 0.0; acc1[r] = 0.0; }
     if (c < it.ncols) {
         const double *ap = it.a + c;
         for (int j = w * CS_ROWS; j < rows; j += CS_WAVES * CS_ROWS) {
@@ -129,58 +134,64 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
                     v[u] = KEEP ? *(gd2_ptr)(ap + (int64_t)(j + u) * ld)
                                 : LD_STREAM_LOAD(ap + (int64_t)(j + u) * ld);
 #pragma unroll
-                for (int u = 0; u < CS_ROWS; ++u) {
-                    const double xv = xp[j + u];
-                    acc0 = fma(v[u].x, xv, acc0);
-                    acc1 = fma(v[u].y, xv, acc1);
+                for (int r = 0; r < NR; ++r) {
+#pragma unroll
+                    for (int u = 0; u < CS_ROWS; ++u) {
+                        const double xv = xp[r][j + u];
+                        acc0[r] = fma(v[u].x, xv, acc0[r]);
+                        acc1[r] = fma(v[u].y, xv, acc1[r]);
+                    }
                 }
             } else {
                 for (int jj = j; jj < rows; ++jj) {
                     const v2d v = KEEP ? *(gd2_ptr)(ap + (int64_t)jj * ld)
                                        : LD_STREAM_LOAD(ap + (int64_t)jj * ld);
-                    const double xv = xp[jj];
-                    acc0 = fma(v.x, xv, acc0);
-                    acc1 = fma(v.y, xv, acc1);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const double xv = xp[r][jj];
+                        acc0[r] = fma(v.x, xv, acc0[r]);
+                        acc1[r] = fma(v.y, xv, acc1[r]);
+                    }
                 }
             }
         }
     }
-    red[w][2 * lane] = acc0;
-    red[w][2 * lane + 1] = acc1;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        red[r][w][2 * lane] = acc0[r];
+        red[r][w][2 * lane + 1] = acc1[r];
+    }
     __syncthreads();
     if (threadIdx.x < 128) {
         const int col = it.col0 + threadIdx.x;
-        double s = red[0][threadIdx.x];
-#pragma unroll
-        for (int ww = 1; ww < CS_WAVES; ++ww) s += red[ww][threadIdx.x];
-        double dv = 0.0;
         if (col < it.ncols) {
-            if (it.scale != nullptr) s *= it.scale[col];
-            ypool[it.y_off + col] = s;
-            if (it.dot_off >= 0) dv = s * dpool[it.dot_off + col];
+            const double scale = it.scale != nullptr ? it.scale[col] : 1.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double s = red[r][0][threadIdx.x];
+#pragma unroll
+                for (int ww = 1; ww < CS_WAVES; ++ww) s += red[r][ww][threadIdx.x];
+                pools.p[r][it.y_off + col] = it.scale != nullptr ? s * scale : s;
+            }
         }
-        if (it.dot_off >= 0) {
-            dv = wave_sum(dv);
-            if (lane == 0) dred[threadIdx.x >> 6] = dv;
-        }
-    }
-    if (it.dot_off >= 0) {
-        __syncthreads();
-        if (threadIdx.x == 0) dot_partials[it.dot_slot] = dred[0] + dred[1];
     }
 }
 
-void launch_ld_colsum(const LdItem *items, int n_items, double *pool, double *dot_partials,
-                      bool keep, hipStream_t s) {
+// pool1 == nullptr: one right-hand side
+void launch_ld_colsum(const LdItem *items, int n_items, double *pool0, double *pool1, bool keep,
+                      hipStream_t s) {
     if (n_items <= 0) return;
-    // x, y and the dot vector live in one pool; within a launch the regions read and written
-    // are disjoint, so handing the same base to the three restrict parameters is sound
-    if (keep)
-        hipLaunchKernelGGL(ld_colsum_kernel<true>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items,
-                           (const double *)pool, pool, (const double *)pool, dot_partials, g_pred);
-    else
-        hipLaunchKernelGGL(ld_colsum_kernel<false>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items,
-                           (const double *)pool, pool, (const double *)pool, dot_partials, g_pred);
+    PoolPairRW pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    const dim3 grid(n_items), block(CS_WAVES * 64);
+    if (pool1) {
+        if (keep) hipLaunchKernelGGL((ld_colsum_kernel<true, 2>), grid, block, 0, s, items, pp, g_pred);
+        else hipLaunchKernelGGL((ld_colsum_kernel<false, 2>), grid, block, 0, s, items, pp, g_pred);
+    } else {
+        if (keep) hipLaunchKernelGGL((ld_colsum_kernel<true, 1>), grid, block, 0, s, items, pp, g_pred);
+        else hipLaunchKernelGGL((ld_colsum_kernel<false, 1>), grid, block, 0, s, items, pp, g_pred);
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -322,7 +333,6 @@ static __device__ __forceinline__ void sym_group_diag(const v2d (&v)[CS_ROWS],
 // vector ALUs a few percent busy, so the second product is free.  Right-hand side r reads its x
 // from pool r and writes its partials at scratch + r * s_stride; each goes through exactly the
 // arithmetic of the NR = 1 kernel.
-struct PoolPair { const double *p[2]; };
 template <int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     const SymItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
@@ -412,7 +422,6 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
 // (J < slab(j), slab order) then the column-sum chunks of j's own slab (chunk order) -- a fixed
 // order -- with the chunk's y.z partial.  The slab index is wave-uniform; eight loads in flight.
 // blockIdx.y = right-hand side (its own pool, scratch and partials behind the first one's).
-struct PoolPairRW { double *p[2]; };
 __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
     const SymCombItem *__restrict__ items, const PoolPairRW pools,
     const double *__restrict__ scratch0, int64_t s_stride, double *__restrict__ dot_partials0,
@@ -487,9 +496,10 @@ void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0,
 // of the symmetric kernel; partial row sums per column slab go to scratch, the combine kernel
 // adds the slabs in order and forms the y.z partial.  Loads are non-temporal (last use).
 // --------------------------------------------------------------------------------------------
+template <int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_rowsum_kernel(
-    const RowItem *__restrict__ items, const double *__restrict__ pool,
-    double *__restrict__ scratch, const int *pred) {
+    const RowItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred) {
     PRED_EXIT(pred);
     const RowItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
@@ -498,34 +508,48 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_rowsum_kernel(
     const bool active = cl < it.w;
     const int rows = it.rows;
     const int64_t ld = it.ld;
-    const double *__restrict__ tp = pool + it.t_off;
-    const double ts0 = active ? tp[cl] : 0.0;
-    const double ts1 = (cl + 1 < it.w) ? tp[cl + 1] : 0.0;
+    double ts0[NR], ts1[NR];
+    double *srow[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double *tp = pools.p[r] + it.t_off;
+        ts0[r] = active ? tp[cl] : 0.0;
+        ts1[r] = (cl + 1 < it.w) ? tp[cl + 1] : 0.0;
+        srow[r] = scratch + r * s_stride + it.s_off;
+    }
     const double *ap = it.a + (active ? cl : 0);          // idle lanes re-read column 0, times 0
-    double *__restrict__ srow = scratch + it.s_off;
     const int ngroups = (rows + CS_ROWS - 1) / CS_ROWS;
     for (int g = w; g < ngroups; g += CS_WAVES) {
         const int r0 = g * CS_ROWS;
         v2d v[CS_ROWS];
-        double p[CS_ROWS];
 #pragma unroll
         for (int u = 0; u < CS_ROWS; ++u)
             v[u] = LD_STREAM_LOAD(ap + (int64_t)min(r0 + u, rows - 1) * ld);
 #pragma unroll
-        for (int u = 0; u < CS_ROWS; ++u) p[u] = fma(v[u].x, ts0, v[u].y * ts1);
-        int rsub;
-        const double t1 = sym_rowsum8(p, lane, rsub);
-        const int rr = r0 + rsub;
-        if ((lane & 7) == 0 && rr < rows) srow[rr] = t1;
+        for (int r = 0; r < NR; ++r) {
+            double p[CS_ROWS];
+#pragma unroll
+            for (int u = 0; u < CS_ROWS; ++u) p[u] = fma(v[u].x, ts0[r], v[u].y * ts1[r]);
+            int rsub;
+            const double t1 = sym_rowsum8(p, lane, rsub);
+            const int rr = r0 + rsub;
+            if ((lane & 7) == 0 && rr < rows) srow[r][rr] = t1;
+        }
     }
 }
 
+// blockIdx.y = right-hand side
 __global__ __launch_bounds__(256) void ld_rowsum_combine_kernel(
-    const RowCombItem *__restrict__ items, const double *__restrict__ xpool,
-    double *__restrict__ ypool, const double *__restrict__ scratch,
-    double *__restrict__ dot_partials, const int *pred) {
+    const RowCombItem *__restrict__ items, const PoolPairRW pools,
+    const double *__restrict__ scratch0, int64_t s_stride, double *__restrict__ dot_partials0,
+    int dot_stride, const int *pred) {
     __shared__ double dred[4];
     PRED_EXIT(pred);
+    const int rhs = blockIdx.y;
+    const double *__restrict__ xpool = pools.p[rhs];
+    double *__restrict__ ypool = pools.p[rhs];
+    const double *__restrict__ scratch = scratch0 + rhs * s_stride;
+    double *__restrict__ dot_partials = dot_partials0 + (int64_t)rhs * dot_stride;
     const RowCombItem it = items[blockIdx.x];
     const int i = it.i0 + threadIdx.x;
     const bool live = i < it.n;
@@ -547,18 +571,29 @@ __global__ __launch_bounds__(256) void ld_rowsum_combine_kernel(
     if (threadIdx.x == 0) dot_partials[it.dot_slot] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
-void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool, double *scratch,
-                      hipStream_t s) {
+void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool0, const double *pool1,
+                      double *scratch, int64_t s_stride, hipStream_t s) {
     if (n_items <= 0) return;
-    hipLaunchKernelGGL(ld_rowsum_kernel, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pool,
-                       scratch, g_pred);
+    PoolPair pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    if (pool1)
+        hipLaunchKernelGGL(ld_rowsum_kernel<2>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pp,
+                           scratch, s_stride, g_pred);
+    else
+        hipLaunchKernelGGL(ld_rowsum_kernel<1>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pp,
+                           scratch, s_stride, g_pred);
 }
 
-void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool,
-                              const double *scratch, double *dot_partials, hipStream_t s) {
+void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool0, double *pool1,
+                              const double *scratch, int64_t s_stride, double *dot_partials,
+                              int dot_stride, hipStream_t s) {
     if (n_items <= 0) return;
-    hipLaunchKernelGGL(ld_rowsum_combine_kernel, dim3(n_items), dim3(256), 0, s, items,
-                       (const double *)pool, pool, scratch, dot_partials, g_pred);
+    PoolPairRW pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    hipLaunchKernelGGL(ld_rowsum_combine_kernel, dim3(n_items, pool1 ? 2 : 1), dim3(256), 0, s,
+                       items, pp, scratch, s_stride, dot_partials, dot_stride, g_pred);
 }
 
 // --------------------------------------------------------------------------------------------
