@@ -333,6 +333,9 @@ static __device__ __forceinline__ void sym_group_diag(const v2d (&v)[CS_ROWS],
 // vector ALUs a few percent busy, so the second product is free.  Right-hand side r reads its x
 // from pool r and writes its partials at scratch + r * s_stride; each goes through exactly the
 // arithmetic of the NR = 1 kernel.
+#ifndef SYM_PIPELINE
+#define SYM_PIPELINE 1
+#endif
 template <int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     const SymItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
@@ -380,15 +383,48 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
             sym_group_diag(v, xrow[r], g * CS_ROWS, rows, active ? cl : 2 * 64, xs0[r], xs1[r],
                            acc0[r], acc1[r], lane, rs_diag[r]);
     }
-    // (2) the rows below it: plain loop, 8 x 1 KiB loads in flight per wave, latency hidden by
-    // occupancy (a manually software-pipelined version measured the same, 1.20 ms @C3)
-    for (; g < nfull; g += CS_WAVES, rp += gstride) {
+    // (2) the rows below it.  One right-hand side: plain loop, 8 x 1 KiB loads in flight per wave,
+    // latency hidden by occupancy (software pipelining measured the same, 1.20 ms @C3).  Two:
+    // the arithmetic per group doubles and fewer waves fit (104 VGPRs), so the next group's
+    // loads are issued before the current group is folded in (double-buffered, unrolled by two).
+    if (SYM_PIPELINE && NR == 2) {
+        v2d vb[CS_ROWS];
+        if (g < nfull) {
 #pragma unroll
-        for (int u = 0; u < CS_ROWS; ++u) v[u] = LD_STREAM_LOAD(rp + (int64_t)u * ld);
+            for (int u = 0; u < CS_ROWS; ++u) v[u] = LD_STREAM_LOAD(rp + (int64_t)u * ld);
+        }
+        while (g < nfull) {
+            const int g2 = g + CS_WAVES;
+            if (g2 < nfull) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
-            sym_group<true>(v, xrow[r], g * CS_ROWS, rows, xs0[r], xs1[r], acc0[r], acc1[r], lane,
-                            srow[r]);
+                for (int u = 0; u < CS_ROWS; ++u) vb[u] = LD_STREAM_LOAD(rp + gstride + (int64_t)u * ld);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                sym_group<true>(v, xrow[r], g * CS_ROWS, rows, xs0[r], xs1[r], acc0[r], acc1[r],
+                                lane, srow[r]);
+            if (g2 >= nfull) { g = g2; rp += gstride; break; }
+            const int g3 = g2 + CS_WAVES;
+            if (g3 < nfull) {
+#pragma unroll
+                for (int u = 0; u < CS_ROWS; ++u) v[u] = LD_STREAM_LOAD(rp + 2 * gstride + (int64_t)u * ld);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                sym_group<true>(vb, xrow[r], g2 * CS_ROWS, rows, xs0[r], xs1[r], acc0[r], acc1[r],
+                                lane, srow[r]);
+            g = g3;
+            rp += 2 * gstride;
+        }
+    } else {
+        for (; g < nfull; g += CS_WAVES, rp += gstride) {
+#pragma unroll
+            for (int u = 0; u < CS_ROWS; ++u) v[u] = LD_STREAM_LOAD(rp + (int64_t)u * ld);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                sym_group<true>(v, xrow[r], g * CS_ROWS, rows, xs0[r], xs1[r], acc0[r], acc1[r],
+                                lane, srow[r]);
+        }
     }
     if (g == nfull && g < ngroups) {                        // the one partial group, below the tile
         const int r0 = nfull * CS_ROWS;
