@@ -207,7 +207,7 @@ void launch_ld_colsum(const LdItem *items, int n_items, double *pool0, double *p
 // Cross-lane moves without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 (two per
 // double, each a round trip through the LDS); gfx950 can do what the butterfly below needs in the
 // vector ALU: v_permlane32_swap / v_permlane16_swap exchange halves of two registers, DPP moves
-// permute within a row of 16 lanes.  (Semantics checked on the device: profiles/permtest.hip.)
+// permute within a row of 16 lanes.  (Semantics checked on the device: profiles/README.md.)
 static __device__ __forceinline__ void swap_halves32(double &a, double &b) {
     // a' = {a[0:31], b[0:31]}, b' = {a[32:63], b[32:63]}
     const unsigned alo = __double2loint(a), ahi = __double2hiint(a);
