@@ -285,7 +285,8 @@ int vilma_read_decision(vilma_ctx *ctx, int slot, int *flag, double *obj2);
  * milliseconds and number of bracketed launches since the last reset (arrays of VILMA_PROF_KINDS). */
 #define VILMA_PROF_LD_SYM 0      /* ld_sym_kernel: symmetric dense blocks, lower triangle read once */
 #define VILMA_PROF_LD_COLSUM 1   /* ld_colsum_kernel: both passes of eigen-form blocks */
-#define VILMA_PROF_LD_COMBINE 2  /* reserved (ld_sym_combine_kernel is not bracketed) */
+#define VILMA_PROF_LD_SYM2 2     /* ld_sym_kernel with two right-hand sides (vilma_trial_beta2): one pass
+                                  * over the store, two products */
 #define VILMA_PROF_KINDS 3
 int vilma_prof_enable(vilma_ctx *ctx, int enable);
 int vilma_prof_read(vilma_ctx *ctx, double *ms_total, int64_t *launches, int reset);

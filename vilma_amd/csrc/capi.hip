@@ -423,7 +423,7 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
     if (it.n_sym > 0) {
         prof_begin(c, s, e0);
         launch_ld_sym(it.sym, it.n_sym, pl, pl2, c->sym_scratch, c->s_stride, s);
-        prof_end(c, s, e0, VILMA_PROF_LD_SYM);
+        prof_end(c, s, e0, pl2 ? VILMA_PROF_LD_SYM2 : VILMA_PROF_LD_SYM);
     }
     // eigen-form blocks, group by group (one group unless VILMA_EIGEN_GROUP_MB says otherwise):
     // both passes over the group's U back to back; one bracket around all = one product
