@@ -64,3 +64,22 @@ def test_bench_two_ranks_launch_line():
                          text=True, check=True)
     e1, e2 = _last_json(one.stdout)['config']['elbo_end'], d['config']['elbo_end']
     assert abs(e1 - e2) < 1e-9 * abs(e1)
+
+
+def test_bench_gpus_without_a_launcher_starts_one():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must not measure one GPU
+    and call it two: it starts the driver's torch.distributed.run line as a child process (before
+    touching the GPU itself) and relays its single JSON line."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(VILMA_BENCH_BACKEND='gloo', VILMA_BENCH_SAME_DEVICE='1')
+    out = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--workload', 'tiny'], cwd=ROOT, env=env, capture_output=True, text=True,
+                         check=True)
+    d = _last_json(out.stdout)
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and 'cpu_baseline' not in d
+    # and a mismatch between --gpus and the launcher's world size is an error, not a 1-GPU run
+    bad = subprocess.run([sys.executable, 'bench.py', '--gpus', '4', '--workload', 'tiny'],
+                         cwd=ROOT, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'),
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)
