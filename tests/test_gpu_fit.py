@@ -248,3 +248,52 @@ def test_rccl_stream_ordering_with_one_rank_group():
             assert abs(vi2._objective - vi3._objective) <= 1e-12 * abs(vi3._objective)
     finally:
         dist.destroy_process_group()
+
+
+def _sweep_trace(monkeypatch, two_step, lookahead, n_sweeps=35):
+    """ELBO / L after every sweep of the synthetic 'tiny' problem (2 cohorts, 6.3 k SNPs, blocks
+    up to ~1 000 SNPs) driven like bench.py drives it."""
+    import torch
+    from vilma_amd.synthetic import SyntheticShard, WORKLOADS
+    from vilma_amd.engine import HipEngine
+    from vilma_amd.sharding import Comm
+    from vilma_amd.variational_inference import SweepDriver
+    monkeypatch.setenv('VILMA_TWO_STEP', '1' if two_step else '0')
+    monkeypatch.setenv('VILMA_LOOKAHEAD', '1' if lookahead else '0')
+    device = torch.device('cuda', 0)
+    sh = SyntheticShard(seed=3, **WORKLOADS['tiny']).build(device)
+    sh.finish_init(sh.inv_se2_local)
+    eng = HipEngine(sh.P, sh.N, sh.M, 1)
+    eng.set_snp_data(sh.adj, sh.se, sh.sld, sh.scalings, sh.annot)
+    eng.set_mixture(np.linalg.inv(sh.covs), np.linalg.slogdet(sh.covs)[1])
+    for p in range(sh.P):
+        eng.load_ld(p, sh.ld_blocks_torch(p, device), sh.perm, sh.n_ld, specs=sh.block_specs())
+    drv = SweepDriver()
+    drv._setup_driver(eng, Comm(), sh.P, sh.M, 1, sh.chi_local, sh.rank_local, [sh.N_global],
+                      np.linalg.slogdet(sh.covs)[1], scale_se=False, num_its=100)
+    drv.initialize_from(sh.fake_mu)
+    state, trace = None, []
+    for k in range(n_sweeps):
+        state, stats = drv.sweep(state, lookahead=k + 1 < n_sweeps)
+        trace.append((state['elbo'], tuple(state['L']), tuple(stats)))
+    mu = eng.get_mu()
+    counts = (drv.n_evaluations, drv.n_trials, drv.n_products, drv.n_stages_ahead)
+    eng.close()
+    return trace, mu, counts
+
+
+def test_two_step_and_lookahead_change_no_bit(monkeypatch):
+    """Two line-search steps per device pass and the stage queued ahead of the device's decision
+    are pure scheduling: ELBO, L, convergence statistics after every sweep and the final vi_mu are
+    BIT-identical to the one-step, host-decides-everything schedule."""
+    base, mu0, c0 = _sweep_trace(monkeypatch, two_step=False, lookahead=False)
+    assert c0[2] == c0[0] and c0[3] == 0                 # one LD pass per point, nothing queued ahead
+    for two_step, lookahead in ((True, False), (False, True), (True, True)):
+        trace, mu, c = _sweep_trace(monkeypatch, two_step, lookahead)
+        assert trace == base, (two_step, lookahead)
+        assert np.array_equal(mu, mu0)
+        assert c[:2] == c0[:2]                           # same points looked at, same trials
+        if two_step:
+            assert c[2] < c0[2]                          # ... in fewer passes over the LD store
+        if lookahead:
+            assert c[3] > 0
