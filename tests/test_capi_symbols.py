@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/vilma_hip.h declares (no compute)."""
+"""The C-ABI library loads and exports every symbol include/*.h declares (no compute)."""
 import os
 import re
 
@@ -8,10 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_header_symbols_are_exported():
-    header = open(os.path.join(ROOT, 'include', 'vilma_hip.h')).read()
-    declared = set(re.findall(r'\b(vilma_[a-z0-9_]+)\s*\(', header))
+    declared = set()
+    for name in ('vilma_hip.h', 'vilma_numerics.h'):
+        header = open(os.path.join(ROOT, 'include', name)).read()
+        declared |= set(re.findall(r'\b(vilma_[a-z0-9_]+)\s*\(', header))
     declared.discard('vilma_ctx')
-    assert len(declared) >= 25
+    assert len(declared) >= 60
     lib = _lib.load()
     for name in sorted(declared):
         assert hasattr(lib, name), 'libvilma_hip.so does not export %s' % name

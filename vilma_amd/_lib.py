@@ -94,6 +94,29 @@ def load():
         'vilma_read_decision': (C.c_int, [vp, C.c_int, vp, vp]),
         'vilma_prof_enable': (C.c_int, [vp, C.c_int]),
         'vilma_prof_read': (C.c_int, [vp, _c_double_p, _c_i64_p, C.c_int]),
+        # include/vilma_numerics.h -- the Function API (vilma_amd/numerics.py)
+        'vilma_num_last_error': (C.c_char_p, []),
+        'vilma_num_sum_betas': (C.c_int, [vp, vp, C.c_double, C.c_int64, vp]),
+        'vilma_num_divide': (C.c_int, [vp, vp, C.c_int64, vp]),
+        'vilma_num_linked_ests': (C.c_int, [vp, vp, vp, vp, C.c_int64, vp]),
+        'vilma_num_likelihood': (C.c_int, [vp] * 9 + [C.c_int, C.c_int64, vp]),
+        'vilma_num_posterior_mean': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
+        'vilma_num_pmv': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
+        'vilma_num_nat_inner_product': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64,
+                                                  C.c_double, vp]),
+        'vilma_num_inner_product_comp': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
+        'vilma_num_sum_annotations': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
+        'vilma_num_delta_kl': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
+        'vilma_num_beta_kl': (C.c_int, [vp, vp, C.c_int64, vp]),
+        'vilma_num_vi_delta_grad': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
+        'vilma_num_map_to_nat_cat': (C.c_int, [vp, C.c_int64, C.c_int, vp]),
+        'vilma_num_invert_nat_cat': (C.c_int, [vp, C.c_int64, C.c_int, vp]),
+        'vilma_num_invert_nat_vi_delta': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int64,
+                                                    vp]),
+        'vilma_num_matrix_invert': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp]),
+        'vilma_num_matrix_log_det': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp]),
+        'vilma_num_vi_sigma_inv': (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, vp]),
+        'vilma_num_vi_sigma_log_det': (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError if the header and the library diverge

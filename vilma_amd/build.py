@@ -6,8 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libvilma_hip.so')
-SOURCES = ['kernels.hip', 'capi.hip']
-HEADERS = ['kernels.h', os.path.join('..', '..', 'include', 'vilma_hip.h')]
+SOURCES = ['kernels.hip', 'capi.hip', 'numerics_api.hip']
+HEADERS = ['kernels.h', os.path.join('..', '..', 'include', 'vilma_hip.h'),
+           os.path.join('..', '..', 'include', 'vilma_numerics.h')]
 
 
 def _hipcc():
