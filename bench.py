@@ -246,7 +246,7 @@ def main():
     for p in range(P):
         if shard.kind == 'lowrank':
             engine.load_ld(p, shard.ld_blocks_torch(p, device, args.ld_form), shard.perm,
-                           shard.n_ld, specs=shard.block_specs(args.ld_form))
+                           shard.n_ld, specs=shard.block_specs(args.ld_form, p))
         else:
             engine.load_ld(p, shard.ld_blocks_torch(p, device), shard.perm, shard.n_ld,
                            specs=shard.block_specs())
@@ -307,9 +307,10 @@ def main():
     n_prod = driver.n_products - pr0
     # algorithmic bytes of ONE product on this rank (stated in DESIGN.md section 5): a dense
     # symmetric block needs its lower triangle once, an eigen-form block its U once
-    specs = shard.block_specs(args.ld_form) if shard.kind == 'lowrank' else shard.block_specs()
-    alg_launch = 8.0 * P * sum(n * (n + 1) / 2 if form == 'dense' else n * r
-                               for form, n, r in specs)
+    alg_launch = 8.0 * sum(n * (n + 1) / 2 if form == 'dense' else n * r
+                           for p in range(P)
+                           for form, n, r in (shard.block_specs(args.ld_form, p)
+                                              if shard.kind == 'lowrank' else shard.block_specs()))
     survey_launch = float(shard.ld_bytes)                # 8 n^2 dense, 8 n r eigen
     avg_ms = kernel_ms / max(launches, 1)
     achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
@@ -347,9 +348,9 @@ def main():
                         'M=%d mixture components, fp64 LD %.2f GB algorithmic (%s), A=1, no '
                         '--learn-scaling' % (args.workload, P, shard.N_global, shard.n_ld_global,
                                              len(shard.sizes_all),
-                                             'AR(1)' if shard.kind == 'ar1' else 'eigen-form (rank %.2f n)' % shard.rank_frac,
+                                             'AR(1)' if shard.kind == 'ar1' else ('factor-model, --ldthresh 0.8 (kept rank %.3f n)' % (sum(float(r.sum()) for r in shard.ranks_by_cohort) / (P * max(1.0, float(shard.sizes.sum())))) if shard.spectrum == 'factor' else 'eigen-form (rank %.2f n)' % shard.rank_frac),
                                              shard.N_global - shard.n_ld_global, M,
-                                             8e-9 * P * float((shard.sizes_all.astype(np.float64) * (shard.sizes_all if shard.kind == 'ar1' else np.maximum(1, np.round(shard.rank_frac * shard.sizes_all)))).sum()),
+                                             (1e-9 * shard.ld_bytes if world == 1 and args.emulate_shard <= 1 else 8e-9 * P * float((shard.sizes_all.astype(np.float64) * shard.ranks_all).sum())),
                                              '8 n^2 as full matrices; the symmetric kernel needs the lower triangle, half of it' if shard.kind == 'ar1' else '8 n r, U counted once'),
             'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
             'points_evaluated_per_sweep': n_eval / args.steps,

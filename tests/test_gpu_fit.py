@@ -170,6 +170,51 @@ def test_synthetic_eigen_form_constants_match_class_api():
     assert abs(elbos['eig'] - elbos['dense']) < 1e-9 * abs(elbos['eig'])
 
 
+def test_factor_model_workload_is_what_the_loader_makes_of_the_same_matrices():
+    """C4f follows SURVEY 8d's C4 recipe: R = D^-1/2 (F F^T/m + 0.05 I) D^-1/2 cut at --ldthresh
+    0.8.  Rebuild every block's R on the host from the same random stream, hand it to the
+    product's own loader type (LowRankMatrix(X, t=0.8): host LAPACK + the reference's selection
+    rule) and compare ranks, operators and the class API's load-time constants."""
+    import torch
+    from vilma_amd.synthetic import SyntheticShard, WORKLOADS, FACTOR_LD_THRESH
+    from vilma_amd.matrix_structures import LowRankMatrix, BlockDiagonalMatrix
+    from vilma_amd.variational_inference import MultiPopVI
+    dev = torch.device('cuda', 0)
+    sh = SyntheticShard(seed=4, **WORKLOADS['tiny4f']).build(dev)
+    sh.finish_init(sh.inv_se2_local)
+    ld = []
+    for p in range(sh.P):
+        mats = []
+        for i, blk in enumerate(sh.blocks):
+            m = -(-blk.n // 4)
+            rng = np.random.default_rng([sh.seed, 5000 + sh.b0 + i, p])
+            F = rng.normal(size=(blk.n, m))
+            R = F @ F.T / m + 0.05 * np.eye(blk.n)
+            d = 1.0 / np.sqrt(np.diag(R))
+            R = d[:, None] * R * d[None, :]
+            mat = LowRankMatrix(X=R, t=FACTOR_LD_THRESH)
+            U, sv = sh._eig[p][i]
+            assert mat.s.shape[0] == U.shape[1] == sh.ranks_by_cohort[p][i] >= m == sh.ranks[i]
+            got = ((U * sv) @ U.T).cpu().numpy()
+            np.testing.assert_allclose(got, (mat.u * mat.s) @ mat.v, rtol=0, atol=1e-11)
+            mats.append(mat)
+        ld.append(BlockDiagonalMatrix(mats, perm=sh.perm, missing=sh.missing))
+    elbos = {}
+    for form in ('eig', 'dense'):
+        vi = MultiPopVI(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
+                        mixture_covs=list(sh.covs), annotations=np.ones((sh.N, 1)),
+                        checkpoint=False, gwas_N=sh.gwas_N, init_hg=sh.init_hg, num_its=3, form=form)
+        np.testing.assert_allclose(vi.adj_marginal_effects, sh.adj, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(vi.chi_stat, sh.chi_local, rtol=1e-8)
+        np.testing.assert_allclose(vi.ld_ranks, sh.rank_local)
+        np.testing.assert_allclose(vi.ld_diags, sh.ld_diags, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(vi.inverse_betas, sh.inverse_betas, rtol=1e-6, atol=1e-10)
+        np.random.seed(1)
+        vi.optimize()
+        elbos[form] = vi._objective
+    assert abs(elbos['eig'] - elbos['dense']) < 1e-9 * abs(elbos['eig'])
+
+
 def test_cli_under_torchrun_two_ranks(tmp_path):
     """`torchrun --nproc-per-node 2 -m vilma_amd fit ...` (rehearsed over gloo with both ranks on
     this GPU): rank 0 writes the same outputs as the single-process run."""

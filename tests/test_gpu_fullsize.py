@@ -27,7 +27,7 @@ def _setup(workload, seed=0, form='auto'):
     for p in range(sh.P):
         if sh.kind == 'lowrank':
             eng.load_ld(p, sh.ld_blocks_torch(p, device, form), sh.perm, sh.n_ld,
-                        specs=sh.block_specs(form))
+                        specs=sh.block_specs(form, p))
         else:
             eng.load_ld(p, sh.ld_blocks_torch(p, device), sh.perm, sh.n_ld,
                         specs=sh.block_specs())

@@ -30,7 +30,17 @@ WORKLOADS = {
     'C5': dict(P=4, n_ld=5_000_000, B=8500, M=81, fixed=None, missing_frac=0.05),
     'tiny4': dict(P=2, n_ld=6_000, B=12, M=12, fixed=None, missing_frac=0.05,
                   kind='lowrank', rank_frac=0.28),
+    # C4f: C4 by SURVEY.md 8d's recipe to the letter -- per block and cohort the factor model
+    # R = D^-1/2 (F F^T / m + 0.05 I) D^-1/2, F ~ N(0,1)^{n x m}, m = ceil(n / 4), eigendecomposed
+    # and cut by the loader's --ldthresh 0.8 rule (kept rank = m or a few more: the F F^T part
+    # sits above 1, the 0.05 floor below 1 - sqrt(0.8) except where a small block's diagonal
+    # scaling lifts it).  Setup eigendecomposes 3 400 blocks on the GPU.
+    'C4f': dict(P=2, n_ld=1_000_000, B=1700, M=40, fixed=None, missing_frac=0.05,
+                kind='lowrank', spectrum='factor', rank_frac=0.25),
+    'tiny4f': dict(P=2, n_ld=6_000, B=12, M=12, fixed=None, missing_frac=0.05,
+                   kind='lowrank', spectrum='factor', rank_frac=0.25),
 }
+FACTOR_LD_THRESH = 0.8
 
 
 def block_sizes(n_ld, B, fixed=None, seed=0):
@@ -121,9 +131,10 @@ class SyntheticShard:
     perm per cohort, and a generator of LD blocks (numpy or device tensors)."""
 
     def __init__(self, P, n_ld, B, M, fixed=None, missing_frac=0.0, seed=0, rank=0, world=1,
-                 gwas_N=1e5, init_hg=0.1, block_range=None, kind='ar1', rank_frac=0.28):
+                 gwas_N=1e5, init_hg=0.1, block_range=None, kind='ar1', rank_frac=0.28,
+                 spectrum='geom'):
         self.P, self.M, self.A, self.seed = P, M, 1, seed
-        self.kind, self.rank_frac = kind, rank_frac
+        self.kind, self.rank_frac, self.spectrum = kind, rank_frac, spectrum
         self.gwas_N = np.full(P, gwas_N, dtype=np.float64)
         self.init_hg = np.full(P, init_hg, dtype=np.float64)
         self.sizes_all = block_sizes(n_ld, B, fixed, seed)
@@ -152,8 +163,16 @@ class SyntheticShard:
                         else np.zeros(0, dtype=np.int64))
         self.perm = np.concatenate([self.ld_snps, self.missing])
         self.covs = mixture_covs(P, M)
-        self.ranks = (self.sizes if kind == 'ar1' else
-                      np.maximum(1, np.round(rank_frac * self.sizes)).astype(np.int64))
+        if kind == 'ar1':
+            self.ranks_all = self.sizes_all.astype(np.int64)
+        elif spectrum == 'factor':
+            # m = ceil(n / 4): the nominal kept rank; build() replaces the local entries by what
+            # the threshold actually keeps, per cohort (ranks_by_cohort)
+            self.ranks_all = -(-self.sizes_all.astype(np.int64) // 4)
+        else:
+            self.ranks_all = np.maximum(1, np.round(rank_frac * self.sizes_all)).astype(np.int64)
+        self.ranks = self.ranks_all[self.b0:self.b1]
+        self.ranks_by_cohort = [self.ranks.copy() for _ in range(P)]
         # algorithmic bytes of one product: 8 n^2 dense, 8 n r eigen form
         self.ld_bytes = 8 * int((self.sizes.astype(np.int64) * self.ranks).sum()) * P
         self._eig = None          # per (cohort, block): (U, s) device tensors, lowrank kind
@@ -178,11 +197,12 @@ class SyntheticShard:
             idx = torch.arange(blk.n, device=device, dtype=torch.float64)
             yield ('dense', torch.pow(float(blk.rho[p]), (idx[:, None] - idx[None, :]).abs()))
 
-    def block_specs(self, form='auto'):
+    def block_specs(self, form='auto', p=0):
+        """(form, n, r) per local block of cohort p, in the order ld_blocks_torch(p, ...) yields."""
         if self.kind == 'lowrank':
             from .matrix_structures import dense_is_cheaper
             out = []
-            for n, r in zip(self.sizes, self.ranks):
+            for n, r in zip(self.sizes, self.ranks_by_cohort[p]):
                 dense = form == 'dense' or (form == 'auto' and dense_is_cheaper(int(n), int(r)))
                 out.append(('dense', int(n), int(n)) if dense else ('eig', int(n), int(r)))
             return out
@@ -247,10 +267,16 @@ class SyntheticShard:
             self.se[:, sl] = blk.se
             for p in range(P):
                 rng = np.random.default_rng([self.seed, 5000 + self.b0 + i, p])
-                G = torch.as_tensor(rng.normal(size=(blk.n, r)), **f64)
-                U = torch.linalg.qr(G)[0].contiguous()
-                sv = torch.as_tensor(np.geomspace(1.0, 0.05, r), **f64)
-                sv = sv * (blk.n / sv.sum())
+                if self.spectrum == 'factor':
+                    _progress('factor-model eigh', i * P + p, len(self.blocks) * P, every=500)
+                    U, sv = _factor_model_eig(rng, blk.n, r, device)
+                    self.ranks_by_cohort[p][i] = U.shape[1]
+                    r = U.shape[1]
+                else:
+                    G = torch.as_tensor(rng.normal(size=(blk.n, r)), **f64)
+                    U = torch.linalg.qr(G)[0].contiguous()
+                    sv = torch.as_tensor(np.geomspace(1.0, 0.05, r), **f64)
+                    sv = sv * (blk.n / sv.sum())
                 self._eig[p].append((U, sv))
                 se = torch.as_tensor(blk.se[p], **f64)
                 zt = torch.as_tensor(blk.beta[p] / blk.se[p], **f64)
@@ -261,7 +287,9 @@ class SyntheticShard:
                 self.betahat[p, sl] = (se * zhat).cpu().numpy()
                 self.adj[p, sl] = ((U @ proj) / se).cpu().numpy()
                 self.ld_diags[p, sl] = ((U * U) @ sv).cpu().numpy()
-        self.rank_local = np.full(P, float(self.ranks.sum()))
+        self.rank_local = np.array([float(rk.sum()) for rk in self.ranks_by_cohort])
+        self.ld_bytes = 8 * int(sum((self.sizes.astype(np.int64) * rk).sum()
+                                    for rk in self.ranks_by_cohort))
         self.sld = self.ld_diags / self.se ** 2
         self.scalings = np.ones((P, N))
         self.annot = np.zeros(N, dtype=np.int32)
@@ -309,6 +337,27 @@ class SyntheticShard:
                 self.fake_mu[p, sl] = self.inverse_betas[p, sl] + 1e-3 * blk.se[p] * blk.init_noise[p]
         # LD-missing SNPs: NaN in every cohort -> cross-cohort nanmean is NaN -> 0 (:653-657)
         return self
+
+
+def _factor_model_eig(rng, n, m, device):
+    """R = D^-1/2 (F F^T / m + 0.05 I) D^-1/2 with F ~ N(0,1)^{n x m}, then what
+    the loader keeps at --ldthresh 0.8 (select_eigenpairs = the reference's _svd_threshold +
+    LowRankMatrix rules).  Returns (U [n, r], s [r]) on `device`; r >= m (the F F^T part is
+    always kept; a few floor eigenvalues of a small block can pass the threshold too)."""
+    import torch
+    from .matrix_structures import select_eigenpairs
+    F = torch.as_tensor(rng.normal(size=(n, m)), dtype=torch.float64, device=device)
+    R = F @ F.T / m
+    R.diagonal().add_(0.05)
+    d = R.diagonal().rsqrt()
+    R = d[:, None] * R * d[None, :]
+    w, V = torch.linalg.eigh(R)
+    keep, degenerate = select_eigenpairs(w.cpu().numpy(), FACTOR_LD_THRESH)
+    if degenerate is not None or keep.size < m:
+        raise RuntimeError('factor-model block of %d SNPs kept %d eigenpairs, expected >= %d'
+                           % (n, keep.size, m))
+    idx = torch.as_tensor(keep, device=device)
+    return V[:, idx].contiguous(), w[idx].contiguous()
 
 
 def ar1_apply(rho, x):
