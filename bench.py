@@ -12,7 +12,7 @@ With N>1 (launched by torch.distributed.run, one rank per GPU) the same global p
 sharded by LD blocks (strong scaling); the 3P+2 sums are all-reduced over RCCL per evaluation.
 
 Prints ONE JSON line (rank 0) with the sweep throughput, the roofline object of the dominant
-kernel (ld_sym_kernel for dense LD, ld_colsum_kernel for eigen-form LD; timed with HIP events on
+kernel (ld_sym_kernel for dense LD, ld_eig_fused_kernel for eigen-form LD; timed with HIP events on
 its launch stream inside the library) and, at N=1, the CPU baseline: the oracle (a port following
 the reference's operation schedule) timed on this host on a bounded sample of the same workload.
 
@@ -295,11 +295,11 @@ def main():
     # bytes of a launch are the store once either way
     sym1, sym2 = prof['ld_sym_kernel'], prof['ld_sym_kernel_two_rhs']
     pooled = {'ld_sym_kernel': (sym1[0] + sym2[0], sym1[1] + sym2[1]),
-              'ld_colsum_kernel': prof['ld_colsum_kernel']}
+              'ld_eig_fused_kernel': prof['ld_eig_fused_kernel']}
     dom = max(pooled, key=lambda k: pooled[k][0])
     kernel_ms, launches = pooled[dom]
-    # (an eigen-form product = first pass, second pass and combine on the same U: the library
-    # brackets the three launches together, so a bracket is a product for either kernel)
+    # (an eigen-form product = the fused launches, one per block-height class, and their combine:
+    # the library brackets them together, so a bracket is a product for either kernel)
     if world > 1:
         elapsed = float(comm.allreduce_np(np.array([elapsed]), op='max')[0])
 

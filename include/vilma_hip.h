@@ -97,7 +97,10 @@ int vilma_ld_begin(vilma_ctx *ctx, int cohort, int n_blocks, int64_t n_ld, const
                    int64_t total_elems);
 
 /* Element counts to use in total_elems (rows are padded to a multiple of 16 doubles = 128 B so
- * that every 1-KiB wave load covers whole cache lines; dense blocks keep the lower triangle). */
+ * that every 1-KiB wave load covers whole cache lines; dense blocks keep the lower triangle; an
+ * eigen-form block keeps U once -- column-major with the column length rounded up to even for the
+ * fused product, row-major for blocks of more than 3 072 SNPs -- and s:
+ * pad2(n) * pad16(r) + pad16(r)). */
 int64_t vilma_ld_dense_elems(int n);
 int64_t vilma_ld_lowrank_elems(int n, int r);
 
@@ -284,7 +287,8 @@ int vilma_read_decision(vilma_ctx *ctx, int slot, int *flag, double *obj2);
  * shards sample).  vilma_prof_read synchronises the device and returns, per kernel kind, the accumulated kernel
  * milliseconds and number of bracketed launches since the last reset (arrays of VILMA_PROF_KINDS). */
 #define VILMA_PROF_LD_SYM 0      /* ld_sym_kernel: symmetric dense blocks, lower triangle read once */
-#define VILMA_PROF_LD_COLSUM 1   /* ld_colsum_kernel: both passes of eigen-form blocks */
+#define VILMA_PROF_LD_EIG 1      /* ld_eig_fused_kernel: one product of the eigen-form blocks (the fused
+                                  * launches, the two-pass kernels of blocks over 3 072 SNPs, combine) */
 #define VILMA_PROF_LD_SYM2 2     /* ld_sym_kernel with two right-hand sides (vilma_trial_beta2): one pass
                                   * over the store, two products */
 #define VILMA_PROF_KINDS 3

@@ -14,7 +14,8 @@ import sys
 
 import pandas as pd
 
-OURS = ("ld_sym_combine_kernel", "ld_sym_kernel", "ld_colsum_kernel", 'snp_pass_kernel', 'delta_kernel', 'reduce_cols_kernel',
+OURS = ("ld_sym_combine_kernel", "ld_sym_kernel", "ld_eig_fused_kernel", "ld_rowsum_combine_kernel",
+        "ld_rowsum_kernel", "ld_colsum_kernel", 'snp_pass_kernel', 'delta_kernel', 'reduce_cols_kernel',
         'finalize_kernel', 'mean_diff', 'gather_x_kernel', 'scatter_y_kernel', 'decide_kernel', 'mstep_kernel',
         'init_state_kernel', 'snp_given_delta_kernel')
 
@@ -24,6 +25,20 @@ def short(name):
         if k in name:
             return k
     return None
+
+
+def per_class(grp, col):
+    """Launches of ld_eig_fused_kernel<R, NR> by class R: mean of `col` over each class's full
+    launches (predicated-off launches last microseconds), and the sum over classes = one product."""
+    if not len(grp):
+        return None
+    grp = grp.copy()
+    grp['R'] = grp['Kernel_Name'].str.extract(r'ld_eig_fused_kernel<(\d+),')[0]
+    out = {}
+    for r, g in grp.groupby('R'):
+        big = g[g.us > 0.5 * g.us.max()]
+        out[str(r)] = {'launches': int(len(big)), 'mean': float(big[col].mean())}
+    return {'per_class': out, 'sum_over_classes': float(sum(v['mean'] for v in out.values()))}
 
 
 def main():
@@ -48,12 +63,16 @@ def main():
         # the dominant kernel's launches split by size: the big launches are the full LD product
         # (launches of a stage queued ahead of a line-search decision that then went the other way
         # exit at once: a few microseconds each; they are not products)
-        for name in ('ld_sym_kernel', 'ld_colsum_kernel'):
-            ld = df[df.k == name]
-            if len(ld):
-                big = ld[ld.us > 0.5 * ld.us.max()]
-                out[name + '_full_product'] = {'calls': int(len(big)), 'avg_us': float(big.us.mean()),
-                                               'skipped_launches': int(len(ld) - len(big))}
+        ld = df[df.k == 'ld_sym_kernel']
+        if len(ld):
+            big = ld[ld.us > 0.5 * ld.us.max()]
+            out['ld_sym_kernel_full_product'] = {'calls': int(len(big)), 'avg_us': float(big.us.mean()),
+                                                 'skipped_launches': int(len(ld) - len(big))}
+        # an eigen-form product = one launch per block-height class (template argument R): the
+        # product's kernel time is the sum over the classes of the mean full launch
+        eig = per_class(df[df.k == 'ld_eig_fused_kernel'], 'us')
+        if eig:
+            out['ld_eig_fused_kernel_full_product'] = eig
         json.dump(out, open(prefix + '_vilma_kernels.json', 'w'), indent=1)
     for f in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
         df = pd.read_csv(f, usecols=['Kernel_Name', 'Counter_Name', 'Counter_Value',
@@ -68,6 +87,11 @@ def main():
                                         'mean_per_dispatch': float(grp.Counter_Value.mean()),
                                         'mean_over_large_dispatches': float(big.Counter_Value.mean()),
                                         'large_dispatches': int(len(big))}
+            if k == 'ld_eig_fused_kernel':
+                # per PRODUCT: the sum over the block-height classes of the mean full launch
+                pc = per_class(grp, 'Counter_Value')
+                out[k][c]['per_class'] = pc['per_class']
+                out[k][c]['mean_over_large_dispatches'] = pc['sum_over_classes']
         json.dump(out, open(prefix + '_pmc.json', 'w'), indent=1)
 
 

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
 def test_sizes_helpers():
     lib = _lib.load()
     assert lib.vilma_ld_dense_elems(5) == 5 * 16          # rows padded to 128 B
-    assert lib.vilma_ld_lowrank_elems(5, 3) == 5 * 16 + 16     # U [5 x ld(3)] then s [ld(3)]
+    assert lib.vilma_ld_lowrank_elems(5, 3) == 6 * 16 + 16     # U (pad2(5) x ld(3)) then s [ld(3)]
     # dense symmetric blocks keep the lower triangle by 128-column slabs
     assert lib.vilma_ld_dense_elems(588) == 128 * (588 + 460 + 332 + 204) + 76 * 80
     assert _lib.ntotals(2) == 8

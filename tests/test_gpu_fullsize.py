@@ -137,8 +137,8 @@ def test_c2_three_sweeps_against_oracle():
 
 
 def test_c4_eigen_form_operator_and_fit():
-    """BASELINE.json configs[3] at full size with EVERY block in eigen form: ld_colsum_kernel on
-    multi-slab U / diag(s)U^T (reference LowRankMatrix.dot, matrix_structures.py:148-152) against
+    """BASELINE.json configs[3] at full size with EVERY block in eigen form: ld_eig_fused_kernel
+    on multi-slab column-major U (reference LowRankMatrix.dot, matrix_structures.py:148-152) against
     U (s * (U^T x)) formed with torch on a sample of blocks, plus linearity, symmetry, zero rows
     at LD-missing SNPs, and the fit invariants."""
     import torch

@@ -223,10 +223,69 @@ def test_errors_are_loud():
     eng.close()
 
 
+@pytest.mark.parametrize('rank_of', [lambda n: 1, lambda n: min(n, 17), lambda n: max(1, n // 4),
+                                     lambda n: n])
+def test_fused_eigen_product_ranks_and_two_right_hand_sides(rank_of):
+    """Eigen-form blocks of every panel-width class with ranks below one panel, ragged, a quarter
+    of the block and full: the operator against numpy, and a two-step trial (two right-hand sides
+    in one pass over U) bit-identical to two one-step trials."""
+    from vilma_amd.engine import HipEngine
+    sizes = [37, 400, 530, 1100, 2100]
+    rng = np.random.default_rng(7)
+    n_ld = sum(sizes)
+    N, P, M = n_ld + 11, 2, 3
+    perm = rng.permutation(N).astype(np.int64)
+    eigs = []
+    for p in range(P):
+        row = []
+        for n in sizes:
+            r = rank_of(n)
+            U = np.linalg.qr(rng.normal(size=(n, r)))[0]
+            row.append((U, rng.uniform(0.1, 2.0, size=r)))
+        eigs.append(row)
+    eng = HipEngine(P, N, M, 1)
+    for p in range(P):
+        eng.load_ld(p, [('eig', U, s) for U, s in eigs[p]], perm, n_ld)
+    x = rng.normal(size=(P, N))
+    got = eng.ld_matvec(x)
+    want = np.zeros((P, N))
+    for p in range(P):
+        lo = 0
+        for n, (U, s) in zip(sizes, eigs[p]):
+            idx = perm[lo:lo + n]
+            want[p, idx] = U @ (s * (U.T @ x[p, idx]))
+            lo += n
+    _close(got, want, rtol=1e-11, atol=1e-11)
+    # a state to run trials from
+    se = rng.uniform(0.005, 0.02, size=(P, N))
+    ldd = np.zeros((P, N)); ldd[:, perm[:n_ld]] = 1.0
+    adj = rng.normal(size=(P, N)) / se
+    adj[:, perm[n_ld:]] = 0.0
+    eng.set_snp_data(adj, se, ldd / se ** 2, np.ones((P, N)), np.zeros(N, dtype=np.int32))
+    covs = np.stack([v * np.eye(P) for v in (1e-6, 1e-4, 1e-2)])
+    eng.set_mixture(np.linalg.inv(covs), np.linalg.slogdet(covs)[1])
+    eng.set_hyper(np.full((1, M), 1.0 / M))
+    mu = rng.normal(size=(M, P, N)) * 1e-3
+    mu[:, :, perm[n_ld:]] = 0.0
+    eng.set_mu(mu)
+    eng.eval(); eng.accept(False)
+    one = {}
+    for step in (0.7, 0.35):
+        one[step] = eng.trial(step).cpu().numpy().copy()
+    ta, tb = eng.trial2(0.7, 0.35)
+    assert np.array_equal(ta.cpu().numpy(), one[0.7])
+    assert np.array_equal(tb.cpu().numpy(), one[0.35])
+    eng.close()
+
+
 @pytest.mark.parametrize('sizes', [[1, 2, 3], [127, 128, 129], [255, 256, 257], [300, 64, 700],
-                                   [1000, 17], [511, 513, 512], [2431]])
+                                   [1000, 17], [511, 513, 512], [2431],
+                                   # the fused eigen-form product holds 2, 4, 8 or 12 rows per
+                                   # thread (blocks up to 512, 1024, 2048, 3072 rows); taller
+                                   # blocks keep the two-pass kernels
+                                   [512, 513, 9], [1024, 1025], [2048, 2049], [3072, 5], [3073, 70]])
 def test_ld_matvec_block_sizes(sizes):
-    """The symmetric (lower-triangle) dense kernel and the eigen-form kernel across slab
+    """The symmetric (lower-triangle) dense kernel and the eigen-form kernels across slab
     boundaries: block sizes around multiples of 128, odd sizes, ragged mixes, perm + missing."""
     from vilma_amd.engine import HipEngine
     rng = np.random.default_rng(sum(sizes))

@@ -24,6 +24,9 @@ struct BlockRec {
     int64_t off_v;       // element offset of the eigenvalues s (eigen form)
     int32_t start;       // LD position of the block's first SNP
     int32_t t_off;       // offset in the cohort's t scratch (eigen form)
+    int w;               // eigen form: rows per thread of the fused product (U stored column-major,
+                         // stride pad2(n)), or 0 = row-major U [n x ld(r)] for the two-pass
+                         // kernels (block too tall for the fused one)
 };
 
 struct CohortLd {
@@ -52,7 +55,29 @@ struct ItemSet {
     RowCombItem *rcomb = nullptr;
     int n_sym = 0, n_comb = 0, n_a = 0, n_row = 0, n_rcomb = 0;
     std::vector<EigenGroup> groups;
+    // fused eigen-form product: one list per block-height class (rows per thread 2, 4, 8, 12) and
+    // the combine items of all fused blocks
+    EigItem *eig[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_eig[4] = {0, 0, 0, 0};
+    RowCombItem *fcomb = nullptr;
+    int n_fcomb = 0;
 };
+inline int eig_class(int R) { return R == 2 ? 0 : R == 4 ? 1 : R == 8 ? 2 : 3; }
+inline int eig_class_rows(int k) { return k == 0 ? 2 : k == 1 ? 4 : k == 2 ? 8 : 12; }
+inline int pad2(int n) { return (n + 1) & ~1; }
+// columns of U one workgroup of the fused product takes (a whole number of batches): about
+// g_eig_slab_elems elements (default 48 k = 384 KB) of U per workgroup, at most 128 columns
+// (VILMA_EIG_SLAB_ELEMS, read when a context is created, keeps the sweep reproducible)
+int g_eig_slab_elems = 49152;
+inline int eig_slab_cols(int n, int R) {
+    const int C = eig_batch_cols(R);
+    const int want = (g_eig_slab_elems / n + C - 1) / C * C;
+    return std::max(C, std::min(128, want));
+}
+inline int eig_n_slabs(int n, int r, int R) {
+    const int cols = eig_slab_cols(n, R);
+    return (r + cols - 1) / cols;
+}
 
 // number of doubles a dense block occupies: per 128-column slab J the panel of rows >= 128 J
 inline int64_t sym_panel_elems(int n, int J);
@@ -121,6 +146,11 @@ struct vilma_ctx {
     // and tail per extra kernel, no measurable gain from the cache.  VILMA_EIGEN_GROUP_MB keeps
     // the experiment reproducible.
     int64_t eigen_group_bytes = INT64_MAX;
+    // eigen-form blocks go through the fused product (panel-major U, read once) unless
+    // VILMA_EIG_FUSED=0 or the block is too tall for the LDS of a CU
+    bool eig_fused = true;
+    double *repack_tmp = nullptr;   // row-major staging of one block's U before the panel repack
+    int64_t repack_elems = 0;
 
     // Work that depends only on the per-SNP pass of an evaluation (responsibility sums of the
     // trial state, convergence statistics) runs on `side`, concurrently with that evaluation's LD
@@ -186,6 +216,8 @@ void dev_free(void *p) { if (p) (void)hipFree(p); }
 
 void free_items(ItemSet &it) {
     dev_free(it.sym); dev_free(it.comb); dev_free(it.a); dev_free(it.row); dev_free(it.rcomb);
+    for (int k = 0; k < 4; ++k) dev_free(it.eig[k]);
+    dev_free(it.fcomb);
     it = ItemSet();
 }
 
@@ -208,6 +240,8 @@ struct HostItems {
     std::vector<RowCombItem> rcomb;
     std::vector<EigenGroup> groups;
     int64_t group_bytes = 0;          // U bytes in the group being filled
+    std::vector<EigItem> eig[4];
+    std::vector<RowCombItem> fcomb;
 };
 
 void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, int32_t s_base,
@@ -241,6 +275,27 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
                 H.comb.push_back(cb);
             }
             s_off += sym_scratch_elems(b.n, CH);
+        } else if (b.w > 0) {
+            // eigen form, fused product: column-major U, one item per slab of columns
+            const int R = b.w, cols = eig_slab_cols(b.n, R);
+            const int ns = eig_n_slabs(b.n, b.r, R), ldc = pad2(b.n);
+            const double *U = co.store + b.off_a, *sv = co.store + b.off_v;
+            for (int J = 0; J < ns; ++J) {
+                EigItem it;
+                const int c0 = J * cols;
+                it.a = U + (int64_t)c0 * ldc;
+                it.scale = sv + c0;
+                it.n = b.n; it.ncols = std::min(cols, b.r - c0); it.ldc = ldc;
+                it.x_off = pN + b.start; it.s_off = s_off + J * b.n; it.pad = 0;
+                H.eig[eig_class(R)].push_back(it);
+            }
+            for (int i0 = 0; i0 < b.n; i0 += 256) {
+                RowCombItem cb;
+                cb.n = b.n; cb.ns = ns; cb.s_base = s_off; cb.y_off = PN + pN + b.start;
+                cb.dot_off = pN + b.start; cb.dot_slot = slot++; cb.i0 = i0; cb.pad = 0;
+                H.fcomb.push_back(cb);
+            }
+            s_off += ns * b.n;
         } else {
             // eigen form: U [n x ld(r)] then s [ld(r)].  New group when this block would push the
             // group's U past the budget (a block larger than the budget gets a group of its own)
@@ -299,6 +354,10 @@ void sort_items(HostItems &H) {
     std::stable_sort(H.sym.begin(), H.sym.end(), [](const SymItem &x, const SymItem &y) {
         return (int64_t)x.rows * x.ld > (int64_t)y.rows * y.ld;
     });
+    for (auto &v : H.eig)
+        std::stable_sort(v.begin(), v.end(), [](const EigItem &x, const EigItem &y) {
+            return (int64_t)x.n * x.ncols > (int64_t)y.n * y.ncols;
+        });
 }
 
 template <typename T>
@@ -314,6 +373,9 @@ int upload_vec(vilma_ctx *c, const std::vector<T> &v, T **dev, int *count) {
 int upload_items(vilma_ctx *c, HostItems &H, ItemSet &out) {
     sort_items(H);
     out.groups = H.groups;
+    for (int k = 0; k < 4; ++k)
+        if (upload_vec(c, H.eig[k], &out.eig[k], &out.n_eig[k])) return 1;
+    if (upload_vec(c, H.fcomb, &out.fcomb, &out.n_fcomb)) return 1;
     return upload_vec(c, H.sym, &out.sym, &out.n_sym) || upload_vec(c, H.comb, &out.comb, &out.n_comb) ||
            upload_vec(c, H.a, &out.a, &out.n_a) || upload_vec(c, H.row, &out.row, &out.n_row) ||
            upload_vec(c, H.rcomb, &out.rcomb, &out.n_rcomb);
@@ -427,15 +489,21 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
     }
     // eigen-form blocks, group by group (one group unless VILMA_EIGEN_GROUP_MB says otherwise):
     // both passes over the group's U back to back; one bracket around all = one product
-    if (!it.groups.empty()) {
+    if (!it.groups.empty() || it.n_fcomb > 0) {
         prof_begin(c, s, e0);
+        // fused product (U read once), one launch per block-height class present, then the combine
+        for (int k = 0; k < 4; ++k)
+            launch_ld_eig_fused(it.eig[k], it.n_eig[k], eig_class_rows(k), pl, pl2, c->sym_scratch,
+                                c->s_stride, s);
+        launch_ld_rowsum_combine(it.fcomb, it.n_fcomb, pl, pl2, c->sym_scratch, c->s_stride,
+                                 c->dot_partials, c->dot_stride, s);
         for (const EigenGroup &g : it.groups) {
             launch_ld_colsum(it.a + g.a0, g.na, pl, pl2, /*keep=*/it.groups.size() > 1, s);
             launch_ld_rowsum(it.row + g.r0, g.nr, pl, pl2, c->sym_scratch, c->s_stride, s);
             launch_ld_rowsum_combine(it.rcomb + g.c0, g.nc, pl, pl2, c->sym_scratch, c->s_stride,
                                      c->dot_partials, c->dot_stride, s);
         }
-        prof_end(c, s, e0, VILMA_PROF_LD_COLSUM);
+        prof_end(c, s, e0, VILMA_PROF_LD_EIG);
     }
     if (it.n_comb > 0)      // not bracketed: tiny, and every event pair costs host time
         launch_ld_sym_combine(it.comb, it.n_comb, pl, pl2, c->sym_scratch, c->s_stride,
@@ -571,6 +639,11 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         const int v = std::atoi(gm);
         if (v >= 1) c->eigen_group_bytes = (int64_t)v << 20;
     }
+    if (const char *ef = std::getenv("VILMA_EIG_FUSED")) c->eig_fused = ef[0] != '0';
+    if (const char *se = std::getenv("VILMA_EIG_SLAB_ELEMS")) {
+        const int v = std::atoi(se);
+        if (v >= 1024) g_eig_slab_elems = v;
+    }
     if (const char *cr = std::getenv("VILMA_LD_CHUNK_ROWS")) {
         const int v = std::atoi(cr);
         if (v >= 128) c->chunk_rows = (v + 31) / 32 * 32;
@@ -623,6 +696,7 @@ void vilma_destroy(vilma_ctx *c) {
     prof_resolve(c);
     free_ready(c);
     for (auto &co : c->ld) dev_free(co.store);
+    dev_free(c->repack_tmp);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (int b = 0; b < 2; ++b) {
@@ -708,7 +782,8 @@ int64_t vilma_ld_dense_elems(int n) {
     return e;
 }
 int64_t vilma_ld_lowrank_elems(int n, int r) {
-    return (int64_t)n * pad_ld(r) + pad_ld(r);          // U [n x ld(r)] then s [ld(r)]
+    // U then s [ld(r)]: U is [n x ld(r)] row-major or [r][pad2(n)] column-major (fused product)
+    return (int64_t)pad2(n) * pad_ld(r) + pad_ld(r);
 }
 
 int vilma_ld_begin(vilma_ctx *c, int cohort, int n_blocks, int64_t n_ld, const int64_t *perm,
@@ -774,19 +849,36 @@ int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U
     if (co.next_start + (int64_t)n > co.n_ld) return fail(c, "blocks exceed n_ld");
     const int64_t need = vilma_ld_lowrank_elems(n, r);
     if (co.store_used + need > co.store_elems) return fail(c, "LD store overflow (total_elems)");
-    // only U and s are stored: both passes of the product read the same row-major U
+    // only U and s are stored.  Fused product: U column-major [r][pad2(n)] (pad row zero); blocks
+    // too tall for it keep the row-major U [n x ld(r)] of the two-pass kernels
+    const int W = c->eig_fused ? eig_rows_per_thread(n) : 0;
     double *dU = co.store + co.store_used;
-    double *dS = dU + (int64_t)n * pad_ld(r);
-    HIPCHK(c, hipMemcpy2D(dU, (size_t)pad_ld(r) * sizeof(double), U, (size_t)r * sizeof(double),
-                          (size_t)r * sizeof(double), (size_t)n, hipMemcpyDefault));
+    double *dS = dU + (int64_t)pad2(n) * pad_ld(r);
+    if (W > 0) {
+        const int64_t need_tmp = (int64_t)n * r;
+        if (need_tmp > c->repack_elems) {
+            dev_free(c->repack_tmp);
+            c->repack_tmp = nullptr;
+            c->repack_elems = 0;
+            if (dev_alloc(c, &c->repack_tmp, need_tmp + need_tmp / 2)) return 1;
+            c->repack_elems = need_tmp + need_tmp / 2;
+        }
+        HIPCHK(c, hipMemcpy(c->repack_tmp, U, (size_t)need_tmp * sizeof(double), hipMemcpyDefault));
+        launch_repack_columns(c->repack_tmp, n, r, pad2(n), dU, nullptr);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemcpy2D(dU, (size_t)pad_ld(r) * sizeof(double), U, (size_t)r * sizeof(double),
+                              (size_t)r * sizeof(double), (size_t)n, hipMemcpyDefault));
+    }
     HIPCHK(c, hipMemcpy(dS, s, (size_t)r * sizeof(double), hipMemcpyDefault));
-    BlockRec b{1, n, r, co.store_used, co.store_used + (int64_t)n * pad_ld(r), co.next_start,
-               (int32_t)co.t_used};
+    BlockRec b{1, n, r, co.store_used, co.store_used + (int64_t)pad2(n) * pad_ld(r), co.next_start,
+               (int32_t)co.t_used, W};
     co.blocks.push_back(b);
     co.store_used += need;
     co.next_start += n;
     co.t_used += pad_ld(r);
-    co.s_used += (int64_t)((r + 127) / 128) * n;         // partial row sums S[slab][n]
+    // partial row sums S[slab][n]
+    co.s_used += (int64_t)(W > 0 ? eig_n_slabs(n, r, W) : (r + 127) / 128) * n;
     co.alg_bytes += (int64_t)8 * n * r;
     return 0;
 }

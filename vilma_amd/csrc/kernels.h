@@ -42,6 +42,22 @@ struct RowCombItem {
     int32_t pad;
 };
 
+// Fused eigen-form product (both uses of U in one workgroup, U read from HBM once and held in
+// registers in between).  U of such a block is stored COLUMN-major (column stride ldc = n rounded
+// up to even, pad row zero).  One work item = a run of consecutive columns ("slab") of one block;
+// the partial y of the slab goes to scratch S[slab][i] and ld_rowsum_combine_kernel adds the slabs
+// in order.  No workgroup ever waits for another.
+struct EigItem {
+    const double *a;       // first column of this slab
+    const double *scale;   // eigenvalue of the slab's first column
+    int32_t n;             // rows of the block
+    int32_t ncols;         // columns in this slab
+    int32_t ldc;           // column stride in doubles (even)
+    int32_t x_off;         // pool offset of x[0] of the block
+    int32_t s_off;         // scratch offset of S[slab][0]
+    int32_t pad;
+};
+
 // One work item of the SYMMETRIC dense product: the panel of one block below (and including)
 // the diagonal tile of a 128-column slab, stored contiguously: rows j0..n-1, `ld` doubles each.
 // A panel is cut into chunks of at most `chunk_rows` rows (a multiple of 32), one work item each,
@@ -126,6 +142,17 @@ void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool0, co
 void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool0, double *pool1,
                               const double *scratch, int64_t s_stride, double *dot_partials,
                               int dot_stride, hipStream_t s);
+
+// Fused eigen-form product on column-major U (see EigItem).  eig_rows_per_thread(n): 2, 4, 8, 12,
+// or 0 = block too tall (two-pass kernels); columns are taken eig_batch_cols(R) at a time.
+int eig_rows_per_thread(int n);
+int eig_batch_cols(int R);
+// One launch takes the items of ONE class R (rows per thread).
+void launch_ld_eig_fused(const EigItem *items, int n_items, int R, const double *pool0,
+                         const double *pool1, double *scratch, int64_t s_stride, hipStream_t s);
+// row-major [n x r] -> column-major [r][ldc], rows n .. ldc-1 zero (load time)
+void launch_repack_columns(const double *src, int n, int r, int64_t ldc, double *dst,
+                           hipStream_t s);
 
 // pool1 != nullptr: two right-hand sides in one pass over the LD store; the second one's scratch
 // sits s_stride doubles, its y.z partials dot_stride slots behind the first one's

@@ -22,6 +22,8 @@
 // and scaled_ld_diags/tau, which turns ~5 full-array streams per pass into ALU work.
 #include "kernels.h"
 
+#include <algorithm>
+
 #define NEG_INF (-__builtin_huge_val())
 
 static __device__ __forceinline__ double wave_sum(double v) {
@@ -630,6 +632,203 @@ void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *poo
     pp.p[1] = pool1 ? pool1 : pool0;
     hipLaunchKernelGGL(ld_rowsum_combine_kernel, dim3(n_items, pool1 ? 2 : 1), dim3(256), 0, s,
                        items, pp, scratch, s_stride, dot_partials, dot_stride, g_pred);
+}
+
+// --------------------------------------------------------------------------------------------
+// Fused eigen-form product: y_partial = U_slab (s * (U_slab^T x)) with U read from HBM ONCE and
+// held in REGISTERS between the two uses.  U is stored column-major (column stride ldc = n rounded
+// up to even, the pad row zero).  One workgroup of 256 threads owns a slab of columns of one
+// block; thread t owns rows 512 i + 2 t, + 1 (i < R / 2): its x and its partial y live in
+// registers for the whole slab.  Columns go in batches of C:
+//   1. the batch is loaded (16 B per lane, 1 KiB per wave-load, consecutive rows of one column);
+//      the NEXT batch's loads are issued before this one is used, so the stream never drains;
+//   2. each thread's partial dot products with x (C values per right-hand side) are summed over
+//      the wave by the halving butterfly of the symmetric kernel (8 values per butterfly, DPP /
+//      permlane moves only) and over the 4 waves through LDS (double-buffered: one barrier per
+//      batch); scaled by the eigenvalues they are t'[c];
+//   3. y += U[:, c] t'[c] from the registers that still hold the batch.
+// The partial y of the slab goes to scratch S[slab][i]; ld_rowsum_combine_kernel adds the slabs
+// in order.  Workgroups never wait for each other; summation orders are fixed.
+// --------------------------------------------------------------------------------------------
+#define EIG_THREADS 256
+#define EIG_MAX_ROWS (EIG_THREADS * 12)     // tallest block the fused kernel takes (R = 12)
+
+int eig_rows_per_thread(int n) {            // 2, 4, 8, 12, or 0: too tall, two-pass kernels
+    if (n <= 2 * EIG_THREADS) return 2;
+    if (n <= 4 * EIG_THREADS) return 4;
+    if (n <= 8 * EIG_THREADS) return 8;
+    if (n <= EIG_MAX_ROWS) return 12;
+    return 0;
+}
+int eig_batch_cols(int R) { return R <= 2 ? 8 : (R <= 4 ? 4 : 2); }
+
+#define EIG_RED_SLOTS 16                      // values per batch, at most (R = 2, two right-hand sides)
+template <int R, int NR>
+static __device__ __forceinline__ void eig_fused_body(
+    const EigItem &it, const PoolPair &pools, double *__restrict__ scratch, int64_t s_stride,
+    double (&red)[2][EIG_THREADS / 64][EIG_RED_SLOTS]) {
+    constexpr int H = R / 2;                       // 16-byte loads per column per thread
+    constexpr int C = R <= 2 ? 8 : (R <= 4 ? 4 : 2);   // columns per batch: <= 12 loads in flight
+    constexpr int V = C * NR;                      // values reduced per batch
+    constexpr int G = (V + 7) / 8;                 // butterflies per batch
+    constexpr int NW = EIG_THREADS / 64;
+    const int n = it.n, ncols = it.ncols;
+    const int64_t ldc = it.ldc;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = 2 * threadIdx.x;              // + 512 i
+    double x[NR][R], y[NR][R];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double *xg = pools.p[r] + it.x_off;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const int row = row0 + 512 * i;
+            x[r][2 * i] = row < n ? xg[row] : 0.0;
+            x[r][2 * i + 1] = row + 1 < n ? xg[row + 1] : 0.0;
+            y[r][2 * i] = y[r][2 * i + 1] = 0.0;
+        }
+    }
+    const double *colp = it.a + row0;
+    v2d nxt[C][H];
+    auto issue = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const bool ok = c0 + c < ncols && row0 + 512 * i < n;
+                nxt[c][i] = ok ? LD_STREAM_LOAD(colp + (int64_t)(c0 + c) * ldc + 512 * i)
+                               : v2d{0.0, 0.0};
+            }
+    };
+    issue(0);
+    int buf = 0;
+    for (int c0 = 0; c0 < ncols; c0 += C, buf ^= 1) {
+        v2d cur[C][H];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int i = 0; i < H; ++i) cur[c][i] = nxt[c][i];
+        issue(c0 + C);                             // nothing is loaded past the slab's last column
+        double p[G * 8];
+#pragma unroll
+        for (int u = 0; u < G * 8; ++u) p[u] = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                    sacc = fma(cur[c][i].x, x[r][2 * i], sacc);
+                    sacc = fma(cur[c][i].y, x[r][2 * i + 1], sacc);
+                }
+                p[c * NR + r] = sacc;
+            }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            double q8[CS_ROWS];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q8[u] = p[8 * g + u];
+            int slot;
+            const double tot = sym_rowsum8(q8, lane, slot);
+            if ((lane & 7) == 0) red[buf][w][8 * g + slot] = tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double sc = c0 + c < ncols ? it.scale[c0 + c] : 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double t = red[buf][0][c * NR + r];
+#pragma unroll
+                for (int ww = 1; ww < NW; ++ww) t += red[buf][ww][c * NR + r];
+                t *= sc;
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                    y[r][2 * i] = fma(cur[c][i].x, t, y[r][2 * i]);
+                    y[r][2 * i + 1] = fma(cur[c][i].y, t, y[r][2 * i + 1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        double *so = scratch + r * s_stride + it.s_off;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const int row = row0 + 512 * i;
+            if (row < n) so[row] = y[r][2 * i];
+            if (row + 1 < n) so[row + 1] = y[r][2 * i + 1];
+        }
+    }
+}
+
+// One launch per block-height class present (R = rows per thread).  A single kernel switching on
+// the class at run time was measured and is slower (C4, one right-hand side: 695 us against
+// 620 us for the four launches together): it runs every class with the register budget of the
+// tallest (172 VGPRs: 2 waves per SIMD instead of 3-4).
+template <int R, int NR>
+__global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_kernel(
+    const EigItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred) {
+    __shared__ double red[2][EIG_THREADS / 64][EIG_RED_SLOTS];
+    PRED_EXIT(pred);
+    const EigItem it = items[blockIdx.x];
+    eig_fused_body<R, NR>(it, pools, scratch, s_stride, red);
+}
+
+template <int R>
+static void launch_eig_r(const EigItem *items, int n_items, const PoolPair &pp, bool two,
+                         double *scratch, int64_t s_stride, hipStream_t s) {
+    const dim3 grid(n_items), block(EIG_THREADS);
+    if (two)
+        hipLaunchKernelGGL((ld_eig_fused_kernel<R, 2>), grid, block, 0, s, items, pp, scratch,
+                           s_stride, g_pred);
+    else
+        hipLaunchKernelGGL((ld_eig_fused_kernel<R, 1>), grid, block, 0, s, items, pp, scratch,
+                           s_stride, g_pred);
+}
+
+void launch_ld_eig_fused(const EigItem *items, int n_items, int R, const double *pool0,
+                         const double *pool1, double *scratch, int64_t s_stride, hipStream_t s) {
+    if (n_items <= 0) return;
+    PoolPair pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    switch (R) {
+        case 2: launch_eig_r<2>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, s); break;
+        case 4: launch_eig_r<4>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, s); break;
+        case 8: launch_eig_r<8>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, s); break;
+        case 12: launch_eig_r<12>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, s); break;
+        default: break;
+    }
+}
+
+// row-major src [n x r] -> column-major dst [r][ldc], rows n .. ldc-1 zero (load time).  A 32 x 32
+// tile goes through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void repack_columns_kernel(const double *__restrict__ src, int n,
+                                                             int r, int64_t ldc,
+                                                             double *__restrict__ dst) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (j < n && c < r) ? src[(int64_t)j * r + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, j = j0 + tx;
+        if (c < r && j < ldc) dst[(int64_t)c * ldc + j] = tile[tx][ty + 8 * k];
+    }
+}
+void launch_repack_columns(const double *src, int n, int r, int64_t ldc, double *dst,
+                           hipStream_t s) {
+    const dim3 grid((unsigned)((ldc + 31) / 32), (unsigned)((r + 31) / 32));
+    hipLaunchKernelGGL(repack_columns_kernel, grid, dim3(256), 0, s, src, n, r, ldc, dst);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -356,7 +356,7 @@ class HipEngine:
         of stream time, which matters on small shards)."""
         self._check(self.lib.vilma_prof_enable(self.ctx, max(1, int(every)) if on else 0))
 
-    PROF_KINDS = ('ld_sym_kernel', 'ld_colsum_kernel', 'ld_sym_kernel_two_rhs')
+    PROF_KINDS = ('ld_sym_kernel', 'ld_eig_fused_kernel', 'ld_sym_kernel_two_rhs')
 
     def prof_read(self, reset=True):
         """{kernel: (milliseconds, launches)} accumulated by the library's HIP events."""

@@ -79,28 +79,33 @@ def dense_bytes_moved(n):
     return 0.5 * n * n + 32.0 * n
 
 
-# Eigen form: the device stores U once and streams it twice per product -- t' = s * (U^T x), then
-# y = U t' on the same array -- at ~0.8 of the dense kernel's rate per element (workload C4: LD
-# alone 5.8 TB/s against 6.9 TB/s, inside the sweep 5.1 against 6.5; all-dense 338, all-eigen 296,
-# chosen per block with this weight 327 sweeps/s, profiles/r02g_*; re-reading U from the
-# Infinity Cache group by group was measured and does not pay).
-EIGEN_FORM_PENALTY = 1.3
+# Eigen form: the device stores U once and, for blocks of up to EIGEN_FUSED_MAX_ROWS SNPs, streams
+# it ONCE per product (ld_eig_fused_kernel: a slab of columns stays in registers between
+# t' = s * (U^T x) and y = U t'); taller blocks stream it twice (two-pass kernels).  Per element the
+# fused kernel runs at ~0.85 of the dense kernel's rate (workload C4, one right-hand side: 5.2-5.8
+# TB/s per block-height class against 6.2 TB/s; r02q: all-eigen 432 sweeps/s, all-dense 331).
+EIGEN_FORM_PENALTY = 1.2
+EIGEN_FUSED_MAX_ROWS = 3072          # csrc/kernels.hip EIG_MAX_ROWS
+
+
+def _eigen_passes(n):
+    return 1.0 if n <= EIGEN_FUSED_MAX_ROWS else 2.0
 
 
 def eigen_cost(n, r):
     """Elements a product streams for an eigen-form block, in dense-kernel elements."""
-    return EIGEN_FORM_PENALTY * 2.0 * n * r
+    return EIGEN_FORM_PENALTY * _eigen_passes(n) * n * r
 
 
 def dense_is_cheaper(n, r):
-    """Dense symmetric form (lower triangle once, ~n^2/2 + 32 n elements) vs eigen form (U twice,
-    2 n r), by the measured cost of a product: eigen form only for r < (n/4 + 16) / 1.3."""
+    """Dense symmetric form (lower triangle once, ~n^2/2 + 32 n elements) vs eigen form (U once,
+    n r), by the measured cost of a product: eigen form only for r < (n/2 + 32) / 1.2."""
     return dense_bytes_moved(n) <= eigen_cost(n, r)
 
 
 def max_eigen_rank(n):
     """Largest rank for which `auto` keeps a block of n SNPs in eigen form (at least 1)."""
-    return max(1, min(n, int(dense_bytes_moved(n) / (EIGEN_FORM_PENALTY * 2.0 * n))))
+    return max(1, min(n, int(dense_bytes_moved(n) / (EIGEN_FORM_PENALTY * _eigen_passes(n) * n))))
 
 
 class LowRankMatrix:
