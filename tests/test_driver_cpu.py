@@ -183,6 +183,48 @@ def test_two_ranks_gloo(name):
     assert sum(info for _, _, info in results) == int(g['N'])
 
 
+def _gather_main(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
+                            world_size=world)
+    try:
+        from vilma_amd.sharding import Comm
+        comm = Comm()
+        comm.GATHER_CHUNK_BYTES = 4096          # force the slice-by-slice path ([7,2,n]: 3 slices)
+        N = 1001
+        rng = np.random.default_rng(0)
+        owner = rng.integers(0, world, N)
+        full = rng.normal(size=(7, 2, N))
+        mine = np.flatnonzero(owner == rank)
+        for arr in (full, full[0], full[0, 0]):          # 3-, 2- and 1-dimensional
+            got = comm.gather_snps(arr[..., mine], mine, N)
+            assert np.array_equal(got, arr)
+        q.put((rank, 'ok', len(mine)))
+    except BaseException:     # noqa: BLE001 - report to the parent
+        import traceback
+        q.put((rank, 'fail', traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_snps_in_slices_two_ranks():
+    """Comm.gather_snps assembles ragged, interleaved shards in global SNP order on every rank,
+    also when the array goes through in slices of its first axis."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gather_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in results:
+        assert status == 'ok', 'rank %d failed:\n%s' % (rank, info)
+    assert sum(info for _, _, info in results) == 1001
+
+
 def test_shard_plan_is_closed_and_balanced():
     from vilma_amd.sharding import plan_shards, local_ld
     g = golden('traj_p2_lowrank.npz')

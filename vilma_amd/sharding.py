@@ -96,9 +96,15 @@ class Comm:
         import torch
         return self.allreduce(torch.as_tensor(np.ascontiguousarray(array, dtype=np.float64)), op)
 
+    # temporaries of gather_snps per collective: a [M,P,N] array goes through in slices of its
+    # first axis so that no rank ever holds world x (the whole array) beside the result
+    GATHER_CHUNK_BYTES = 256 << 20
+
     def gather_snps(self, local, snp_index, n_global):
         """Assemble an array whose LAST axis is the shard's SNPs into the global SNP order on
-        every rank.  `snp_index` = global indices of the local SNPs."""
+        every rank (the class API returns whole arrays on every rank).  `snp_index` = global
+        indices of the local SNPs.  Large arrays are gathered slice by slice along their first
+        axis: the temporaries stay below GATHER_CHUNK_BYTES x world."""
         local = np.ascontiguousarray(local, dtype=np.float64)
         if self.world == 1:
             out = np.empty(local.shape[:-1] + (n_global,))
@@ -109,23 +115,34 @@ class Comm:
         counts = [None] * self.world
         dist.all_gather_object(counts, int(local.shape[-1]), group=self.group)
         width = max(counts)
-        lead = local.shape[:-1]
 
         def padded(a, dtype):
-            buf = np.zeros(lead + (width,) if a.ndim > 1 else (width,), dtype=dtype)
+            buf = np.zeros(a.shape[:-1] + (width,), dtype=dtype)
             buf[..., :a.shape[-1]] = a
             t = torch.as_tensor(buf)
             return t.cuda() if self.backend == 'nccl' else t
-        mine = padded(local, np.float64)
+
         idx = padded(np.asarray(snp_index, dtype=np.int64), np.int64)
-        bufs = [torch.empty_like(mine) for _ in range(self.world)]
         idxs = [torch.empty_like(idx) for _ in range(self.world)]
-        dist.all_gather(bufs, mine, group=self.group)
         dist.all_gather(idxs, idx, group=self.group)
-        out = np.empty(lead + (n_global,))
-        for r in range(self.world):
-            n = counts[r]
-            out[..., idxs[r].cpu().numpy()[:n]] = bufs[r].cpu().numpy()[..., :n]
+        where = [idxs[r].cpu().numpy()[:counts[r]] for r in range(self.world)]
+        out = np.empty(local.shape[:-1] + (n_global,))
+
+        def gather_into(dst, src):
+            mine = padded(src, np.float64)
+            bufs = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(bufs, mine, group=self.group)
+            for r in range(self.world):
+                dst[..., where[r]] = bufs[r].cpu().numpy()[..., :counts[r]]
+
+        lead = local.shape[0] if local.ndim > 1 else 1
+        row_bytes = 8 * width * max(1, int(np.prod(local.shape[1:-1])))
+        step = lead if local.ndim == 1 else max(1, int(self.GATHER_CHUNK_BYTES // max(1, row_bytes)))
+        if local.ndim == 1 or step >= lead:
+            gather_into(out, local)
+        else:       # the same number of collectives on every rank: lead and width are global
+            for lo in range(0, lead, step):
+                gather_into(out[lo:lo + step], local[lo:lo + step])
         return out
 
 
