@@ -59,6 +59,8 @@ struct ItemSet {
     // the combine items of all fused blocks
     EigItem *eig[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_eig[4] = {0, 0, 0, 0};
+    EigItem *eig_all = nullptr;      // the same items in one list (largest first), for the
+    int n_eig_all = 0;               // single-launch variant small shards use
     RowCombItem *fcomb = nullptr;
     int n_fcomb = 0;
 };
@@ -149,6 +151,8 @@ struct vilma_ctx {
     // eigen-form blocks go through the fused product (panel-major U, read once) unless
     // VILMA_EIG_FUSED=0 or the block is too tall for the LDS of a CU
     bool eig_fused = true;
+    // fewer fused work items than this: one launch for all block heights (VILMA_EIG_MERGE_BELOW)
+    int eig_merge_below = 8192;
     double *repack_tmp = nullptr;   // row-major staging of one block's U before the panel repack
     int64_t repack_elems = 0;
 
@@ -217,6 +221,7 @@ void dev_free(void *p) { if (p) (void)hipFree(p); }
 void free_items(ItemSet &it) {
     dev_free(it.sym); dev_free(it.comb); dev_free(it.a); dev_free(it.row); dev_free(it.rcomb);
     for (int k = 0; k < 4; ++k) dev_free(it.eig[k]);
+    dev_free(it.eig_all);
     dev_free(it.fcomb);
     it = ItemSet();
 }
@@ -373,8 +378,15 @@ int upload_vec(vilma_ctx *c, const std::vector<T> &v, T **dev, int *count) {
 int upload_items(vilma_ctx *c, HostItems &H, ItemSet &out) {
     sort_items(H);
     out.groups = H.groups;
-    for (int k = 0; k < 4; ++k)
+    std::vector<EigItem> eig_all;
+    for (int k = 0; k < 4; ++k) {
         if (upload_vec(c, H.eig[k], &out.eig[k], &out.n_eig[k])) return 1;
+        eig_all.insert(eig_all.end(), H.eig[k].begin(), H.eig[k].end());
+    }
+    std::stable_sort(eig_all.begin(), eig_all.end(), [](const EigItem &x, const EigItem &y) {
+        return (int64_t)x.n * x.ncols > (int64_t)y.n * y.ncols;
+    });
+    if (upload_vec(c, eig_all, &out.eig_all, &out.n_eig_all)) return 1;
     if (upload_vec(c, H.fcomb, &out.fcomb, &out.n_fcomb)) return 1;
     return upload_vec(c, H.sym, &out.sym, &out.n_sym) || upload_vec(c, H.comb, &out.comb, &out.n_comb) ||
            upload_vec(c, H.a, &out.a, &out.n_a) || upload_vec(c, H.row, &out.row, &out.n_row) ||
@@ -491,10 +503,14 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
     // both passes over the group's U back to back; one bracket around all = one product
     if (!it.groups.empty() || it.n_fcomb > 0) {
         prof_begin(c, s, e0);
-        // fused product (U read once), one launch per block-height class present, then the combine
-        for (int k = 0; k < 4; ++k)
-            launch_ld_eig_fused(it.eig[k], it.n_eig[k], eig_class_rows(k), pl, pl2, c->sym_scratch,
-                                c->s_stride, s);
+        // fused product (U read once): one launch per block-height class present -- or, on a small
+        // shard, all classes in one launch -- then the combine
+        if (it.n_eig_all < c->eig_merge_below)
+            launch_ld_eig_fused_all(it.eig_all, it.n_eig_all, pl, pl2, c->sym_scratch, c->s_stride, s);
+        else
+            for (int k = 0; k < 4; ++k)
+                launch_ld_eig_fused(it.eig[k], it.n_eig[k], eig_class_rows(k), pl, pl2,
+                                    c->sym_scratch, c->s_stride, s);
         launch_ld_rowsum_combine(it.fcomb, it.n_fcomb, pl, pl2, c->sym_scratch, c->s_stride,
                                  c->dot_partials, c->dot_stride, s);
         for (const EigenGroup &g : it.groups) {
@@ -640,6 +656,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         if (v >= 1) c->eigen_group_bytes = (int64_t)v << 20;
     }
     if (const char *ef = std::getenv("VILMA_EIG_FUSED")) c->eig_fused = ef[0] != '0';
+    if (const char *mb = std::getenv("VILMA_EIG_MERGE_BELOW")) c->eig_merge_below = std::atoi(mb);
     if (const char *se = std::getenv("VILMA_EIG_SLAB_ELEMS")) {
         const int v = std::atoi(se);
         if (v >= 1024) g_eig_slab_elems = v;

@@ -150,6 +150,10 @@ int eig_batch_cols(int R);
 // One launch takes the items of ONE class R (rows per thread).
 void launch_ld_eig_fused(const EigItem *items, int n_items, int R, const double *pool0,
                          const double *pool1, double *scratch, int64_t s_stride, hipStream_t s);
+// the items of every class in one launch (small shards: one ramp and tail instead of four)
+void launch_ld_eig_fused_all(const EigItem *items, int n_items, const double *pool0,
+                             const double *pool1, double *scratch, int64_t s_stride,
+                             hipStream_t s);
 // row-major [n x r] -> column-major [r][ldc], rows n .. ldc-1 zero (load time)
 void launch_repack_columns(const double *src, int n, int r, int64_t ldc, double *dst,
                            hipStream_t s);

@@ -5,8 +5,11 @@
 //                      of each panel in one pass; ld_sym_combine_kernel adds the partials in a
 //                      fixed order -- replaces BlockDiagonalMatrix.dot (reference
 //                      matrix_structures.py:389-408).  HBM-streaming, 16-byte coalesced loads.
-//   ld_colsum_kernel   out[c] = sum_j A[j][c] x[j] on a 128-column slab: both passes of
-//                      eigen-form blocks, LowRankMatrix.dot (matrix_structures.py:148-152).
+//   ld_eig_fused_kernel  eigen-form blocks, y = U (s * (U^T x)) with U read once: a slab of columns
+//                      of the column-major U stays in registers between its two uses --
+//                      LowRankMatrix.dot (matrix_structures.py:148-152).  ld_colsum_kernel +
+//                      ld_rowsum_kernel: the same product in two passes over a row-major U, for
+//                      blocks too tall for the fused kernel (> 3 072 SNPs).
 //   snp_pass_kernel    fused per-SNP pass: natural-gradient blend, new_mu, mixture
 //                      responsibilities (online softmax), posterior moments, KL and likelihood
 //                      partial sums -- replaces numerics.py:11-146, 179-213 and
@@ -776,6 +779,39 @@ __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_kernel(
     PRED_EXIT(pred);
     const EigItem it = items[blockIdx.x];
     eig_fused_body<R, NR>(it, pools, scratch, s_stride, red);
+}
+
+// All classes in one launch: the item says how many rows per thread its block needs.  Every class
+// then runs with the register budget of the tallest, which costs ~10 % on a full-size product --
+// but a small shard (an 8-GPU rank: ~1 300 items in all) gains more from one ramp and one tail
+// instead of four; launch_ld_eig_fused_all is used below EIG_MERGE_BELOW items.
+template <int NR>
+__global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_all_kernel(
+    const EigItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred) {
+    __shared__ double red[2][EIG_THREADS / 64][EIG_RED_SLOTS];
+    PRED_EXIT(pred);
+    const EigItem it = items[blockIdx.x];
+    if (it.n <= 2 * EIG_THREADS) eig_fused_body<2, NR>(it, pools, scratch, s_stride, red);
+    else if (it.n <= 4 * EIG_THREADS) eig_fused_body<4, NR>(it, pools, scratch, s_stride, red);
+    else if (it.n <= 8 * EIG_THREADS) eig_fused_body<8, NR>(it, pools, scratch, s_stride, red);
+    else eig_fused_body<12, NR>(it, pools, scratch, s_stride, red);
+}
+
+void launch_ld_eig_fused_all(const EigItem *items, int n_items, const double *pool0,
+                             const double *pool1, double *scratch, int64_t s_stride,
+                             hipStream_t s) {
+    if (n_items <= 0) return;
+    PoolPair pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    const dim3 grid(n_items), block(EIG_THREADS);
+    if (pool1)
+        hipLaunchKernelGGL((ld_eig_fused_all_kernel<2>), grid, block, 0, s, items, pp, scratch,
+                           s_stride, g_pred);
+    else
+        hipLaunchKernelGGL((ld_eig_fused_all_kernel<1>), grid, block, 0, s, items, pp, scratch,
+                           s_stride, g_pred);
 }
 
 template <int R>
