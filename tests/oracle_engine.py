@@ -207,7 +207,7 @@ class OracleEngine:
         self.cur = self.trial_state
 
     def delta_sums(self, which=0):
-        st = self.cur if which == 0 else self.trial_state
+        st = self.cur if which == 0 else (self.trial_state_b if which == 3 else self.trial_state)
         self._sums.copy_(torch.as_tensor(nm.sum_annotations(st['delta'], self.annot,
                                                             self.A).ravel()))
         return self._sums
