@@ -97,13 +97,24 @@ def test_gpu_eigh_keeps_the_ranks_lapack_keeps():
              ((75, 0.5, 1.0), (588, 0.93, 1.0), (1300, 0.7, 1.0), (2431, 0.95, 1.0), (700, 0.9, 0.8))]
     cases += [(_rank_deficient(rng, 900, 300), 1.0), (_rank_deficient(rng, 640, 480), 0.8),
               (-np.eye(5), 1.0), (np.zeros((4, 4)), 1.0), (0.05 * np.eye(6), 0.5)]
-    for X, t in cases:
+    def check(X, t, got):
         host = LowRankMatrix(X, t)
-        Ud, sd, s = ld_device._gpu_factors(torch, staging, compute, X, t)
+        Ud, sd, s = got
         assert Ud.shape == host.u.shape and sd.shape == host.s.shape, (X.shape, t)
         np.testing.assert_allclose(s, host.s, rtol=1e-10, atol=1e-12)
         recon = ((Ud * sd) @ Ud.T).cpu().numpy()
         np.testing.assert_allclose(recon, host.reconstruct(), rtol=0, atol=1e-10)
+    for X, t in cases:
+        check(X, t, ld_device._gpu_factors(torch, staging, compute, X, t))
+    # the same blocks in stacks: ragged sizes padded to a common one (the padding's eigenvalue
+    # sits below each block's Gershgorin bound, also for the negative-definite case)
+    small = [(k, X, t) for k, (X, t) in enumerate(cases) if X.shape[0] <= 128]
+    mid = [(k, X, t) for k, (X, t) in enumerate(cases) if 576 < X.shape[0] <= 704]
+    assert len(small) >= 4 and len(mid) >= 3
+    for group in (small, mid):
+        got = ld_device._gpu_factors_stacked(torch, staging, compute, group)
+        for k, X, t in group:
+            check(X, t, got[k])
 
 
 def test_lazy_schema_streams_to_the_device(tmp_path):

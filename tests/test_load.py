@@ -197,3 +197,27 @@ def test_select_eigenpairs_is_lowrankmatrix_selection():
                 assert host.s.shape == (1,) and host.s[0] == 0
             else:
                 np.testing.assert_array_equal(ev[idx], host.s)
+
+
+def test_gpu_eigh_plan_and_stacks(monkeypatch):
+    """The loader's cost model (ld_device.plan_gpu_eigh / gpu_stacks): all but the small blocks go
+    to the GPU, in stacks padded to their largest member, none smaller than half of that, no
+    stack beyond the memory cap; nothing without a deferred matrix goes."""
+    from vilma_amd import ld_device
+    from vilma_amd.synthetic import block_sizes
+    sizes = [int(n) for n in block_sizes(1_000_000, 1700, None, 0)]
+    chosen = ld_device.plan_gpu_eigh(sizes, [True] * len(sizes), 16)
+    assert all(sizes[b] > 128 for b in chosen) and all(sizes[b] < 320 for b in range(len(sizes))
+                                                       if b not in chosen)
+    assert len(chosen) > 0.9 * len(sizes)
+    stacks = ld_device.gpu_stacks(sizes, chosen)
+    assert sorted(b for st in stacks for b in st) == sorted(chosen)
+    for st in stacks:
+        npad = ld_device._padded(max(sizes[b] for b in st))
+        assert all(2 * sizes[b] >= npad for b in st)
+        assert len(st) * 8 * npad * npad <= ld_device.EIGH_STACK_BYTES or len(st) == 1
+        assert len(st) <= ld_device.EIGH_STACK_MAX
+    assert len(stacks) < len(chosen) / 8                 # real stacks, not singletons
+    assert ld_device.plan_gpu_eigh(sizes, [False] * len(sizes), 16) == set()
+    monkeypatch.setenv('VILMA_GPU_EIGH', '0')
+    assert ld_device.plan_gpu_eigh(sizes, [True] * len(sizes), 16) == set()

@@ -4,10 +4,12 @@ The reference does all of this on the host, once per fit, block by block
 (/root/reference/src/vilma/variational_inference.py:189-252 calling matrix_structures.py:
 148-152 `dot`, 159-196 `inverse_dot`, 349-387 `ridge_inverse_dot`, 426-447 `diag` / `get_rank`).
 At 1 M SNPs x 2 cohorts that is minutes of host time against milliseconds of sweeps, so here
-the eigendecompositions are shared between the host cores (LAPACK `eigh`, one call per core:
-the routine the reference uses) and the GPU (rocSOLVER through torch.linalg.eigh, which takes
-the LARGEST blocks -- 19x a host thread at 2 400 SNPs, no better than one at 200), and
-everything that consumes the factors runs on the device while the next blocks decompose:
+the eigendecompositions are shared between the GPU -- rocSOLVER's BATCHED symmetric eigensolver
+through torch.linalg.eigh on stacks of blocks padded to a common size: one launch sequence
+serves a whole stack, 0.8 ms per 576-SNP block in stacks of 32 against 13.7 ms alone and 23 ms
+on a host thread (profiles/microbench_batched_eigh.py) -- and the host cores (LAPACK `eigh`,
+one call per core, the routine the reference uses: still the better place for the small
+blocks), and everything that consumes the factors runs on the device:
 
   * `stream_cohort`: the factors (U, s) of each block travel through pinned staging buffers on
     a copy stream (uploads overlap the host's decompositions and the device work of the block
@@ -62,11 +64,16 @@ class _Staging:
             slot['buf'] = t.empty(max(n, 1 << 16), dtype=t.float64).pin_memory()
         host = slot['buf'][:n].view(array.shape)
         host.numpy()[...] = array                    # one host copy into pinned memory
-        dev = t.empty(array.shape, dtype=t.float64, device=self.device)
+        # The device tensor belongs to the copy stream (allocated under it) and is USED on the
+        # compute stream: record_stream keeps the allocator from handing its memory to the next
+        # upload while compute kernels that read it are still queued.
+        compute = t.cuda.current_stream(self.device)
         with t.cuda.stream(self.stream):
+            dev = t.empty(array.shape, dtype=t.float64, device=self.device)
             dev.copy_(host, non_blocking=True)
             ev = t.cuda.Event()
             ev.record(self.stream)
+        dev.record_stream(compute)
         slot['event'] = ev
         return dev, ev
 
@@ -88,59 +95,142 @@ def store_upper_bound(lib, sizes, form):
     return total
 
 
-# Cost model of one block's eigh, seconds: LAPACK dsyevd on ONE host thread and rocSOLVER (one
-# matrix per call through torch.linalg.eigh) on the GPU, fitted to profiles/r01f_microbench_eigh.txt
-# (n = 200 / 588 / 1200 / 2431: host 3 / 23 / 335 / 1319 ms, GPU 4.5 / 13.5 / 28 / 69 ms).
+# Cost model of one block's eigh, seconds.  Host: LAPACK dsyevd on ONE thread (n = 200 / 588 /
+# 1200 / 2431: 3 / 23 / 335 / 1319 ms, profiles/r01f_microbench_eigh.txt).  GPU: rocSOLVER's batched
+# dsyevd is launch-bound, so a stack of k equal-size matrices takes about as long as one until the
+# chip fills: T1(n) / min(k, ksat(n)) per matrix, T1 = 4 / 14 / 25 / 38 / 66 ms at n = 192 / 576 /
+# 1024 / 1536 / 2432 and 0.17 / 0.82 / 2.3 / 6.0 / 18 ms per matrix in stacks of 32
+# (profiles/r02s_microbench_batched_eigh.txt).
+# `workers` LAPACK threads do not deliver `workers` times one thread (memory-bound tridiagonal
+# reductions, numpy's wrappers): 400 blocks of the LDetect size law take 2.7-3.2 s on 16 workers
+# against ~12 s of summed single-thread time (profiles/r02s_load_timing.txt)
+HOST_POOL_EFFICIENCY = 0.27
+EIGH_PAD = 64                 # blocks are padded to a multiple of this to share a stack
+EIGH_STACK_BYTES = 1.5e9      # device bytes of one stack (its matrices; rocSOLVER's workspace is extra)
+EIGH_STACK_MAX = 64
+
+
 def _host_eigh_seconds(n):
     return 23e-3 * (n / 588.0) ** 2.9
 
 
-def _gpu_eigh_seconds(n):
-    return 4e-3 + 2.7e-5 * n
+def _gpu_eigh_seconds(n, stack=1):
+    t1 = 4e-3 + 2.7e-5 * n
+    ksat = 17.0 * (576.0 / max(n, 1)) ** 1.1
+    return t1 / max(1.0, min(float(stack), ksat))
+
+
+def _padded(n):
+    return (int(n) + EIGH_PAD - 1) // EIGH_PAD * EIGH_PAD
+
+
+def _stack_limit(npad):
+    return int(max(1, min(EIGH_STACK_MAX, EIGH_STACK_BYTES // (8 * npad * npad))))
+
+
+def _stack_fill(npad):
+    """Matrices of padded size npad one batched call takes in about the time of one."""
+    return 17.0 * (576.0 / max(npad, 1)) ** 1.1
 
 
 def plan_gpu_eigh(sizes, deferred, workers):
-    """Which blocks to eigendecompose on the GPU while the host pool does the rest: the GPU's
-    advantage over a host thread grows with n (1.5x at 200 SNPs, 19x at 2431), so it takes the
-    largest blocks, as many as keep its queue no longer than the pool's.  Returns a set of block
-    indices (empty when VILMA_GPU_EIGH=0)."""
+    """Which blocks to eigendecompose on the GPU (in stacks, see gpu_stacks) and which on the
+    host pool.  The GPU pass runs before the pool's (see stream_cohort), so a block goes to the
+    GPU when its share of a full stack costs less than its share of the pool: in practice
+    everything above ~150 SNPs.  Returns a set of block indices (empty when VILMA_GPU_EIGH=0)."""
     import os
     if os.environ.get('VILMA_GPU_EIGH', '1') == '0':
         return set()
-    order = sorted((b for b in range(len(sizes)) if deferred[b]), key=lambda b: -sizes[b])
-    host = sum(_host_eigh_seconds(sizes[b]) for b in order)
-    gpu, chosen = 0.0, set()
-    for b in order:
-        tg, th = _gpu_eigh_seconds(sizes[b]), _host_eigh_seconds(sizes[b])
-        if tg >= th or gpu + tg > (host - th) / max(1, workers):
-            break
-        gpu += tg
-        host -= th
-        chosen.add(b)
-    return chosen
+    if os.environ.get('VILMA_GPU_EIGH') == 'all':
+        return {b for b in range(len(sizes)) if deferred[b]}
+    pool = max(1.0, HOST_POOL_EFFICIENCY * workers)
+    return {b for b, n in enumerate(sizes)
+            if deferred[b] and _gpu_eigh_seconds(_padded(n), _stack_fill(_padded(n)))
+            < _host_eigh_seconds(n) / pool}
 
 
-def _gpu_factors(torch, staging, compute, X, t):
-    """eigh of one symmetric block on the GPU and the reference's selection of eigenpairs
-    (matrix_structures.select_eigenpairs on the eigenvalues, on the host: n doubles).
-    Returns (U [n,r] device, s [r] device, s on the host)."""
-    n = X.shape[0]
-    Xd, ev = staging.upload(X)
-    compute.wait_event(ev)
-    w, Q = torch.linalg.eigh(Xd)
-    w_host = w.cpu().numpy()
+def gpu_stacks(sizes, on_gpu):
+    """Group the GPU's blocks into stacks for the batched eigensolver: largest first, each stack
+    padded to its largest member and filled with the next-largest blocks up to the number the
+    solver takes in the time of one (launch-bound: _stack_fill), the memory cap, and no member
+    smaller than half the padded size.  Returns a list of lists of block indices."""
+    order = sorted(on_gpu, key=lambda b: (-sizes[b], b))
+    stacks, i = [], 0
+    while i < len(order):
+        npad = _padded(sizes[order[i]])
+        k = int(max(1, min(_stack_limit(npad), np.ceil(_stack_fill(npad)))))
+        j = i + 1
+        while j < len(order) and j - i < k and 2 * sizes[order[j]] >= npad:
+            j += 1
+        stacks.append(order[i:j])
+        i = j
+    return stacks
+
+
+def _select_from_spectrum(torch, w_dev, Q_cols, w_host, t):
+    """The reference's choice of eigenpairs (matrix_structures.select_eigenpairs) applied to an
+    ascending spectrum w_host (host) / w_dev (device) with eigenvectors in the COLUMNS of Q_cols
+    [n, n] (device view).  Returns (U [n,r] device, s [r] device, s on the host)."""
+    n = Q_cols.shape[0]
     idx, degenerate = ms.select_eigenpairs(w_host, t)
-    f64 = dict(dtype=torch.float64, device=Xd.device)
+    f64 = dict(dtype=torch.float64, device=Q_cols.device)
     if degenerate == 'ones':
         return torch.ones((n, 1), **f64), torch.zeros(1, **f64), np.zeros(1)
     lo, hi = int(idx[0]), int(idx[-1]) + 1
     if hi - lo == idx.size:                          # a contiguous range of the ascending spectrum
-        Ud = Q[:, lo:hi].contiguous()
+        Ud = Q_cols[:, lo:hi].contiguous()
+        sd = w_dev[lo:hi].contiguous()
     else:
-        Ud = Q[:, torch.as_tensor(idx, device=Xd.device)].contiguous()
+        sel = torch.as_tensor(idx, device=Q_cols.device)
+        Ud = Q_cols[:, sel].contiguous()
+        sd = w_dev[sel].contiguous()
     if degenerate == 'zero':
         return Ud, torch.zeros(1, **f64), np.zeros(1)
-    return Ud, w[torch.as_tensor(idx, device=Xd.device)].contiguous(), w_host[idx]
+    return Ud, sd, w_host[idx]
+
+
+def _gpu_factors_stacked(torch, staging, compute, items):
+    """eigh of several symmetric blocks in ONE batched call.  items: list of (key, X [n,n] host,
+    t); all are padded to the largest one's size rounded up to EIGH_PAD.  A block sits in the top-left corner of
+    its npad x npad slot; the rest of the diagonal is a value below the block's Gershgorin bound
+    (-(2 max_i sum_j |X_ij| + 1)), so the padded matrix is block diagonal, its ascending spectrum
+    is the padding's eigenvalue `pad` times followed by the block's own, and the block's
+    eigenvectors are zero on the padding.  Returns {key: (U [n,r] device, s [r] device, s on the
+    host)}."""
+    npad = _padded(max(X.shape[0] for _, X, _ in items))
+    B = len(items)
+    dev = staging.device
+    if B == 1 and items[0][1].shape[0] == npad:
+        key, X, t = items[0]
+        Xd, ev = staging.upload(X)
+        compute.wait_event(ev)
+        w, Q = torch.linalg.eigh(Xd)
+        return {key: _select_from_spectrum(torch, w, Q, w.cpu().numpy(), t)}
+    stack = torch.zeros((B, npad, npad), dtype=torch.float64, device=dev)
+    for i, (_, X, _) in enumerate(items):
+        n = X.shape[0]
+        Xd, ev = staging.upload(X)
+        compute.wait_event(ev)
+        stack[i, :n, :n] = Xd
+        if n < npad:
+            stack[i].diagonal()[n:] = -(2.0 * Xd.abs().sum(dim=1).max() + 1.0)
+    w, Q = torch.linalg.eigh(stack)
+    del stack
+    w_host = w.cpu().numpy()
+    out = {}
+    for i, (key, X, t) in enumerate(items):
+        n = X.shape[0]
+        pad = npad - n
+        if not np.all(np.isfinite(w_host[i])):
+            raise RuntimeError('batched eigh failed on a block of %d SNPs (non-finite spectrum)' % n)
+        out[key] = _select_from_spectrum(torch, w[i, pad:], Q[i, :n, pad:], w_host[i, pad:], t)
+    return out
+
+
+def _gpu_factors(torch, staging, compute, X, t):
+    """eigh of one symmetric block on the GPU and the reference's selection of eigenpairs.
+    Returns (U [n,r] device, s [r] device, s on the host)."""
+    return _gpu_factors_stacked(torch, staging, compute, [(0, X, t)])[0]
 
 
 def _load_symmetric(m):
@@ -152,9 +242,29 @@ def _load_symmetric(m):
     return X, t
 
 
+def _decompose_on_gpu(torch, staging, compute, pool, mats, sizes, on_gpu):
+    """Eigendecompose the blocks `on_gpu` stack by stack (gpu_stacks: largest first; the host
+    pool reads and checks the next stack's matrices while the GPU works on the current one).
+    Returns {block index: (U, s, s on the host)}, everything on the device."""
+    chunks = gpu_stacks(sizes, on_gpu)
+    factors = {}
+
+    def read(chunk):
+        return [(b, pool.submit(_load_symmetric, mats[b])) for b in chunk]
+    nxt = read(chunks[0]) if chunks else None
+    for c in range(len(chunks)):
+        cur, nxt = nxt, (read(chunks[c + 1]) if c + 1 < len(chunks) else None)
+        items = []
+        for b, fut in cur:
+            X, t = fut.result()
+            items.append((b, X, t))
+        factors.update(_gpu_factors_stacked(torch, staging, compute, items))
+    return factors
+
+
 def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
-    """Decompose (host, thread pool) and install (device) the blocks of one cohort's local
-    BlockDiagonalMatrix `ld`, in LD order.  z_ld [n_ld]: z = beta-hat / se at the LD positions.
+    """Decompose (GPU in stacks, then host thread pool) and install (device) the blocks of one
+    cohort's local BlockDiagonalMatrix `ld`, in LD order.  z_ld [n_ld]: z = beta-hat / se at the LD positions.
 
     Returns dict(diag [n_ld], rmle [n_ld] = R R^+ z, chi = z^T R^+ z, rank) -- what
     VIScheme.__init__ derives per cohort (variational_inference.py:189-192, 236-252)."""
@@ -181,7 +291,7 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
     def decompose(b):
         m = mats[b]
         if b in on_gpu:
-            return m, _load_symmetric(m)             # read + check only: the GPU decomposes it
+            return m, b                      # already decomposed on the GPU (first pass below)
         m.materialize()                  # np.linalg.eigh + thresholding; releases the GIL
         return m, None
 
@@ -193,6 +303,11 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
     compute = torch.cuda.current_stream(dev)
     try:
         with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            # first pass: the GPU's share, stack by stack (device-resident factors); second pass:
+            # every block in LD order, the host pool decomposing its share a window ahead
+            t0 = time.perf_counter()
+            gpu_factors = _decompose_on_gpu(torch, staging, compute, pool, mats, sizes, on_gpu)
+            t_gpu = time.perf_counter() - t0
             pending = []
             it = iter(range(len(mats)))
             start = 0
@@ -212,7 +327,7 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
                 t0 = time.perf_counter()
                 refill()
                 if raw is not None:
-                    Ud, sd, s = _gpu_factors(torch, staging, compute, raw[0], raw[1])
+                    Ud, sd, s = gpu_factors.pop(raw)
                     n, r = Ud.shape
                     rank += r if r > 1 else (0 if s[0] == 0 else 1)     # LowRankMatrix.get_rank
                 else:
@@ -242,11 +357,12 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
         if limiter is not None:
             limiter.restore_original_limits()
     engine.ld_end(cohort)
-    logging.info('LD cohort %d: %d blocks streamed to the device (%d decomposed on the GPU); main '
-                 'thread waited %.2f s for the host pool, spent %.2f s on uploads and device '
-                 'work', cohort, len(mats), len(on_gpu), t_wait, t_dev)
+    logging.info('LD cohort %d: %d blocks streamed to the device (%d decomposed on the GPU in '
+                 '%.2f s); main thread waited %.2f s for the host pool, spent %.2f s on uploads '
+                 'and device work', cohort, len(mats), len(on_gpu), t_gpu, t_wait, t_dev)
     return {'diag': diag.cpu().numpy(), 'rmle': rmle.cpu().numpy(), 'chi': float(chi.item()),
-            'rank': float(rank), 'wait_s': t_wait, 'device_s': t_dev, 'gpu_eigh': len(on_gpu)}
+            'rank': float(rank), 'wait_s': t_wait, 'device_s': t_dev, 'gpu_eigh': len(on_gpu),
+            'gpu_eigh_s': t_gpu}
 
 
 def ridge_start(engine, b, reg, diag, rtol=1e-13, max_iter=20000):
