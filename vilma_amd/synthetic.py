@@ -260,6 +260,11 @@ class SyntheticShard:
         self.adj = np.zeros((P, N))
         self._eig = [[] for _ in range(P)]
         f64 = dict(dtype=torch.float64, device=device)
+        factor_eig = None
+        if self.spectrum == 'factor':
+            factor_eig = [_factor_model_eig_stacked(
+                [(i, np.random.default_rng([self.seed, 5000 + self.b0 + i, p]), blk.n)
+                 for i, blk in enumerate(self.blocks)], device) for p in range(P)]
         for i, blk in enumerate(self.blocks):
             lo = self.snp_start[i]
             sl = slice(lo, lo + blk.n)
@@ -268,10 +273,10 @@ class SyntheticShard:
             for p in range(P):
                 rng = np.random.default_rng([self.seed, 5000 + self.b0 + i, p])
                 if self.spectrum == 'factor':
-                    _progress('factor-model eigh', i * P + p, len(self.blocks) * P, every=500)
-                    U, sv = _factor_model_eig(rng, blk.n, r, device)
+                    U, sv = factor_eig[p].pop(i)
                     self.ranks_by_cohort[p][i] = U.shape[1]
                     r = U.shape[1]
+                    rng.normal(size=(blk.n, -(-blk.n // 4)))      # F was drawn from this stream
                 else:
                     G = torch.as_tensor(rng.normal(size=(blk.n, r)), **f64)
                     U = torch.linalg.qr(G)[0].contiguous()
@@ -337,6 +342,45 @@ class SyntheticShard:
                 self.fake_mu[p, sl] = self.inverse_betas[p, sl] + 1e-3 * blk.se[p] * blk.init_noise[p]
         # LD-missing SNPs: NaN in every cohort -> cross-cohort nanmean is NaN -> 0 (:653-657)
         return self
+
+
+def _factor_model_eig_stacked(blocks, device):
+    """_factor_model_eig for many blocks at once: (key, rng, n) triples -> {key: (U, s)}.  The
+    matrices are eigendecomposed in stacks like the loader's (ld_device.gpu_stacks: rocSOLVER's
+    batched solver is launch-bound, a stack costs about what one matrix does)."""
+    import torch
+    from . import ld_device
+    from .matrix_structures import select_eigenpairs
+    sizes = {key: n for key, _, n in blocks}
+    rngs = {key: rng for key, rng, _ in blocks}
+    out = {}
+    stacks = ld_device.gpu_stacks(sizes, list(sizes))
+    for si, members in enumerate(stacks):
+        _progress('factor-model eigh, stack', si, len(stacks), every=20)
+        npad = ld_device._padded(max(sizes[k] for k in members))
+        stack = torch.zeros((len(members), npad, npad), dtype=torch.float64, device=device)
+        for j, key in enumerate(members):
+            n = sizes[key]
+            m = -(-n // 4)
+            F = torch.as_tensor(rngs[key].normal(size=(n, m)), dtype=torch.float64, device=device)
+            R = F @ F.T / m
+            R.diagonal().add_(0.05)
+            d = R.diagonal().rsqrt()
+            stack[j, :n, :n] = d[:, None] * R * d[None, :]
+            if n < npad:
+                stack[j].diagonal()[n:] = -(2.0 * n + 1.0)        # below -sum_j |R_ij| >= -n
+        w, V = torch.linalg.eigh(stack)
+        w_host = w.cpu().numpy()
+        for j, key in enumerate(members):
+            n = sizes[key]
+            pad, m = npad - n, -(-n // 4)
+            keep, degenerate = select_eigenpairs(w_host[j, pad:], FACTOR_LD_THRESH)
+            if degenerate is not None or keep.size < m:
+                raise RuntimeError('factor-model block of %d SNPs kept %d eigenpairs, expected '
+                                   '>= %d' % (n, keep.size, m))
+            idx = torch.as_tensor(keep + pad, device=device)
+            out[key] = (V[j, :n, idx].contiguous(), w[j, idx].contiguous())
+    return out
 
 
 def _factor_model_eig(rng, n, m, device):
