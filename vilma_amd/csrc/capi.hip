@@ -398,6 +398,9 @@ int ensure_ready(vilma_ctx *c) {
     for (int p = 0; p < c->P; ++p)
         if (!c->ld[p].ended) return fail(c, "LD for cohort " + std::to_string(p) + " not loaded");
     free_ready(c);
+    dev_free(c->repack_tmp);             // load-time staging of the eigen-form repack: done with
+    c->repack_tmp = nullptr;
+    c->repack_elems = 0;
     // work items carry 32-bit offsets into the vector pool and the scratch: check the totals
     // BEFORE any offset is formed
     {
