@@ -110,9 +110,12 @@ int64_t vilma_ld_lowrank_elems(int n, int r);
  * (LowRankMatrix, matrix_structures.py:95-152), NOT the raw .npy matrix. */
 int vilma_ld_add_dense(vilma_ctx *ctx, int cohort, int n, const double *R);
 
-/* Add the next block in eigen form: U [n*r] row-major, s [r]; dot = U (s * (U^T x))
- * (LowRankMatrix.dot, matrix_structures.py:148-152).  Only U and s are stored; both passes of a
- * product read the same row-major U (column sums, then row sums). */
+/* Add the next block in eigen form: U [n*r] row-major (host or device), s [r];
+ * dot = U (s * (U^T x)) (LowRankMatrix.dot, matrix_structures.py:148-152).  Only U and s are
+ * stored.  Blocks of up to 3 072 SNPs keep U column-major and a product reads it ONCE (the fused
+ * kernel holds a slab of columns in registers between the two uses); taller blocks keep it
+ * row-major and read it twice (column sums, then row sums).  The call repacks; the caller's
+ * layout is always row-major. */
 int vilma_ld_add_lowrank(vilma_ctx *ctx, int cohort, int n, int r, const double *U,
                          const double *s);
 
