@@ -242,23 +242,56 @@ def _load_symmetric(m):
     return X, t
 
 
-def _decompose_on_gpu(torch, staging, compute, pool, mats, sizes, on_gpu):
-    """Eigendecompose the blocks `on_gpu` stack by stack (gpu_stacks: largest first; the host
-    pool reads and checks the next stack's matrices while the GPU works on the current one).
-    Returns {block index: (U, s, s on the host)}, everything on the device."""
+import os as _os
+# host threads feeding the batched solver, one stream each (VILMA_GPU_EIGH_LANES overrides)
+GPU_EIGH_LANES = int(_os.environ.get('VILMA_GPU_EIGH_LANES', '3'))
+
+
+def _decompose_on_gpu(torch, device, pool, mats, sizes, on_gpu):
+    """Eigendecompose the blocks `on_gpu` stack by stack (gpu_stacks: largest first).  rocSOLVER's
+    launch sequences are bound by the host thread that issues them (two threads on two streams:
+    1.5x on stacks of blocks up to ~600 SNPs, nothing above 1 000), so GPU_EIGH_LANES threads take
+    alternate stacks, each on its own stream with its own staging buffers; the host pool reads and
+    checks a lane's next stack while the GPU works on its current one.  Returns {block index:
+    (U, s, s on the host)}, everything on the device and safe to use on the current stream."""
+    from concurrent.futures import ThreadPoolExecutor
     chunks = gpu_stacks(sizes, on_gpu)
-    factors = {}
+    if not chunks:
+        return {}
+    compute = torch.cuda.current_stream(device)
+    lanes = max(1, min(GPU_EIGH_LANES, len(chunks)))
 
     def read(chunk):
         return [(b, pool.submit(_load_symmetric, mats[b])) for b in chunk]
-    nxt = read(chunks[0]) if chunks else None
-    for c in range(len(chunks)):
-        cur, nxt = nxt, (read(chunks[c + 1]) if c + 1 < len(chunks) else None)
-        items = []
-        for b, fut in cur:
-            X, t = fut.result()
-            items.append((b, X, t))
-        factors.update(_gpu_factors_stacked(torch, staging, compute, items))
+
+    def lane(k):
+        mine = chunks[k::lanes]
+        stream = torch.cuda.Stream(device=device)
+        stream.wait_stream(compute)
+        staging = _Staging(torch, device)
+        out = {}
+        with torch.cuda.stream(stream):
+            nxt = read(mine[0])
+            for c in range(len(mine)):
+                cur, nxt = nxt, (read(mine[c + 1]) if c + 1 < len(mine) else None)
+                items = []
+                for b, fut in cur:
+                    X, t = fut.result()
+                    items.append((b, X, t))
+                out.update(_gpu_factors_stacked(torch, staging, stream, items))
+        stream.synchronize()
+        return out
+
+    factors = {}
+    if lanes == 1:
+        factors.update(lane(0))
+    else:
+        with ThreadPoolExecutor(max_workers=lanes) as ex:
+            for part in ex.map(lane, range(lanes)):
+                factors.update(part)
+    for Ud, sd, _ in factors.values():          # allocated on a lane's stream, used on this one
+        Ud.record_stream(compute)
+        sd.record_stream(compute)
     return factors
 
 
@@ -306,7 +339,7 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
             # first pass: the GPU's share, stack by stack (device-resident factors); second pass:
             # every block in LD order, the host pool decomposing its share a window ahead
             t0 = time.perf_counter()
-            gpu_factors = _decompose_on_gpu(torch, staging, compute, pool, mats, sizes, on_gpu)
+            gpu_factors = _decompose_on_gpu(torch, dev, pool, mats, sizes, on_gpu)
             t_gpu = time.perf_counter() - t0
             pending = []
             it = iter(range(len(mats)))
