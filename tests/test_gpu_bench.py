@@ -66,6 +66,27 @@ def test_bench_two_ranks_launch_line():
     assert abs(e1 - e2) < 1e-9 * abs(e1)
 
 
+def test_bench_four_ranks_long_run_matches_one_gpu():
+    """Four ranks (rehearsed over gloo on this GPU), 30 sweeps with the look-ahead pipeline and
+    rejected steps in them: every rank takes the same decisions sweep after sweep (a mismatch
+    would hang a collective) and the sharded fit reaches the single-GPU ELBO."""
+    env = dict(os.environ, VILMA_BENCH_BACKEND='gloo', VILMA_BENCH_SAME_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4',
+           '--master-addr', '127.0.0.1', '--master-port', str(29990 + os.getpid() % 9),
+           'bench.py', '--gpus', '4', '--steps', '30', '--warmup', '2', '--workload', 'tiny']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, check=True,
+                         timeout=600)
+    d = _last_json(out.stdout)
+    assert d['n_gpus'] == 4 and d['steps'] == 30
+    assert d['config']['beta_trials_per_sweep'] > 1.0          # the run did see rejected steps
+    one = subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '30',
+                          '--warmup', '2', '--no-cpu-baseline'], cwd=ROOT, capture_output=True,
+                         text=True, check=True)
+    o = _last_json(one.stdout)
+    assert abs(o['config']['elbo_end'] - d['config']['elbo_end']) < 1e-9 * abs(o['config']['elbo_end'])
+    assert o['config']['beta_trials_per_sweep'] == d['config']['beta_trials_per_sweep']
+
+
 def test_bench_gpus_without_a_launcher_starts_one():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must not measure one GPU
     and call it two: it starts the driver's torch.distributed.run line as a child process (before
