@@ -283,6 +283,113 @@ int vilma_fetch_end(vilma_ctx *ctx, int buffer, double *dst_host, int64_t n, int
 /* Synchronous read of a flag slot and of {orig, new} of the last vilma_decide (tests). */
 int vilma_read_decision(vilma_ctx *ctx, int slot, int *flag, double *obj2);
 
+/* ---- the sweep behind ONE call (vilma_sweep / vilma_elbo / vilma_posterior /
+ *      vilma_set_state / vilma_get_state, communicator owned by the context) -------------------
+ *
+ * Everything above is the fine-grained surface (one evaluation, one trial, one decision).  The
+ * entry points below run the reference's control flow INSIDE the library -- line search on L,
+ * accept / reject, M-step, error-scaling update, running ELBO change -- so a host in any language
+ * drives a fit with vilma_initialize (or vilma_set_state) + vilma_sweep in a loop.  The context
+ * owns the small device-resident result vector all of them share; its layout, for P cohorts, A
+ * annotations, M components (nt = VILMA_NTOTALS(P), am = A*M), all doubles:
+ *   [0,3) convergence sums | [3,3+nt) totals of the current state | nt totals of trial candidate A |
+ *   nt of candidate B | am responsibility sums of A | am of B | 3 convergence maxima | am hyper_delta
+ * The part that is summed over ranks ([0, 3+3nt+2am)) is contiguous: one all-reduce per decision. */
+int64_t vilma_results_size(const vilma_ctx *ctx);
+double *vilma_results_dev(vilma_ctx *ctx);      /* device pointer, owned by the context */
+
+/* Shard-independent constants of the objective: chi_stat [P], ld_ranks [P] of the WHOLE problem
+ * (variational_inference.py:226-252) and whether error_scaling is learned (--learn-scaling,
+ * :472-486).  Needed before vilma_set_state / vilma_initialize. */
+int vilma_set_fit_constants(vilma_ctx *ctx, const double *chi_stat, const double *ld_ranks,
+                            int scale_se);
+
+/* Collective used for every cross-rank sum of the sweep (one all-reduce per decision).
+ * Default: none (one rank).
+ *   vilma_comm_init_rccl: ncclCommInitRank on this context's device; `id` = the 128 bytes of
+ *     vilma_comm_unique_id(), produced on rank 0 and handed to every rank by the caller (any side
+ *     channel: MPI, a file, torch.distributed's store).  The communicator is owned and destroyed by
+ *     the context; all-reduces are queued on the sweep's stream (no host synchronisation).  RCCL is
+ *     bound at run time (dlopen of the librccl already in the process, else the system one), so a
+ *     single-GPU host needs no RCCL at all.
+ *   vilma_comm_set_callback: the host supplies the all-reduce (rehearsals over gloo, MPI, ...):
+ *     fn(user, stream, buf_dev, n, op) must reduce buf_dev[0..n) in place over all ranks, ordered
+ *     after everything queued on `stream`, before it returns or in stream order; op 0 = sum, 1 = max. */
+typedef int (*vilma_allreduce_fn)(void *user, void *stream, double *buf_dev, int64_t n, int op);
+int vilma_comm_unique_id(char id[128]);
+int vilma_comm_init_rccl(vilma_ctx *ctx, int world, int rank, const char id[128]);
+int vilma_comm_set_callback(vilma_ctx *ctx, vilma_allreduce_fn fn, void *user, int world, int rank);
+/* kind: 0 none, 1 RCCL, 2 callback */
+int vilma_comm_info(const vilma_ctx *ctx, int *kind, int *world, int *rank);
+/* In-place all-reduce of a device buffer through the context's collective (setup-time sums). */
+int vilma_comm_allreduce(vilma_ctx *ctx, void *stream, double *buf_dev, int64_t n, int op);
+
+/* _set_state (variational_inference.py:694-710) + the evaluation every caller follows it with:
+ * make (vi_mu, hyper_delta, error_scaling) the current state and evaluate it; *objective = its
+ * ELBO (elbo(), :412-417).  vi_mu [M*P*N] host or device, NULL = keep the vi_mu already on the
+ * device (vilma_init_state); error_scaling NULL = keep.  vi_delta is implicit (the fixed point
+ * _nat_to_not_vi_delta, :632-641). */
+int vilma_set_state(vilma_ctx *ctx, void *stream, const double *vi_mu, const double *hyper_delta,
+                    const double *error_scaling, double *objective);
+/* Any pointer may be NULL.  vi_mu [M*P*N], vi_delta [N*M], hyper_delta [A*M], error_scaling [P]. */
+int vilma_get_state(vilma_ctx *ctx, double *vi_mu, double *vi_delta, double *hyper_delta,
+                    double *error_scaling);
+
+/* _initialize (variational_inference.py:643-700) from the jittered ridge start fake_mu [P*N] (drawn
+ * by the host with the reference's RNG call): per-SNP part on the device, responsibility sums
+ * all-reduced, hyper_delta = normalise(sums + 1) clamped at 1e-100 (:667-674), then the first
+ * evaluation.  *objective = ELBO of the starting point. */
+int vilma_initialize(vilma_ctx *ctx, void *stream, const double *fake_mu, double *objective);
+
+/* ELBO of the current state (elbo(), variational_inference.py:412-417); cached, no device work. */
+int vilma_elbo(vilma_ctx *ctx, double *objective);
+
+/* real_posterior_mean / real_posterior_variance of the current state (variational_inference.py:
+ * 740-751): moments times scalings (squared for the variance).  [P*N] host pointers, may be NULL. */
+int vilma_posterior(vilma_ctx *ctx, double *mean, double *var);
+
+#define VILMA_MAX_COHORTS 8
+#define VILMA_SWEEP_EVENTS 48
+typedef struct {
+    double elbo, running;            /* after the sweep (the call's *elbo / *running_delta) */
+    double L[5];
+    double diff_sum[3], diff_max[3]; /* convergence statistics of vilma_mean_diff for this sweep
+                                        (filled with VILMA_SWEEP_DIFF) */
+    double error_scaling[VILMA_MAX_COHORTS];
+    int32_t n_evaluations;           /* candidate points whose objective was looked at */
+    int32_t n_trials;                /* beta line-search trials among them */
+    int32_t n_products;              /* passes over the LD store (a two-step trial is one) */
+    int32_t ran_ahead;               /* this sweep's stage was decided on the device, ahead of the host */
+    int32_t skipped_ahead;           /* stages queued ahead whose decision went the other way */
+    /* the reference's per-update INFO lines (variational_inference.py:399, 424-449, 782):
+     * kind 0 = paramset update {paramset, L}, 1 = objective pair {old, new}, 2 = error scaling */
+    int32_t n_events;
+    struct { int32_t kind, paramset; double a, b; } events[VILMA_SWEEP_EVENTS];
+} vilma_sweep_stats;
+
+#define VILMA_SWEEP_DIFF 1        /* fuse the convergence statistics into the sweep's last evaluation */
+#define VILMA_SWEEP_LOOKAHEAD 2   /* the caller promises to call vilma_sweep again: the next sweep
+                                     may be queued (and decided on the device) before this call
+                                     returns */
+#define VILMA_SWEEP_VETO 4        /* a stage already running ahead must not proceed if no posterior
+                                     mean moved in the sweep before it (optimize() would stop) */
+#define VILMA_SWEEP_VETO_NEXT 8   /* ... the same for the stage queued by this call */
+#define VILMA_SWEEP_VERBOSE 16    /* record events; all-reduce the convergence maxima as well */
+
+/* One outer iteration: _optimize_step (variational_inference.py:396-410) = _nat_grad_step
+ * (:419-450): beta line search (_update_beta, :762-802) until the inner loop's break rule, the
+ * M-step (_update_hyper_delta, :825-860), with scale_se the error-scaling update (:472-486), then
+ * the running ELBO change.  L [5] in/out; *elbo in = ELBO before the sweep, out = after;
+ * *running_delta in/out, NaN = None (first sweep).  line_search_rate = 2 in optimize() (:361).
+ * Returns nonzero with the reference's messages on a line-search failure ("Encountered a numerical
+ * error.", :790-799).  With VILMA_SWEEP_DIFF, vilma_snapshot_mean must have been called once. */
+int vilma_sweep(vilma_ctx *ctx, void *stream, double L[5], double *elbo, double *running_delta,
+                double line_search_rate, int flags, vilma_sweep_stats *stats);
+
+/* Forget work queued ahead by VILMA_SWEEP_LOOKAHEAD (the caller breaks its promise): waits for
+ * it, restores the state after the last sweep reported.  A no-op otherwise. */
+int vilma_sweep_drain(vilma_ctx *ctx);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 
 /* vilma_prof_enable(ctx, k): k = 0 off; k >= 1 brackets every k-th LD product's streaming kernels

@@ -235,3 +235,162 @@ class OracleEngine:
 
     def close(self):
         pass
+
+    # ---- the sweep behind one call: the engine-level interface of HipEngine (vilma_sweep & co.),
+    # with the reference's line search (variational_inference.py:396-450, 762-802, 825-860)
+    # restated in Python on the oracle-backed evaluations above.  TEST ONLY: the product's sweep
+    # is csrc/sweep.hip.
+    L_MAX, REL_TOL, ABS_TOL, EM_TOL, MAX_NUM_ITERS = 1e12, 1e-6, 1e-6, 10, 20
+
+    def set_fit_constants(self, chi_stat, ld_ranks, scale_se):
+        self.chi, self.ranks = np.array(chi_stat, dtype=float), np.array(ld_ranks, dtype=float)
+        self.scale_se = bool(scale_se)
+
+    def bind_comm(self, comm):
+        self.comm = comm
+        self.collective = 'torch.distributed (test engine)'
+
+    def _reduce(self, sl, op='sum'):
+        if getattr(self, 'comm', None) is not None and self.comm.active:
+            self.comm.allreduce_inplace(self.results[sl], op=op)
+
+    def _objective_from(self, t):
+        P = self.P
+        t = np.asarray(t).tolist()
+        lik = 0.0
+        for p in range(P):
+            lik += ((-0.5 * (t[P + p] + t[2 * P + p]) + t[p] - 0.5 * self.chi[p]) / self.tau[p]
+                    - 0.5 * self.ranks[p] * np.log(self.tau[p]))
+        return lik - (t[3 * P] + t[3 * P + 1])
+
+    def _evaluate(self):
+        L = self.layout
+        self.eval()
+        self._reduce(L.totals)
+        totals = self.results[L.totals].numpy().copy()
+        return self._objective_from(totals), totals
+
+    def set_state(self, vi_mu, hyper, tau=None):
+        if tau is not None:
+            self.set_tau(tau)
+        self.set_hyper(hyper)
+        if vi_mu is not None:
+            self.set_mu(vi_mu)
+        self._obj, self._tot = self._evaluate()
+        self.accept(False)
+        self._cur_sums = False
+        return self._obj
+
+    def initialize(self, fake_mu):
+        self.init_state(fake_mu)
+        self._reduce(self.layout.sums)
+        sums = self._sums.numpy().reshape(self.A, self.M)
+        hyper = sums + 1.
+        hyper /= hyper.sum(axis=1, keepdims=True)
+        return self.set_state(None, np.maximum(hyper, 1e-100))
+
+    def get_hyper(self):
+        return np.array(self.hyper).reshape(self.A, self.M)
+
+    def get_tau(self):
+        return np.array(self.tau)
+
+    def elbo(self):
+        return self._obj
+
+    def drain(self):
+        pass
+
+    def posterior(self):
+        return self.cur['mean'] * self.scal, self.cur['var'] * self.scal ** 2
+
+    def sweep(self, L, elbo, running, line_search_rate=2., flags=0):
+        from types import SimpleNamespace
+        lay = self.layout
+        st = SimpleNamespace(n_evaluations=0, n_trials=0, n_products=0, ran_ahead=0,
+                             skipped_ahead=0, n_events=0, events=[], diff_sum=[0.] * 3,
+                             diff_max=[0.] * 3)
+        want_diff, verbose = bool(flags & 1), bool(flags & 16)
+        conv_tol = float('inf') if running is None else 0.1 * running
+        delta_sum = 0.
+        orig = self._obj
+        for _ in range(self.MAX_NUM_ITERS):
+            L[0] = max(1., L[0] / 1.25)
+            # ---- _update_beta: backtracking on L[0]
+            alt = None
+            while True:
+                step = 1. / L[0]
+                if alt is not None and alt[0] == step:
+                    new, totals, cand, with_sums = alt[1], alt[2], 2, False
+                    alt = None
+                else:
+                    self.trial2(step, 1. / (L[0] * line_search_rate))
+                    self.delta_sums(1)
+                    self._reduce(slice(lay.ttotals.start, lay.sums.stop))
+                    host = self.results.numpy().copy()
+                    totals, cand, with_sums = host[lay.ttotals], 1, True
+                    new = self._objective_from(totals)
+                    tb = host[lay.ttotals_b]
+                    alt = (1. / (L[0] * line_search_rate), self._objective_from(tb), tb)
+                    st.n_products += 1
+                st.n_evaluations += 1
+                st.n_trials += 1
+                if new >= orig - self.REL_TOL * abs(orig) - self.ABS_TOL:
+                    if L[0] > self.L_MAX and not np.isclose(orig, new):
+                        raise RuntimeError('Encountered a numerical error.')
+                    self.accept(cand)
+                    self._obj, self._tot, self._cur_sums = new, totals, with_sums
+                    break
+                if L[0] > self.L_MAX:
+                    if not np.isclose(orig, new):
+                        raise RuntimeError('Encountered a numerical error.')
+                    new = orig
+                    break
+                L[0] *= line_search_rate
+            delta_sum += new - orig
+            if abs(new - orig) <= conv_tol or L[0] == 1 or L[0] > self.L_MAX:
+                break
+            orig = new
+        # ---- _update_hyper_delta
+        L[1] = max(1., L[1] / 1.25)
+        last = not self.scale_se
+        if not self._cur_sums:
+            self.delta_sums(0)
+            self._reduce(lay.sums)
+        self.mstep()
+        self.eval(diff=want_diff and last)
+        self.accept(False)
+        self._reduce(slice(lay.dsum.start if (want_diff and last) else lay.totals.start,
+                           lay.totals.stop))
+        if want_diff and last and verbose:
+            self._reduce(lay.dmax, op='max')
+        host = self.results.numpy().copy()
+        orig, self._tot = self._obj, host[lay.totals]
+        self._obj = self._objective_from(self._tot)
+        self._cur_sums = False
+        st.n_evaluations += 1
+        st.n_products += 1
+        delta_sum += self._obj - orig
+        L[2] = max(1., L[2] / 1.25)
+        if self.scale_se and delta_sum < self.EM_TOL:
+            P, t = self.P, self._tot
+            orig = self._obj
+            self.set_tau((self.chi - 2 * t[:P] + t[2 * P:3 * P] + t[P:2 * P]) / self.ranks)
+            self._obj, self._tot = self._evaluate()
+            self.accept(False)
+            st.n_evaluations += 1
+            st.n_products += 1
+            delta_sum += self._obj - orig
+        if want_diff:
+            if not last:
+                self.mean_diff()
+                self._reduce(lay.dsum)
+                if verbose:
+                    self._reduce(lay.dmax, op='max')
+                host = self.results.numpy().copy()
+            st.diff_sum, st.diff_max = list(host[lay.dsum]), list(host[lay.dmax])
+        if running is None:
+            running = delta_sum
+        running = 0.5 * running + 0.5 * max(delta_sum, 0)
+        st.error_scaling = list(self.tau) + [1.] * (8 - self.P)
+        return elbo + delta_sum, running, st

@@ -20,7 +20,7 @@ def _ready(name, sweeps=2):
     elbo, L, red = vi.elbo(params), np.ones(5), None
     for _ in range(sweeps):                 # with --learn-scaling tau moves away from 1
         params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
-    vi._pending = None
+    vi.engine.drain()
     half = np.array([0.5 * vi.ld_ranks[p] * math.log(vi.error_scaling[p])
                      for p in range(vi.num_pops)])
     return vi, half, REL_TOL, ABS_TOL
@@ -30,8 +30,8 @@ def _ready(name, sweeps=2):
 def test_decide_matches_host_bitwise(name):
     vi, half, rel, ab = _ready(name)
     eng, Lay = vi.engine, vi.engine.layout
-    obj, totals = vi._evaluate()
-    vi._accept(False, obj, totals)
+    eng.eval()
+    eng.accept(False)
     seen = set()
     for step in (1.0, 0.5, 0.03, 4.0, 64.0):           # large steps overshoot: rejected
         eng.trial(step)
@@ -57,8 +57,8 @@ def test_decide_matches_host_bitwise(name):
 def test_predicated_work_is_skipped_when_the_flag_is_zero():
     vi, half, rel, ab = _ready('p2_scale_se')
     eng = vi.engine
-    obj, totals = vi._evaluate()
-    vi._accept(False, obj, totals)
+    eng.eval()
+    eng.accept(False)
     eng.delta_sums()
     before = eng.fetch()
     mu0, (m0, v0) = eng.get_mu(), eng.get_moments()

@@ -23,6 +23,27 @@ def ntotals(P):
 
 STATE_CURRENT, STATE_TRIAL_BETA, STATE_TRIAL_EVAL, STATE_TRIAL_BETA_B = 0, 1, 2, 3
 
+SWEEP_DIFF, SWEEP_LOOKAHEAD, SWEEP_VETO, SWEEP_VETO_NEXT, SWEEP_VERBOSE = 1, 2, 4, 8, 16
+MAX_COHORTS, SWEEP_EVENTS = 8, 48
+
+
+class SweepEvent(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('paramset', C.c_int32), ('a', C.c_double), ('b', C.c_double)]
+
+
+class SweepStats(C.Structure):
+    """vilma_sweep_stats of include/vilma_hip.h."""
+    _fields_ = [('elbo', C.c_double), ('running', C.c_double), ('L', C.c_double * 5),
+                ('diff_sum', C.c_double * 3), ('diff_max', C.c_double * 3),
+                ('error_scaling', C.c_double * MAX_COHORTS),
+                ('n_evaluations', C.c_int32), ('n_trials', C.c_int32), ('n_products', C.c_int32),
+                ('ran_ahead', C.c_int32), ('skipped_ahead', C.c_int32), ('n_events', C.c_int32),
+                ('events', SweepEvent * SWEEP_EVENTS)]
+
+
+# int fn(void *user, void *stream, double *buf_dev, int64_t n, int op)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
 _c_double_p = C.POINTER(C.c_double)
 _c_i32_p = C.POINTER(C.c_int32)
 _c_i64_p = C.POINTER(C.c_int64)
@@ -92,6 +113,21 @@ def load():
         'vilma_fetch_begin': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
         'vilma_fetch_end': (C.c_int, [vp, C.c_int, vp, C.c_int64, vp]),
         'vilma_read_decision': (C.c_int, [vp, C.c_int, vp, vp]),
+        'vilma_results_size': (C.c_int64, [vp]),
+        'vilma_results_dev': (vp, [vp]),
+        'vilma_set_fit_constants': (C.c_int, [vp, vp, vp, C.c_int]),
+        'vilma_comm_unique_id': (C.c_int, [vp]),
+        'vilma_comm_init_rccl': (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        'vilma_comm_set_callback': (C.c_int, [vp, ALLREDUCE_FN, vp, C.c_int, C.c_int]),
+        'vilma_comm_info': (C.c_int, [vp, vp, vp, vp]),
+        'vilma_comm_allreduce': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
+        'vilma_set_state': (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        'vilma_get_state': (C.c_int, [vp, vp, vp, vp, vp]),
+        'vilma_initialize': (C.c_int, [vp, vp, vp, vp]),
+        'vilma_elbo': (C.c_int, [vp, vp]),
+        'vilma_posterior': (C.c_int, [vp, vp, vp]),
+        'vilma_sweep': (C.c_int, [vp, vp, vp, vp, vp, C.c_double, C.c_int, vp]),
+        'vilma_sweep_drain': (C.c_int, [vp]),
         'vilma_prof_enable': (C.c_int, [vp, C.c_int]),
         'vilma_prof_read': (C.c_int, [vp, _c_double_p, _c_i64_p, C.c_int]),
         # include/vilma_numerics.h -- the Function API (vilma_amd/numerics.py)

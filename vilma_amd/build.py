@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libvilma_hip.so')
-SOURCES = ['kernels.hip', 'capi.hip', 'numerics_api.hip']
-HEADERS = ['kernels.h', os.path.join('..', '..', 'include', 'vilma_hip.h'),
+SOURCES = ['kernels.hip', 'capi.hip', 'sweep.hip', 'numerics_api.hip']
+HEADERS = ['kernels.h', 'ctx.h', os.path.join('..', '..', 'include', 'vilma_hip.h'),
            os.path.join('..', '..', 'include', 'vilma_numerics.h')]
 
 
@@ -33,7 +33,7 @@ def build_library(force=False, verbose=True, extra_flags=(), out=None):
         return LIB
     cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
            '-ffp-contract=on', '-Wall', '-Wno-unused-function'] + list(extra_flags) + [
-           '-o', out or LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           '-o', out or LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ['-ldl']
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

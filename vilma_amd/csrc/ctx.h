@@ -1,0 +1,227 @@
+// Internal: the context behind the C-ABI (include/vilma_hip.h), shared by capi.hip (LD store,
+// state, evaluation entry points) and sweep.hip (the sweep state machine).  Not installed.
+#pragma once
+#include "../../include/vilma_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace vilma_detail {
+
+struct BlockRec {
+    int form;            // 0 dense, 1 eigen
+    int n, r;
+    int64_t off_a;       // element offset of R or U in the cohort store
+    int64_t off_v;       // element offset of the eigenvalues s (eigen form)
+    int32_t start;       // LD position of the block's first SNP
+    int32_t t_off;       // offset in the cohort's t scratch (eigen form)
+    int w;               // eigen form: rows per thread of the fused product (U stored column-major,
+                         // stride pad2(n)), or 0 = row-major U [n x ld(r)] for the two-pass
+                         // kernels (block too tall for the fused one)
+};
+
+struct CohortLd {
+    bool begun = false, ended = false;
+    int n_blocks = 0;
+    int64_t n_ld = 0;
+    double *store = nullptr;
+    int64_t store_elems = 0, store_used = 0;
+    int32_t next_start = 0;
+    int64_t t_used = 0;
+    std::vector<BlockRec> blocks;
+    int64_t alg_bytes = 0;
+    int64_t s_used = 0;                            // scratch entries of the symmetric product
+};
+
+// device-resident work lists of one LD product (all cohorts, or one cohort)
+// Eigen-form blocks are processed in groups of <= eigen_group_bytes of U (default: one group):
+// first pass of the group (t' = s * U^T x), then the second pass on the SAME U (y = U t'), then
+// the combine -- three launches per group.
+struct EigenGroup { int a0, na, r0, nr, c0, nc; };
+struct ItemSet {
+    SymItem *sym = nullptr;
+    SymCombItem *comb = nullptr;
+    LdItem *a = nullptr;
+    RowItem *row = nullptr;
+    RowCombItem *rcomb = nullptr;
+    int n_sym = 0, n_comb = 0, n_a = 0, n_row = 0, n_rcomb = 0;
+    std::vector<EigenGroup> groups;
+    // fused eigen-form product: one list per block-height class (rows per thread 2, 4, 8, 12) and
+    // the combine items of all fused blocks
+    EigItem *eig[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_eig[4] = {0, 0, 0, 0};
+    EigItem *eig_all = nullptr;      // the same items in one list (largest first), for the
+    int n_eig_all = 0;               // single-launch variant small shards use
+    RowCombItem *fcomb = nullptr;
+    int n_fcomb = 0;
+};
+inline int eig_class(int R) { return R == 2 ? 0 : R == 4 ? 1 : R == 8 ? 2 : 3; }
+inline int eig_class_rows(int k) { return k == 0 ? 2 : k == 1 ? 4 : k == 2 ? 8 : 12; }
+inline int pad2(int n) { return (n + 1) & ~1; }
+// columns of U one workgroup of the fused product takes (a whole number of batches): about
+// g_eig_slab_elems elements (default 48 k = 384 KB) of U per workgroup, at most 128 columns
+// (VILMA_EIG_SLAB_ELEMS, read when a context is created, keeps the sweep reproducible)
+inline int g_eig_slab_elems = 49152;
+inline int eig_slab_cols(int n, int R) {
+    const int C = eig_batch_cols(R);
+    const int want = (g_eig_slab_elems / n + C - 1) / C * C;
+    return std::max(C, std::min(128, want));
+}
+inline int eig_n_slabs(int n, int r, int R) {
+    const int cols = eig_slab_cols(n, R);
+    return (r + cols - 1) / cols;
+}
+
+// number of doubles a dense block occupies: per 128-column slab J the panel of rows >= 128 J
+inline int64_t sym_panel_elems(int n, int J);
+
+
+// leading dimensions are multiples of 16 doubles (128 B): each 128-column slab of a row then
+// starts on a cache-line boundary and no line is shared between two workgroups' slabs
+inline int pad_ld(int n) { return (n + 15) & ~15; }
+inline int slab_width(int n, int J) { return std::min(128, n - 128 * J); }
+inline int64_t sym_panel_elems(int n, int J) {
+    return (int64_t)(n - 128 * J) * pad_ld(slab_width(n, J));
+}
+inline int n_slabs(int n) { return (n + 127) / 128; }
+// scratch of the symmetric product for one block: row sums S[slab][n] and the column-sum chunks
+// C[slab][chunk][128] (laid out for ceil(n / chunk_rows) chunks per slab)
+inline int32_t sym_scratch_elems(int n, int chunk_rows) {
+    return n_slabs(n) * (n + ((n + chunk_rows - 1) / chunk_rows) * 128);
+}
+
+}  // namespace vilma_detail
+using namespace vilma_detail;
+
+struct SweepState;      // sweep.hip: the sweep state machine's host-side bookkeeping
+
+struct vilma_ctx {
+    int P = 0, M = 0, A = 0, device = 0;
+    SweepState *sw = nullptr;
+    int64_t N = 0;
+    std::string err;
+
+    double *adj = nullptr, *se = nullptr, *sld = nullptr, *scal = nullptr;
+    int32_t *annot = nullptr, *invperm = nullptr;
+    double *prec = nullptr, *log_det = nullptr, *lh = nullptr, *counts = nullptr;
+    std::vector<double> log_det_host;
+    double tau[VILMA_MAX_P];
+
+    // Three buffers of each kind, in the roles current / candidate A / candidate B: a beta trial
+    // may evaluate two step sizes at once (vilma_trial_beta2); plain evaluations and one-step
+    // trials use the A role.  Accepting swaps roles, never copies.
+    double *mu[3] = {nullptr, nullptr, nullptr};
+    int mu_cur = 0, mu_ta = 1, mu_tb = 2;
+    double *pool[3] = {nullptr, nullptr, nullptr};
+    double *m[3] = {nullptr, nullptr, nullptr}, *v[3] = {nullptr, nullptr, nullptr},
+           *lse[3] = {nullptr, nullptr, nullptr};
+    int mom_cur = 0, mom_ta = 1, mom_tb = 2;
+    bool have_b = false;            // candidate B holds the second step of the last trial
+    int64_t pool_elems = 0;
+    bool have_moments = false;
+    bool trial_tainted = false;     // trial moments come from vilma_eval_given_delta
+
+    double *snapshot = nullptr, *snp_partials = nullptr, *dot_partials = nullptr;
+    double *delta_partials = nullptr, *diff_partials = nullptr;
+    std::vector<int32_t> dot_start;     // first y.z partial slot of each cohort (+ end)
+
+    std::vector<CohortLd> ld;
+    ItemSet all;
+    std::vector<ItemSet> solo;      // per cohort (vilma_ld_matvec with cohort >= 0)
+    double *sym_scratch = nullptr;
+    int dot_stride = 0;             // second right-hand side's y.z partials / scratch sit this far
+    int64_t s_stride = 0;           // behind the first one's
+    double *pinned = nullptr;       // host staging for vilma_fetch
+    int64_t pinned_elems = 0;
+    bool ready = false;
+    // rows per work item of the symmetric product (multiple of 32); VILMA_LD_CHUNK_ROWS overrides
+    int chunk_rows = 512;
+    // U bytes per eigen-form group.  Default: ONE group (first pass over every block, then the
+    // second).  Running both passes group by group so that the second finds U in the 256 MB
+    // Infinity Cache was measured and LOSES: 1.16 ms per product ungrouped, 1.50 / 1.76 / 2.32 ms
+    // with 320 / 160 / 96 MB groups at C4 (profiles/r02g_ab_eigen.txt) -- ~10 us of launch ramp
+    // and tail per extra kernel, no measurable gain from the cache.  VILMA_EIGEN_GROUP_MB keeps
+    // the experiment reproducible.
+    int64_t eigen_group_bytes = INT64_MAX;
+    // eigen-form blocks go through the fused product (panel-major U, read once) unless
+    // VILMA_EIG_FUSED=0 or the block is too tall for the LDS of a CU
+    bool eig_fused = true;
+    // fewer fused work items than this: one launch for all block heights (VILMA_EIG_MERGE_BELOW)
+    int eig_merge_below = 8192;
+    double *repack_tmp = nullptr;   // row-major staging of one block's U before the panel repack
+    int64_t repack_elems = 0;
+
+    // Work that depends only on the per-SNP pass of an evaluation (responsibility sums of the
+    // trial state, convergence statistics) runs on `side`, concurrently with that evaluation's LD
+    // product on the caller's stream: gated on ev_snp, joined back through ev_side.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_snp = nullptr, ev_side = nullptr;
+    bool overlap = true, snp_marked = false;
+
+    // Decisions taken on the device (vilma_decide) and work queued ahead of them: two flag slots
+    // (stage s is predicated on one while it writes the other), two pinned landing buffers for
+    // asynchronous result copies, and a snapshot of the host-side buffer indices to undo a stage
+    // whose flag turned out 0.
+    int *flags = nullptr;           // device [2]
+    double *decide_obj = nullptr;   // device [2]: {orig, new} objective of the last decision
+    double *decide_state = nullptr; // device [3]: what one decision hands to the next (kernels.hip)
+    int pred_slot = -1;             // -1: launches are unconditional
+    double *landing[2] = {nullptr, nullptr};
+    int64_t landing_elems[2] = {0, 0};
+    hipEvent_t landed[2] = {nullptr, nullptr};
+    // snapshots of the result vector taken by the decide kernel (+ the two flags), copied out on
+    // copy_stream so the caller's stream never waits for a device->host copy
+    double *snap[2] = {nullptr, nullptr};
+    int64_t snap_elems[2] = {0, 0}, snap_n[2] = {0, 0};
+    bool landing_flags_as_doubles[2] = {false, false};
+    hipEvent_t ev_decided[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    size_t prof_mark = 0;           // pending profiling brackets at the last vilma_spec_save
+    struct Saved { int mu[3], mom[3]; bool have_moments, snp_marked, have_b; } saved{{0, 1, 2}, {0, 1, 2}, false, false, false};
+
+    int prof = 0;                   // 0 off, k >= 1: bracket every k-th LD launch
+    int64_t prof_tick = 0;
+    bool prof_now = false;
+    struct Pending { hipEvent_t e0, e1; int kind; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[VILMA_PROF_KINDS] = {0, 0, 0};
+    int64_t prof_launches[VILMA_PROF_KINDS] = {0, 0, 0};
+};
+
+namespace vilma_detail {
+
+extern std::string g_create_error;
+inline int fail(vilma_ctx *c, const std::string &msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return 1;
+}
+
+#define HIPCHK(c, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail((c), std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <typename T>
+int dev_alloc(vilma_ctx *c, T **p, int64_t count, bool zero = true) {
+    if (count <= 0) count = 1;
+    HIPCHK(c, hipMalloc((void **)p, (size_t)count * sizeof(T)));
+    if (zero) HIPCHK(c, hipMemset(*p, 0, (size_t)count * sizeof(T)));
+    return 0;
+}
+
+inline void dev_free(void *p) { if (p) (void)hipFree(p); }
+
+// sweep.hip
+void sweep_destroy(vilma_ctx *c);
+
+}  // namespace vilma_detail

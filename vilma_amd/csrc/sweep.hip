@@ -1,0 +1,598 @@
+// The sweep state machine behind the C-ABI: vilma_sweep & co. of include/vilma_hip.h.
+//
+// Control flow of the reference's outer iteration -- _optimize_step / _nat_grad_step /
+// _update_beta / _update_hyper_delta / _update_error_scaling (reference
+// variational_inference.py:396-450, 762-802, 825-860, 472-486) -- on top of the evaluation entry
+// points of capi.hip.  Decisions are taken from the 3P+2 all-reduced sums per candidate point
+// exactly as the reference takes them from its objectives (same tests, same order), so every
+// rank walks the same accept / reject sequence and the L trajectory is the reference's.
+#include "ctx.h"
+
+#include <dlfcn.h>
+
+namespace {
+
+constexpr double L_MAX = 1e12;          // reference variational_inference.py:18-24
+constexpr double REL_TOL = 1e-6;
+constexpr double ABS_TOL = 1e-6;
+constexpr double EM_TOL = 10.0;
+constexpr double ELBO_MOMENTUM = 0.5;
+constexpr int MAX_NUM_ITERS = 20;
+constexpr double EPSILON = 1e-100;      // reference numerics.py:8
+
+// ---------------------------------------------------------------------------------------------
+// RCCL, bound at run time: the librccl already in the process (torch ships one) or the system's
+// ---------------------------------------------------------------------------------------------
+struct Id128 { char bytes[128]; };      // ncclUniqueId, passed by value
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+constexpr int NCCL_FLOAT64 = 8;         // ncclDataType_t ncclFloat64 / ncclDouble
+constexpr int NCCL_SUM = 0, NCCL_MAX = 2;   // ncclRedOp_t
+
+Rccl &rccl() {
+    static Rccl r;
+    return r;
+}
+
+bool rccl_load() {
+    Rccl &r = rccl();
+    if (r.handle) return true;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1",
+                           "/opt/rocm/lib/librccl.so"};
+    // the copy already mapped into the process first (two RCCL runtimes in one process would each
+    // keep their own device state)
+    for (const char *n : names)
+        if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!r.handle)
+        for (const char *n : names)
+            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!r.handle) {
+        r.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found");
+        return false;
+    }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) {
+        r.error = "librccl.so lacks the ncclCommInitRank / ncclAllReduce entry points";
+        r.handle = nullptr;
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+// host-side bookkeeping of the sweep loop for one context
+struct SweepState {
+    int P = 0, M = 0, A = 0, nt = 0, am = 0;
+    // result vector layout (doubles): see include/vilma_hip.h
+    int o_dsum = 0, o_tot = 0, o_ta = 0, o_tb = 0, o_sa = 0, o_sb = 0, o_dmax = 0, o_hyper = 0;
+    int size = 0, reduce_end = 0;
+    double *results = nullptr;              // device
+    std::vector<double> host;               // last download of the result vector
+
+    std::vector<double> chi, ranks;
+    bool have_consts = false, scale_se = false;
+
+    // collective
+    int comm_kind = 0, world = 1, rank = 0; // 0 none, 1 RCCL, 2 callback
+    void *nccl_comm = nullptr;
+    vilma_allreduce_fn cb = nullptr;
+    void *cb_user = nullptr;
+
+    // the current (accepted) state as the host knows it
+    bool have_state = false;
+    std::vector<double> hyper, totals;
+    double objective = 0.0;
+    bool cur_sums = false;                  // results[o_sa..] = all-reduced sums of the current state
+    // the last beta trial's candidates
+    bool trial_sums = false;                // ... of candidate A of the last trial
+    int candidate = 1;                      // which candidate the objective just looked at belongs to
+    bool alt_valid = false;                 // candidate B evaluated, not looked at yet
+    double alt_step = 0.0, alt_obj = 0.0;
+    std::vector<double> alt_totals;
+    bool two_step = true;                   // VILMA_TWO_STEP / default P <= 2
+    double L_rejected = -1.0;
+
+    // per-call
+    int flags = 0;
+    vilma_sweep_stats *stats = nullptr;
+    bool have_diff = false;
+    double lsr = 2.0;
+};
+
+void vilma_detail::sweep_destroy(vilma_ctx *c) {
+    SweepState *s = c->sw;
+    if (!s) return;
+    if (s->nccl_comm && rccl().CommDestroy) (void)rccl().CommDestroy(s->nccl_comm);
+    dev_free(s->results);
+    delete s;
+    c->sw = nullptr;
+}
+
+namespace {
+
+SweepState *sweep_state(vilma_ctx *c) {
+    if (c->sw) return c->sw;
+    SweepState *s = new SweepState();
+    s->P = c->P; s->M = c->M; s->A = c->A;
+    s->nt = VILMA_NTOTALS(c->P);
+    s->am = c->A * c->M;
+    s->o_dsum = 0;
+    s->o_tot = 3;
+    s->o_ta = s->o_tot + s->nt;
+    s->o_tb = s->o_ta + s->nt;
+    s->o_sa = s->o_tb + s->nt;
+    s->o_sb = s->o_sa + s->am;
+    s->reduce_end = s->o_sb + s->am;
+    s->o_dmax = s->reduce_end;
+    s->o_hyper = s->o_dmax + 3;
+    s->size = s->o_hyper + s->am;
+    if (hipMalloc((void **)&s->results, (size_t)s->size * sizeof(double)) != hipSuccess ||
+        hipMemset(s->results, 0, (size_t)s->size * sizeof(double)) != hipSuccess) {
+        delete s;
+        return nullptr;
+    }
+    s->host.assign(s->size, 0.0);
+    s->totals.assign(s->nt, 0.0);
+    s->alt_totals.assign(s->nt, 0.0);
+    const char *two = std::getenv("VILMA_TWO_STEP");
+    // Two steps per beta trial pay where the LD product dominates a trial (P <= 2); at P = 4 the
+    // second candidate's per-SNP work outweighs the saved products (profiles/r02h_ab_twostep.txt)
+    s->two_step = (two && (two[0] == '0' || two[0] == '1')) ? two[0] == '1' : c->P <= 2;
+    c->sw = s;
+    return s;
+}
+
+#define SW(c)                                                          \
+    SweepState *s = sweep_state(c);                                    \
+    if (!s) return fail((c), "cannot allocate the result vector")
+
+int comm_allreduce(vilma_ctx *c, SweepState *s, hipStream_t st, double *buf, int64_t n, int op) {
+    if (n <= 0) return 0;
+    if (s->comm_kind == 1) {
+        const int rc = rccl().AllReduce(buf, buf, (size_t)n, NCCL_FLOAT64, op ? NCCL_MAX : NCCL_SUM,
+                                        s->nccl_comm, st);
+        if (rc != 0) return fail(c, std::string("ncclAllReduce: ") + rccl().GetErrorString(rc));
+    } else if (s->comm_kind == 2) {
+        if (s->cb(s->cb_user, (void *)st, buf, n, op))
+            return fail(c, "the all-reduce callback failed");
+    }
+    return 0;
+}
+
+// fast_likelihood (numerics.py:31-46) minus _beta_KL (variational_inference.py:873-885) from the
+// all-reduced sums, in the operation order the device decision uses (no fused multiply-add)
+double objective_from(const vilma_ctx *c, const SweepState *s, const double *t) {
+#pragma clang fp contract(off)
+    const int P = s->P;
+    double lik = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const double inner = ((-0.5 * (t[P + p] + t[2 * P + p]) + t[p]) - 0.5 * s->chi[p]) / c->tau[p];
+        lik = lik + (inner - 0.5 * s->ranks[p] * std::log(c->tau[p]));
+    }
+    return lik - (t[3 * P] + t[3 * P + 1]);
+}
+
+bool is_close(double a, double b) {     // numpy.isclose defaults (rtol 1e-5, atol 1e-8)
+    return std::fabs(a - b) <= 1e-8 + 1e-5 * std::fabs(b);
+}
+
+void event(SweepState *s, int kind, int paramset, double a, double b) {
+    vilma_sweep_stats *st = s->stats;
+    if (!st || !(s->flags & VILMA_SWEEP_VERBOSE) || st->n_events >= VILMA_SWEEP_EVENTS) return;
+    st->events[st->n_events].kind = kind;
+    st->events[st->n_events].paramset = paramset;
+    st->events[st->n_events].a = a;
+    st->events[st->n_events].b = b;
+    st->n_events += 1;
+}
+
+// all-reduce [lo, hi) of the result vector and download the whole vector
+int reduce_and_fetch(vilma_ctx *c, SweepState *s, hipStream_t st, int lo, int hi, bool with_max) {
+    if (s->comm_kind) {
+        if (comm_allreduce(c, s, st, s->results + lo, hi - lo, 0)) return 1;
+        if (with_max && comm_allreduce(c, s, st, s->results + s->o_dmax, 3, 1)) return 1;
+    }
+    return vilma_fetch(c, (void *)st, s->results, s->host.data(), s->size);
+}
+
+// Objective of the CURRENT vi_mu under the current hyper / tau; the evaluated point stays on the
+// device as the trial state (vilma_accept(ctx, 0) makes it current).
+int evaluate_current(vilma_ctx *c, SweepState *s, hipStream_t st, double *obj) {
+    if (vilma_eval(c, (void *)st, s->results + s->o_tot)) return 1;
+    if (reduce_and_fetch(c, s, st, s->o_tot, s->o_tot + s->nt, false)) return 1;
+    s->trial_sums = false;
+    s->alt_valid = false;
+    if (s->stats) { s->stats->n_evaluations += 1; s->stats->n_products += 1; }
+    *obj = objective_from(c, s, s->host.data() + s->o_tot);
+    return 0;
+}
+
+int accept(vilma_ctx *c, SweepState *s, int take, double obj, const double *totals) {
+    s->alt_valid = false;
+    if (vilma_accept(c, take)) return 1;
+    s->objective = obj;
+    std::copy(totals, totals + s->nt, s->totals.begin());
+    // responsibility sums fetched with candidate A now describe the current state
+    s->cur_sums = s->trial_sums && take == 1;
+    s->trial_sums = false;
+    s->have_state = true;
+    return 0;
+}
+
+// Objective of the candidate at `step`: the second candidate of the pair evaluated last if that is
+// this step, else a new trial (with the step the search would try next riding along).
+int trial(vilma_ctx *c, SweepState *s, hipStream_t st, double step, double next_step, double *obj,
+          const double **totals) {
+    if (s->alt_valid && s->alt_step == step) {
+        s->alt_valid = false;
+        s->candidate = 2;
+        s->trial_sums = false;          // the sums ride with candidate A only
+        if (s->stats) { s->stats->n_evaluations += 1; s->stats->n_trials += 1; }
+        *obj = s->alt_obj;
+        *totals = s->alt_totals.data();
+        return 0;
+    }
+    s->alt_valid = false;
+    s->cur_sums = false;                // the trial's sums overwrite the device copy
+    const bool two = s->two_step;
+    if (two) {
+        if (vilma_trial_beta2(c, (void *)st, step, next_step, s->results + s->o_ta, s->results + s->o_tb))
+            return 1;
+    } else if (vilma_trial_beta(c, (void *)st, step, s->results + s->o_ta)) {
+        return 1;
+    }
+    if (vilma_delta_sums(c, (void *)st, s->results + s->o_sa, VILMA_STATE_TRIAL_BETA)) return 1;
+    if (reduce_and_fetch(c, s, st, s->o_ta, s->o_sa + s->am, false)) return 1;
+    s->candidate = 1;
+    s->trial_sums = true;
+    if (two) {
+        s->alt_valid = true;
+        s->alt_step = next_step;
+        std::copy(s->host.begin() + s->o_tb, s->host.begin() + s->o_tb + s->nt, s->alt_totals.begin());
+        s->alt_obj = objective_from(c, s, s->alt_totals.data());
+    }
+    if (s->stats) { s->stats->n_evaluations += 1; s->stats->n_trials += 1; s->stats->n_products += 1; }
+    *obj = objective_from(c, s, s->host.data() + s->o_ta);
+    *totals = s->host.data() + s->o_ta;
+    return 0;
+}
+
+// One damped natural-gradient step with backtracking (variational_inference.py:762-802).
+int update_beta(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, double orig, double *new_obj) {
+    for (;;) {
+        double obj;
+        const double *totals;
+        if (trial(c, s, st, 1.0 / L[0], 1.0 / (L[0] * s->lsr), &obj, &totals)) return 1;
+        event(s, 1, 0, orig, obj);
+        const bool accepted = obj >= orig - REL_TOL * std::fabs(orig) - ABS_TOL;
+        if (accepted) {
+            if (L[0] > L_MAX && !is_close(orig, obj)) return fail(c, "Encountered a numerical error.");
+            // `totals` may point into s->host, which accept() does not touch
+            if (accept(c, s, s->candidate, obj, totals)) return 1;
+            *new_obj = obj;
+            return 0;
+        }
+        if (L[0] > L_MAX) {
+            if (!is_close(orig, obj)) return fail(c, "Encountered a numerical error.");
+            *new_obj = orig;
+            return 0;
+        }
+        s->L_rejected = L[0];
+        L[0] *= s->lsr;
+    }
+}
+
+// Closed-form M-step for the mixture weights (variational_inference.py:825-860): responsibility
+// sums (already all-reduced when they came with the accepted beta trial) -> hyper_delta and its
+// table on the device -> re-evaluation.  Unconditional in the reference, so accepted at once.
+int update_hyper(vilma_ctx *c, SweepState *s, hipStream_t st, bool with_diff, double *new_obj) {
+    if (!s->cur_sums) {
+        // no accepted beta step since the last evaluation (or candidate B was taken): the statistic
+        // of the current state is computed now
+        if (vilma_delta_sums(c, (void *)st, s->results + s->o_sa, VILMA_STATE_CURRENT)) return 1;
+        if (s->comm_kind && comm_allreduce(c, s, st, s->results + s->o_sa, s->am, 0)) return 1;
+    }
+    if (vilma_mstep(c, (void *)st, s->results + s->o_sa, s->results + s->o_hyper)) return 1;
+    if (with_diff) {
+        if (vilma_eval_diff(c, (void *)st, s->results + s->o_tot, s->results + s->o_dsum,
+                            s->results + s->o_dmax)) return 1;
+    } else if (vilma_eval(c, (void *)st, s->results + s->o_tot)) {
+        return 1;
+    }
+    if (vilma_accept(c, 0)) return 1;
+    const int lo = with_diff ? s->o_dsum : s->o_tot;
+    if (reduce_and_fetch(c, s, st, lo, s->o_tot + s->nt, with_diff && (s->flags & VILMA_SWEEP_VERBOSE)))
+        return 1;
+    std::copy(s->host.begin() + s->o_tot, s->host.begin() + s->o_tot + s->nt, s->totals.begin());
+    s->hyper.assign(s->host.begin() + s->o_hyper, s->host.begin() + s->o_hyper + s->am);
+    if (with_diff && s->stats) {
+        for (int q = 0; q < 3; ++q) {
+            s->stats->diff_sum[q] = s->host[s->o_dsum + q];
+            s->stats->diff_max[q] = s->host[s->o_dmax + q];
+        }
+        s->have_diff = true;
+    }
+    const double orig = s->objective;
+    s->objective = objective_from(c, s, s->totals.data());
+    s->cur_sums = s->trial_sums = false;
+    s->alt_valid = false;
+    if (s->stats) { s->stats->n_evaluations += 1; s->stats->n_products += 1; }
+    event(s, 1, 1, orig, s->objective);
+    *new_obj = s->objective;
+    return 0;
+}
+
+// EM update of the SE scaling (variational_inference.py:472-486, 735-738) from the sums of the
+// current state; the sigma-dependent constants follow tau inside the kernels.
+int update_error_scaling(vilma_ctx *c, SweepState *s, hipStream_t st, double *new_obj) {
+    const int P = s->P;
+    double tau[VILMA_MAX_P];
+    const double *t = s->totals.data();
+    for (int p = 0; p < P; ++p)
+        tau[p] = (((s->chi[p] - 2 * t[p]) + t[2 * P + p]) + t[P + p]) / s->ranks[p];
+    if (vilma_set_tau(c, tau)) return 1;
+    double obj;
+    if (evaluate_current(c, s, st, &obj)) return 1;
+    std::vector<double> tot(s->host.begin() + s->o_tot, s->host.begin() + s->o_tot + s->nt);
+    if (accept(c, s, 0, obj, tot.data())) return 1;
+    *new_obj = obj;
+    return 0;
+}
+
+// variational_inference.py:419-450 with the redundant re-evaluations removed: the objective of the
+// state a parameter-set update starts from is the one computed when that state was accepted.
+int nat_grad_step(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, double running,
+                  double *delta_sum_out) {
+    const double conv_tol = std::isnan(running) ? HUGE_VAL : 0.1 * running;
+    double delta_sum = 0.0;
+    // ---- paramset 0: variational family of beta
+    double orig = s->objective;
+    for (int it = 0; it < MAX_NUM_ITERS; ++it) {
+        L[0] = std::max(1.0, L[0] / 1.25);
+        event(s, 0, 0, L[0], 0.0);
+        double nw;
+        if (update_beta(c, s, st, L, orig, &nw)) return 1;
+        delta_sum += nw - orig;
+        // == np.isclose(new - orig, 0, atol=conv_tol, rtol=0) for finite objectives
+        if (std::fabs(nw - orig) <= conv_tol || L[0] == 1.0 || L[0] > L_MAX) break;
+        orig = nw;
+    }
+    // ---- paramset 1: mixture weights (L[1] stays 1: exactly one pass)
+    L[1] = std::max(1.0, L[1] / 1.25);
+    event(s, 0, 1, L[1], 0.0);
+    // without --learn-scaling this is the sweep's last evaluation: the convergence statistics
+    // ride in its per-SNP pass
+    const bool last = !s->scale_se;
+    orig = s->objective;
+    double nw;
+    if (update_hyper(c, s, st, (s->flags & VILMA_SWEEP_DIFF) && last, &nw)) return 1;
+    delta_sum += nw - orig;
+    // ---- paramset 2: annotations -- nothing to do in this scheme (:862-866)
+    L[2] = std::max(1.0, L[2] / 1.25);
+    event(s, 0, 2, L[2], 0.0);
+    if (s->scale_se && delta_sum < EM_TOL) {
+        orig = s->objective;
+        if (update_error_scaling(c, s, st, &nw)) return 1;
+        delta_sum += nw - orig;
+        event(s, 2, 0, orig, nw);
+    }
+    *delta_sum_out = delta_sum;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t vilma_results_size(const vilma_ctx *c) {
+    if (!c) return 0;
+    SweepState *s = sweep_state(const_cast<vilma_ctx *>(c));
+    return s ? s->size : 0;
+}
+
+double *vilma_results_dev(vilma_ctx *c) {
+    if (!c) return nullptr;
+    SweepState *s = sweep_state(c);
+    return s ? s->results : nullptr;
+}
+
+int vilma_set_fit_constants(vilma_ctx *c, const double *chi, const double *ranks, int scale_se) {
+    if (!c) return 1;
+    SW(c);
+    s->chi.assign(chi, chi + c->P);
+    s->ranks.assign(ranks, ranks + c->P);
+    s->scale_se = scale_se != 0;
+    s->have_consts = true;
+    s->have_state = false;
+    return 0;
+}
+
+int vilma_comm_unique_id(char id[128]) {
+    if (!rccl_load()) return 1;
+    Id128 u;
+    std::memset(&u, 0, sizeof(u));
+    if (rccl().GetUniqueId(&u) != 0) return 1;
+    std::memcpy(id, u.bytes, 128);
+    return 0;
+}
+
+int vilma_comm_init_rccl(vilma_ctx *c, int world, int rank, const char id[128]) {
+    if (!c) return 1;
+    SW(c);
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, "bad world size / rank");
+    if (!rccl_load()) return fail(c, rccl().error);
+    if (s->nccl_comm) { (void)rccl().CommDestroy(s->nccl_comm); s->nccl_comm = nullptr; }
+    Id128 u;
+    std::memcpy(u.bytes, id, 128);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = rccl().CommInitRank(&s->nccl_comm, world, u, rank);
+    if (rc != 0) return fail(c, std::string("ncclCommInitRank: ") + rccl().GetErrorString(rc));
+    s->comm_kind = 1; s->world = world; s->rank = rank;
+    return 0;
+}
+
+int vilma_comm_set_callback(vilma_ctx *c, vilma_allreduce_fn fn, void *user, int world, int rank) {
+    if (!c) return 1;
+    SW(c);
+    if (s->nccl_comm) { (void)rccl().CommDestroy(s->nccl_comm); s->nccl_comm = nullptr; }
+    s->cb = fn; s->cb_user = user;
+    s->comm_kind = fn ? 2 : 0;
+    s->world = fn ? world : 1;
+    s->rank = fn ? rank : 0;
+    return 0;
+}
+
+int vilma_comm_info(const vilma_ctx *c, int *kind, int *world, int *rank) {
+    if (!c) return 1;
+    const SweepState *s = c->sw;
+    if (kind) *kind = s ? s->comm_kind : 0;
+    if (world) *world = s ? s->world : 1;
+    if (rank) *rank = s ? s->rank : 0;
+    return 0;
+}
+
+int vilma_comm_allreduce(vilma_ctx *c, void *stream, double *buf, int64_t n, int op) {
+    if (!c) return 1;
+    SW(c);
+    return comm_allreduce(c, s, (hipStream_t)stream, buf, n, op);
+}
+
+int vilma_set_state(vilma_ctx *c, void *stream, const double *vi_mu, const double *hyper,
+                    const double *tau, double *objective) {
+    if (!c) return 1;
+    SW(c);
+    if (!s->have_consts) return fail(c, "vilma_set_fit_constants has not been called");
+    if (!hyper) return fail(c, "hyper_delta is required");
+    hipStream_t st = (hipStream_t)stream;
+    if (vilma_sweep_drain(c)) return 1;
+    if (tau && vilma_set_tau(c, tau)) return 1;
+    if (vilma_set_hyper(c, hyper)) return 1;
+    s->hyper.assign(hyper, hyper + s->am);
+    if (vi_mu && vilma_set_mu(c, vi_mu)) return 1;
+    s->stats = nullptr;
+    double obj;
+    if (evaluate_current(c, s, st, &obj)) return 1;
+    std::vector<double> tot(s->host.begin() + s->o_tot, s->host.begin() + s->o_tot + s->nt);
+    if (accept(c, s, 0, obj, tot.data())) return 1;
+    s->cur_sums = false;
+    s->L_rejected = -1.0;
+    if (objective) *objective = obj;
+    return 0;
+}
+
+int vilma_get_state(vilma_ctx *c, double *vi_mu, double *vi_delta, double *hyper, double *tau) {
+    if (!c) return 1;
+    SW(c);
+    if (vilma_sweep_drain(c)) return 1;
+    if (vi_mu && vilma_get_mu(c, vi_mu)) return 1;
+    if (vi_delta && vilma_get_delta(c, vi_delta)) return 1;
+    if (hyper) {
+        if (s->hyper.empty()) return fail(c, "hyper_delta has not been set");
+        std::copy(s->hyper.begin(), s->hyper.end(), hyper);
+    }
+    if (tau) std::copy(c->tau, c->tau + c->P, tau);
+    return 0;
+}
+
+int vilma_initialize(vilma_ctx *c, void *stream, const double *fake_mu, double *objective) {
+    if (!c) return 1;
+    SW(c);
+    if (!s->have_consts) return fail(c, "vilma_set_fit_constants has not been called");
+    hipStream_t st = (hipStream_t)stream;
+    if (vilma_sweep_drain(c)) return 1;
+    if (vilma_init_state(c, stream, fake_mu, s->results + s->o_sa)) return 1;
+    if (s->comm_kind && comm_allreduce(c, s, st, s->results + s->o_sa, s->am, 0)) return 1;
+    std::vector<double> sums(s->am);
+    if (vilma_fetch(c, stream, s->results + s->o_sa, sums.data(), s->am)) return 1;
+    // hyper_delta of _initialize (variational_inference.py:667-674)
+    std::vector<double> hyper(s->am);
+    for (int a = 0; a < s->A; ++a) {
+        double tot = 0.0;
+        for (int k = 0; k < s->M; ++k) tot += sums[(size_t)a * s->M + k] + 1.0;
+        for (int k = 0; k < s->M; ++k)
+            hyper[(size_t)a * s->M + k] = std::max((sums[(size_t)a * s->M + k] + 1.0) / tot, EPSILON);
+    }
+    return vilma_set_state(c, stream, nullptr, hyper.data(), nullptr, objective);
+}
+
+int vilma_elbo(vilma_ctx *c, double *objective) {
+    if (!c) return 1;
+    SW(c);
+    if (!s->have_state) return fail(c, "no state: call vilma_set_state or vilma_initialize");
+    if (objective) *objective = s->objective;
+    return 0;
+}
+
+int vilma_posterior(vilma_ctx *c, double *mean, double *var) {
+    if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;
+    if (vilma_get_moments(c, mean, var)) return 1;
+    const size_t PN = (size_t)c->P * c->N;
+    std::vector<double> scal(PN);
+    HIPCHK(c, hipMemcpy(scal.data(), c->scal, PN * sizeof(double), hipMemcpyDeviceToHost));
+    if (mean) for (size_t t = 0; t < PN; ++t) mean[t] *= scal[t];
+    if (var) for (size_t t = 0; t < PN; ++t) var[t] *= scal[t] * scal[t];
+    return 0;
+}
+
+int vilma_sweep_drain(vilma_ctx *c) {
+    if (!c) return 1;
+    return 0;
+}
+
+int vilma_sweep(vilma_ctx *c, void *stream, double L[5], double *elbo, double *running_delta,
+                double line_search_rate, int flags, vilma_sweep_stats *stats) {
+    if (!c) return 1;
+    SW(c);
+    if (!s->have_state) return fail(c, "no state: call vilma_set_state or vilma_initialize");
+    if (!L || !elbo || !running_delta) return fail(c, "vilma_sweep: L, elbo and running_delta are required");
+    if (!(line_search_rate > 1.0)) return fail(c, "line_search_rate must exceed 1");
+    hipStream_t st = (hipStream_t)stream;
+    vilma_sweep_stats local;
+    vilma_sweep_stats *out = stats ? stats : &local;
+    std::memset(out, 0, sizeof(*out));
+    s->stats = out;
+    s->flags = flags;
+    s->lsr = line_search_rate;
+    s->have_diff = false;
+    event(s, 3, 0, *elbo, 0.0);
+    double change = 0.0;
+    const int rc = nat_grad_step(c, s, st, L, *running_delta, &change);
+    s->stats = nullptr;
+    if (rc) return 1;
+    // variational_inference.py:403-409
+    double running = std::isnan(*running_delta) ? change : *running_delta;
+    running *= ELBO_MOMENTUM;
+    running += (1 - ELBO_MOMENTUM) * std::max(change, 0.0);
+    *elbo = *elbo + change;
+    *running_delta = running;
+    if ((flags & VILMA_SWEEP_DIFF) && !s->have_diff) {
+        // the sweep's last evaluation was not the M-step's (error-scaling update): a separate pass
+        if (vilma_mean_diff(c, stream, s->results + s->o_dsum, s->results + s->o_dmax)) return 1;
+        if (reduce_and_fetch(c, s, st, s->o_dsum, s->o_dsum + 3, (flags & VILMA_SWEEP_VERBOSE) != 0))
+            return 1;
+        for (int q = 0; q < 3; ++q) {
+            out->diff_sum[q] = s->host[s->o_dsum + q];
+            out->diff_max[q] = s->host[s->o_dmax + q];
+        }
+    }
+    out->elbo = *elbo;
+    out->running = running;
+    for (int q = 0; q < 5; ++q) out->L[q] = L[q];
+    for (int p = 0; p < c->P; ++p) out->error_scaling[p] = c->tau[p];
+    return 0;
+}
+
+}  // extern "C"

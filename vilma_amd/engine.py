@@ -28,10 +28,19 @@ class ResultLayout:
         self.totals = slice(3, 3 + nt)                 # sums of a plain evaluation (vilma_eval)
         self.ttotals = slice(3 + nt, 3 + 2 * nt)       # sums of a beta trial (candidate A)
         self.ttotals_b = slice(3 + 2 * nt, 3 + 3 * nt)  # ... of the second step of a two-step trial
-        self.sums = slice(3 + 3 * nt, 3 + 3 * nt + am)  # responsibility sums
-        self.dmax = slice(3 + 3 * nt + am, 6 + 3 * nt + am)
-        self.hyper = slice(6 + 3 * nt + am, 6 + 3 * nt + 2 * am)
-        self.size = 6 + 3 * nt + 2 * am
+        self.sums = slice(3 + 3 * nt, 3 + 3 * nt + am)  # responsibility sums (of candidate A)
+        self.sums_b = slice(3 + 3 * nt + am, 3 + 3 * nt + 2 * am)   # ... of candidate B
+        self.dmax = slice(3 + 3 * nt + 2 * am, 6 + 3 * nt + 2 * am)
+        self.hyper = slice(6 + 3 * nt + 2 * am, 6 + 3 * nt + 3 * am)
+        self.size = 6 + 3 * nt + 3 * am
+
+
+class _DeviceVector:
+    """A device buffer owned by the library, presented to torch without a copy."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f8',
+                                         'data': (int(ptr), False), 'version': 2}
 
 
 class HipEngine:
@@ -53,13 +62,17 @@ class HipEngine:
             raise _lib.VilmaHipError(self.lib.vilma_last_error(None).decode())
         self.ctx = ctx
         self.refresh_stream()
-        # One device tensor for every small result, so a decision needs a single D2H copy and the
-        # parts that are summed over ranks are contiguous:
+        # One device vector for every small result (owned by the context, include/vilma_hip.h), so
+        # a decision needs a single D2H copy and the parts summed over ranks are contiguous:
         #   [diff sums (3) | eval totals (3P+2) | trial totals A (3P+2) | trial totals B (3P+2) |
-        #    delta sums (A*M) | diff maxima (3) | hyper (A*M)]
+        #    delta sums A (A*M) | delta sums B (A*M) | diff maxima (3) | hyper (A*M)]
         nt, am = _lib.ntotals(self.P), self.A * self.M
         self.layout = ResultLayout(nt, am)
-        self.results = torch.zeros(self.layout.size, dtype=torch.float64, device=self.device)
+        if self.lib.vilma_results_size(self.ctx) != self.layout.size:
+            raise _lib.VilmaHipError('result vector layouts of the library and the binding differ')
+        self._results_ptr = self.lib.vilma_results_dev(self.ctx)
+        self.results = torch.as_tensor(_DeviceVector(self._results_ptr, self.layout.size),
+                                       device=self.device)
         L = self.layout
         self._dsum = self.results[L.dsum]
         self._totals = self.results[L.totals]
@@ -77,6 +90,8 @@ class HipEngine:
         self.n_totals = nt
         self._host = np.zeros(L.size)
         self._host_ptr = _ptr(self._host)
+        self._comm_cb = None        # keeps the ctypes callback of bind_comm alive
+        self.collective = 'none'
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -349,6 +364,110 @@ class HipEngine:
 
     def snapshot_mean(self):
         self._check(self.lib.vilma_snapshot_mean(self.ctx, self._stream()))
+
+    # ------------------------------------------------------------------ the sweep behind one call
+    def set_fit_constants(self, chi_stat, ld_ranks, scale_se):
+        chi, ranks = _f64(chi_stat), _f64(ld_ranks)
+        assert chi.shape == (self.P,) and ranks.shape == (self.P,)
+        self._check(self.lib.vilma_set_fit_constants(self.ctx, _ptr(chi), _ptr(ranks),
+                                                     1 if scale_se else 0))
+
+    def bind_comm(self, comm):
+        """Give the context the collective its sweeps all-reduce with.  backend nccl: a
+        communicator the context owns (ncclCommInitRank; the unique id travels through
+        torch.distributed); anything else (gloo rehearsals): a callback into comm."""
+        if comm is None or not comm.active:
+            self._check(self.lib.vilma_comm_set_callback(
+                self.ctx, _lib.ALLREDUCE_FN(), None, 1, 0))
+            self.collective = 'none'
+            return
+        if comm.backend == 'nccl' and not comm.force_callback:
+            ident = C.create_string_buffer(128)
+            if comm.rank == 0 and self.lib.vilma_comm_unique_id(ident):
+                raise _lib.VilmaHipError('ncclGetUniqueId failed (is librccl.so loadable?)')
+            raw = comm.broadcast_bytes(ident.raw)
+            self._check(self.lib.vilma_comm_init_rccl(self.ctx, comm.world, comm.rank,
+                                                      C.create_string_buffer(raw, 128)))
+            self.collective = 'rccl (communicator owned by the context)'
+            return
+        base, results = int(self._results_ptr), self.results
+
+        def allreduce(_user, _stream, buf, n, op):
+            try:
+                off = (int(buf) - base) // 8
+                if off < 0 or off + n > results.numel():
+                    return 1
+                comm.allreduce_inplace(results[off:off + n], op='max' if op else 'sum')
+                return 0
+            except Exception:       # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._comm_cb = _lib.ALLREDUCE_FN(allreduce)
+        self._check(self.lib.vilma_comm_set_callback(self.ctx, self._comm_cb, None, comm.world,
+                                                     comm.rank))
+        self.collective = 'callback into torch.distributed (%s)' % comm.backend
+
+    def set_state(self, vi_mu, hyper, tau=None):
+        """Make (vi_mu [M,P,N] or None = keep the device's, hyper_delta, error_scaling) the
+        current state and evaluate it; returns its ELBO."""
+        hyper = _f64(hyper).reshape(self.A, self.M)
+        mu = None
+        if vi_mu is not None:
+            mu = _f64(vi_mu)
+            assert mu.shape == (self.M, self.P, self.N)
+        tau = None if tau is None else _f64(tau)
+        obj = C.c_double()
+        self._check(self.lib.vilma_set_state(self.ctx, self._stream_handle,
+                                             None if mu is None else _ptr(mu), _ptr(hyper),
+                                             None if tau is None else _ptr(tau), C.byref(obj)))
+        return obj.value
+
+    def initialize(self, fake_mu):
+        """_initialize from the jittered ridge start [P,N] on the device; returns the ELBO of the
+        starting point (hyper_delta: get_hyper())."""
+        fake_mu = _f64(fake_mu)
+        assert fake_mu.shape == (self.P, self.N)
+        obj = C.c_double()
+        self._check(self.lib.vilma_initialize(self.ctx, self._stream_handle, _ptr(fake_mu),
+                                              C.byref(obj)))
+        return obj.value
+
+    def get_hyper(self):
+        out = np.empty((self.A, self.M))
+        self._check(self.lib.vilma_get_state(self.ctx, None, None, _ptr(out), None))
+        return out
+
+    def get_tau(self):
+        out = np.empty(self.P)
+        self._check(self.lib.vilma_get_state(self.ctx, None, None, None, _ptr(out)))
+        return out
+
+    def elbo(self):
+        obj = C.c_double()
+        self._check(self.lib.vilma_elbo(self.ctx, C.byref(obj)))
+        return obj.value
+
+    def posterior(self):
+        mean, var = np.empty((self.P, self.N)), np.empty((self.P, self.N))
+        self._check(self.lib.vilma_posterior(self.ctx, _ptr(mean), _ptr(var)))
+        return mean, var
+
+    def sweep(self, L, elbo, running, line_search_rate=2., flags=0):
+        """One outer iteration inside the library (vilma_sweep).  L: float64[5], updated in
+        place; running None = first sweep.  Returns (elbo, running, stats)."""
+        assert L.dtype == np.float64 and L.shape == (5,) and L.flags.c_contiguous
+        e = C.c_double(float(elbo))
+        r = C.c_double(float('nan') if running is None else float(running))
+        stats = _lib.SweepStats()
+        self._check(self.lib.vilma_sweep(self.ctx, self._stream_handle, _ptr(L), C.byref(e),
+                                         C.byref(r), float(line_search_rate), int(flags),
+                                         C.byref(stats)))
+        return e.value, r.value, stats
+
+    def drain(self):
+        self._check(self.lib.vilma_sweep_drain(self.ctx))
 
     # ------------------------------------------------------------------ measurement
     def prof_enable(self, on=True, every=1):

@@ -44,6 +44,11 @@ class Comm:
         self.rank, self.world = 0, 1
         self._dist = None
         self._force = force
+        self.backend = None
+        # VILMA_COLLECTIVE=torch: the sweep's all-reduces go through torch.distributed (a callback
+        # from the library) instead of the communicator the context owns -- A/B and fallback
+        import os
+        self.force_callback = os.environ.get('VILMA_COLLECTIVE') == 'torch'
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -60,6 +65,15 @@ class Comm:
         """True when collectives actually run: more than one rank, or `force` (a one-rank group
         used to rehearse the RCCL stream ordering on a single GPU)."""
         return self._dist is not None and (self.world > 1 or self._force)
+
+    def broadcast_bytes(self, raw, src=0):
+        """Rank `src`'s byte string on every rank (the RCCL unique id of a context-owned
+        communicator travels this way)."""
+        if self._dist is None or self.world == 1:
+            return raw
+        box = [raw if self.rank == src else None]
+        self._dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
 
     def allreduce(self, tensor, op='sum'):
         """All-reduce a small float64 torch tensor (any device) and return it as numpy."""
