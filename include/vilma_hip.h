@@ -213,6 +213,16 @@ int vilma_accept(vilma_ctx *ctx, int take_mu);
 #define VILMA_STATE_TRIAL_BETA_B 3 /* candidate B of vilma_trial_beta2 */
 int vilma_delta_sums(vilma_ctx *ctx, void *stream, double *sums_dev, int which);
 
+/* The same statistic for the candidates of the LAST vilma_trial_beta(2) without reading their
+ * vi_mu again: the trial's per-SNP pass keeps every softmax term of a tile of 64 SNPs on chip
+ * until the tile's normaliser is known and leaves per-tile sums behind; this call only adds the
+ * tiles up (fixed order).  sums_b_dev (may be NULL) = candidate B's.  Fails -- use
+ * vilma_delta_sums -- when M is too large for the on-chip stash (LDS; M up to ~48 with two
+ * candidates, ~100 with one) or VILMA_TILE_SUMS=0. */
+int vilma_trial_sums(vilma_ctx *ctx, void *stream, double *sums_a_dev, double *sums_b_dev);
+/* 0, 1 or 2: how many candidates of the last trial vilma_trial_sums can serve. */
+int vilma_trial_sums_available(const vilma_ctx *ctx);
+
 /* The M-step of _update_hyper_delta on the device, without a host round trip: from the
  * (all-reduced) sums_dev [A*M] of vilma_delta_sums compute
  * hyper = normalise(max(sums / (annotation_counts + 1e-100), 1e-100)) (variational_inference.py:

@@ -72,6 +72,12 @@ def test_eval_trial_and_sums(name, form):
         new_delta = nm.fast_invert_nat_vi_delta(new_mu, nat_mu, const, vi.nat_grad_vi_delta)
         tot = eng.trial(step).cpu().numpy()
         _close(tot, oracle_totals(vi, (new_mu, new_delta, hyper)), rtol=1e-9, atol=1e-8)
+        # the M-step statistic of the candidate, two ways: the per-tile sums its own per-SNP pass
+        # left behind (no second pass over vi_mu) and delta_kernel
+        want_sums = nm.sum_annotations(new_delta, vi.annotations, vi.num_annotations)
+        if eng.trial_sums_available():
+            _close(eng.trial_sums().cpu().numpy().reshape(want_sums.shape), want_sums, rtol=1e-10)
+        _close(eng.delta_sums(1).cpu().numpy().reshape(want_sums.shape), want_sums, rtol=1e-10)
     eng.accept(True)
     _close(eng.get_mu(), new_mu, rtol=1e-9, atol=1e-16)
     _close(eng.get_delta(), new_delta, rtol=1e-8, atol=1e-300)
@@ -180,15 +186,23 @@ def test_two_step_trial_equals_two_trials(name, form):
     for step in (sa, sb):
         eng = fresh()
         tot = eng.trial(step).cpu().numpy().copy()
+        tile = eng.trial_sums().cpu().numpy().copy() if eng.trial_sums_available() else None
         sums = eng.delta_sums(1).cpu().numpy().copy()
         eng.accept(True)
-        single[step] = (tot, sums, eng.get_mu(), eng.get_moments(), eng.get_delta())
+        single[step] = (tot, sums, eng.get_mu(), eng.get_moments(), eng.get_delta(), tile)
         eng.close()
     for take in (1, 2):
         eng = fresh()
         ta, tb = eng.trial2(sa, sb)
         ta, tb = ta.cpu().numpy().copy(), tb.cpu().numpy().copy()
         assert np.array_equal(ta, single[sa][0]) and np.array_equal(tb, single[sb][0])
+        if eng.trial_sums_available() == 2:
+            # both candidates' responsibility sums out of the one pass: bit-identical to the
+            # one-step trial's, and the same numbers delta_kernel derives from the stored vi_mu
+            tile_a, tile_b = (t.cpu().numpy().copy() for t in eng.trial_sums(both=True))
+            assert np.array_equal(tile_a, single[sa][5]) and np.array_equal(tile_b, single[sb][5])
+            np.testing.assert_allclose(tile_a, single[sa][1], rtol=1e-12)
+            np.testing.assert_allclose(tile_b, single[sb][1], rtol=1e-12)
         sums = eng.delta_sums(1 if take == 1 else 3).cpu().numpy().copy()
         eng.accept(take)
         want = single[sa if take == 1 else sb]

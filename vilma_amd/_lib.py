@@ -101,6 +101,8 @@ def load():
         'vilma_trial_beta2': (C.c_int, [vp, vp, C.c_double, C.c_double, vp, vp]),
         'vilma_accept': (C.c_int, [vp, C.c_int]),
         'vilma_delta_sums': (C.c_int, [vp, vp, vp, C.c_int]),
+        'vilma_trial_sums': (C.c_int, [vp, vp, vp, vp]),
+        'vilma_trial_sums_available': (C.c_int, [vp]),
         'vilma_mean_diff': (C.c_int, [vp, vp, vp, vp]),
         'vilma_snapshot_mean': (C.c_int, [vp, vp]),
         'vilma_fetch': (C.c_int, [vp, vp, vp, vp, C.c_int64]),

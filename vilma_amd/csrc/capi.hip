@@ -332,6 +332,8 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
     a.pool_cur = c->pool[cur]; a.m_cur = c->m[cur];
     a.pool_out = c->pool[tr]; a.m_out = c->m[tr]; a.v_out = c->v[tr]; a.lse_out = c->lse[tr];
     a.partials = c->snp_partials;
+    a.lse_ref = c->have_moments ? c->lse[cur] : nullptr;
+    a.sum_partials = nullptr;
     a.scal = c->scal; a.snapshot = c->snapshot; a.diff = 0;
     a.step = step;
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
@@ -374,13 +376,18 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     fill_snp_args(c, a, step);
     a.step2 = step2;
     a.diff = (!blend && dsum_dev && dmax_dev) ? 1 : 0;
-    launch_snp_pass(a, blend, two ? 2 : 1, s);
+    // a beta trial also leaves the per-tile responsibility sums of its candidates (vilma_trial_sums)
+    const int ns = two ? 2 : 1;
+    const bool stash = blend && c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, ns);
+    if (stash) a.sum_partials = c->sum_partials;
+    c->tile_sums_ns = stash ? ns : 0;
+    launch_snp_pass(a, blend, ns, s);
     if (c->overlap && c->ev_snp) {
         (void)hipEventRecord(c->ev_snp, s);
         c->snp_marked = true;
     }
     run_ld(c, s, c->pool[c->mom_ta], two ? c->pool[c->mom_tb] : nullptr, -1);
-    const int grid = snp_pass_grid(c->N);
+    const int grid = snp_tile_grid(c->N);
     launch_finalize(c->snp_partials, grid, c->P, c->dot_partials, c->dot_start.data(),
                     totals_dev, a.diff ? dsum_dev : nullptr, a.diff ? dmax_dev : nullptr, s);
     if (two)        // candidate B: its partial columns sit behind A's and the statistics columns
@@ -431,7 +438,12 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         rc |= dev_alloc(c, &c->lse[s], N);
     }
     rc |= dev_alloc(c, &c->snapshot, PN);
-    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_pass_grid(N) * (2 * (2 * P + 2) + 6));
+    rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_tile_grid(N) * (2 * (2 * P + 2) + 6));
+    if (snp_pass_can_stash(M, P, 1)) {
+        const char *st = std::getenv("VILMA_TILE_SUMS");        // =0: always delta_kernel (A/B)
+        if (!(st && st[0] == '0'))
+            rc |= dev_alloc(c, &c->sum_partials, tile_sums_elems(N, A * M, 2));
+    }
     // per-wave rows plus the scratch rows of every pass of the column reduction (exact)
     rc |= dev_alloc(c, &c->delta_partials,
                     std::max(delta_partial_rows(N), init_partial_rows(N)) * A * M);
@@ -521,7 +533,7 @@ void vilma_destroy(vilma_ctx *c) {
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->side) (void)hipStreamDestroy(c->side);
     void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
-                    c->lh, c->counts, c->mu[0], c->mu[1], c->mu[2], c->m[0], c->m[1], c->m[2], c->v[0],
+                    c->lh, c->counts, c->sum_partials, c->mu[0], c->mu[1], c->mu[2], c->m[0], c->m[1], c->m[2], c->v[0],
                     c->v[1], c->v[2], c->lse[0], c->lse[1], c->lse[2], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials};
     for (void *p : ptrs) dev_free(p);
     delete c;
@@ -882,6 +894,32 @@ int vilma_delta_sums(vilma_ctx *c, void *stream, double *sums_dev, int which) {
     hipStream_t s = (hipStream_t)stream;
     hipStream_t q = which == VILMA_STATE_CURRENT ? s : side_begin(c, s);
     launch_delta_sums(a, sums_dev, q);
+    side_end(c, s, q);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int vilma_trial_sums_available(const vilma_ctx *c) { return c ? c->tile_sums_ns : 0; }
+
+int vilma_trial_sums(vilma_ctx *c, void *stream, double *sums_a_dev, double *sums_b_dev) {
+    if (!c) return 1;
+    if (c->tile_sums_ns < 1) return fail(c, "the last trial left no per-tile sums (use vilma_delta_sums)");
+    if (!sums_a_dev) return fail(c, "vilma_trial_sums: sums_a_dev is required");
+    if (sums_b_dev && c->tile_sums_ns < 2) return fail(c, "no second candidate");
+    hipStream_t s = (hipStream_t)stream;
+    // the rows depend on the trial's per-SNP pass alone: reduce them beside its LD product
+    hipStream_t q = side_begin(c, s);
+    const int AM = c->A * c->M;
+    const int64_t rows_elems = (int64_t)snp_tile_grid(c->N) * AM;
+    double *scratch = c->sum_partials + 2 * rows_elems;
+    if (sums_b_dev && sums_b_dev > sums_a_dev) {
+        // both candidates in one launch sequence
+        launch_tile_sums(c->sum_partials, c->N, AM, 2, scratch, sums_a_dev, sums_b_dev - sums_a_dev, q);
+    } else {
+        launch_tile_sums(c->sum_partials, c->N, AM, 1, scratch, sums_a_dev, 0, q);
+        if (sums_b_dev)
+            launch_tile_sums(c->sum_partials + rows_elems, c->N, AM, 1, scratch, sums_b_dev, 0, q);
+    }
     side_end(c, s, q);
     HIPCHK(c, hipGetLastError());
     return 0;

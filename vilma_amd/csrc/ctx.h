@@ -128,6 +128,11 @@ struct vilma_ctx {
     bool have_moments = false;
     bool trial_tainted = false;     // trial moments come from vilma_eval_given_delta
 
+    // per-tile responsibility sums a stashing beta trial leaves behind ([candidate][tile][A*M] +
+    // reduction scratch; nullptr when M is too large for the stash) and how many candidates of the
+    // LAST trial have them (0: none -- the sums come from delta_kernel)
+    double *sum_partials = nullptr;
+    int tile_sums_ns = 0;
     double *snapshot = nullptr, *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;
     std::vector<int32_t> dot_start;     // first y.z partial slot of each cohort (+ end)

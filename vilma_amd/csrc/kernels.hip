@@ -965,33 +965,84 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 }
 
 // --------------------------------------------------------------------------------------------
-// fused per-SNP pass (one thread per SNP, coalesced along the SNP axis of vi_mu [M][P][N])
+// fused per-SNP pass.  A workgroup of four waves takes a TILE of 64 SNPs (lane = SNP, coalesced
+// along the SNP axis of vi_mu [M][P][N]); the waves split the mixture components between them in
+// batches of KB (batch b belongs to wave b % 4), so the per-component tables stay wave-uniform
+// (scalar loads) while a small shard still gets four times the waves of a thread-per-SNP layout.
+//
+// Softmax over components against a FIXED shift.  Responsibilities delta_k ~ exp(u_k),
+// u_k = 0.5 (quad_k - log det Lam_k) + lh_k, are accumulated as e_k = w_k exp(a_k - s) with
+// a_k = 0.5 quad_k + lh_k, w_k = det^-1/2 (an rsqrt instead of a log per (component, SNP)) and
+// s = the log-normaliser of the CURRENT accepted state of that SNP: the candidate's own
+// normaliser is Z = sum_k e_k and delta_k = e_k / Z exactly, with no running maximum, no
+// rescaling, and every term final the moment it is formed.  That is what lets the e_k be stashed
+// (LDS, one double per (component, candidate, SNP)) and turned into the per-annotation
+// responsibility sums -- the M-step statistic, sum_annotations (numerics.py:118-129) -- at the
+// end of the same pass, for BOTH candidates of a two-step trial, instead of re-reading the
+// candidate's vi_mu in a second kernel.  Safety: each wave also tracks max_k a_k; if Z leaves
+// [1e-150, 1e150] for any SNP of the tile (a state that moved by hundreds of log units, or no
+// reference yet) the tile is redone once with s = max_k a_k, for which Z is within
+// [min w, M max w].  The decision is uniform over the workgroup and depends on the data only, so
+// results are reproducible.  In the KL terms the log-determinants of fast_delta_kl and
+// fast_beta_kl cancel, so their sum needs only quad_k and tr(Prec_k Sig_k).
 // --------------------------------------------------------------------------------------------
 #define SNP_THREADS 256
+#define SNP_TILE 64
 #ifndef KU
 #define KU 4
 #endif
 
-// (Splitting the components of one SNP over 4 lanes to get 4x the waves on small shards was
-// measured and rejected for this kernel: 63 vs 52 us per evaluation at 131 k SNPs -- the
-// per-component tables stop being wave-uniform.  It does pay for delta_kernel below.)
-// NS = candidates evaluated in one pass: 1, or 2 for a beta trial at the step sizes `step` and
-// `step2` (the line search's current L and the L it would try next, variational_inference.py:
-// 777-800) -- vi_mu, Lam_k, Sig_k and the per-component tables are loaded / formed once and shared,
-// so the second candidate costs its own blend, softmax and stores only.  Each candidate goes
-// through exactly the arithmetic of the NS = 1 kernel, in the same order.
-template <int P, bool BLEND, bool ONE_ANNOT, int NS>
+int snp_pass_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
+int snp_tile_grid(int64_t N) { return (int)((N + SNP_TILE - 1) / SNP_TILE); }
+
+static inline int snp_kb(int P) { return P <= 2 ? KU : (KU > 2 ? 2 : KU); }
+// stash slots per wave: components a wave can own (whole batches)
+static inline int snp_slots(int M, int P) {
+    const int kb = snp_kb(P), nb = (M + kb - 1) / kb;
+    return (nb + 3) / 4 * kb;
+}
+// accumulators a wave hands to wave 0 per candidate: Z, Skl, Sip, amax, Sm[P], S2[P]
+static inline int snp_nacc(int P) { return 4 + 2 * P; }
+size_t snp_pass_lds_bytes(int M, int P, int ns, bool stash) {
+    size_t b = (size_t)3 * ns * snp_nacc(P) * SNP_TILE * sizeof(double);      // waves 1..3 -> wave 0
+    b += (size_t)(2 * ns + 1) * SNP_TILE * sizeof(double);                    // 1/Z, shift, retry flag
+    if (stash) b += (size_t)snp_slots(M, P) * ns * SNP_THREADS * sizeof(double);
+    return b;
+}
+// The stash is used when two workgroups still fit a CU's 160 KB of LDS (one is not enough to hide
+// the pass's latencies: profiles/r02s_ab_snp_pass_occupancy.txt); beyond that (M above ~48 with
+// two candidates, ~100 with one) the sums come from delta_kernel as before.
+bool snp_pass_can_stash(int M, int P, int ns) {
+    return snp_pass_lds_bytes(M, P, ns, true) <= (size_t)80 * 1024;
+}
+
+// sum over the 64 lanes of 8 values at once (halving butterfly, DPP / permlane moves only): the
+// total of value `row` ends up in the lanes with (lane & 7) == 0 of its lane group
+static __device__ __forceinline__ double tile_sum8(const double (&p)[8], int lane, int &row) {
+    return sym_rowsum8(p, lane, row);
+}
+
+template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH>
 __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
     static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
     constexpr int NT = 2 * P + 2;
-    __shared__ double red[SNP_THREADS / 64][NT < 6 ? 6 : NT];
+    constexpr int NACC = 4 + 2 * P;
+    constexpr int KB = P <= 2 ? KU : (KU > 2 ? 2 : KU);
+    extern __shared__ double lds[];
     PRED_EXIT(a.pred);
     const int N = a.N, M = a.M;
     const int64_t N64 = N;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = blockIdx.x * SNP_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * SNP_TILE + lane;
     const bool live = i < N;
     const int ii = live ? i : N - 1;
+    // LDS: [3][NS][NACC][64] partials | [NS][64] 1/Z | [NS][64] shift | [64] retry | stash
+    double *part_lds = lds;
+    double *invz_lds = part_lds + 3 * NS * NACC * SNP_TILE;
+    double *shift_lds = invz_lds + NS * SNP_TILE;
+    double *retry_lds = shift_lds + NS * SNP_TILE;
+    double *stash = retry_lds + SNP_TILE;
 
     double d[P], se[P], adj[P], sld[P], g[P];
 #pragma unroll
@@ -1019,31 +1070,23 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     mu_out[0] = a.mu_out;
     if (NS == 2) { step[NS - 1] = a.step2; mu_out[NS - 1] = a.mu_out2; }
 
-    // Responsibilities delta_k ~ exp(u_k), u_k = 0.5 (quad_k - log det Lam_k) + lh_k, are
-    // accumulated as w_k exp(a_k - max a) with a_k = 0.5 quad_k + lh_k and w_k = det^-1/2: an
-    // rsqrt instead of a log per (component, SNP).  In the KL terms the log-determinants of
-    // fast_delta_kl and fast_beta_kl cancel, so their sum needs only quad_k and tr(Prec_k Sig_k).
-    // Online softmax with ONE exp per component: with d = a_k - max, t = exp(-|d|) is the weight
-    // of the new term when d <= 0 and the rescale factor of the running sums when d > 0.
-    double mx[NS], Z[NS], Skl[NS], Sip[NS], Sm[NS][P], S2[NS][P];
-#pragma unroll
-    for (int c = 0; c < NS; ++c) {
-        mx[c] = NEG_INF; Z[c] = 0.0; Skl[c] = 0.0; Sip[c] = 0.0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) { Sm[c][p] = 0.0; S2[c][p] = 0.0; }
-    }
-
     // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
     // buffered: the loads of batch b+1 are issued BEFORE batch b is folded in and its new vi_mu
     // stored.  On gfx9 loads and stores retire through one in-order counter (vmcnt), so a wave that
     // stores and then loads waits for its own stores to reach HBM before it sees the loaded data;
     // with the next loads ahead of the stores it only ever waits for loads.
-    constexpr int KB = P <= 2 ? KU : (KU > 2 ? 2 : KU);
     const const_tab prec_tab = as_table(a.prec);
     const const_tab lh_tab = as_table(a.lh);          // one annotation: the row is wave-uniform
     // tables of a whole batch are fetched up front too (P <= 2: 5 doubles per component fit the
     // scalar registers), so the batch computes without a scalar-load stall per component
     constexpr bool TAB_AHEAD = P <= 2;
+
+    double shift[NS], Z[NS], Skl[NS], Sip[NS], amax[NS], Sm[NS][P], S2[NS][P];
+    {
+        const double s0 = a.lse_ref != nullptr ? a.lse_ref[ii] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) shift[c] = s0;
+    }
 
     // with several annotations the log-weight row differs per lane: those (vector) loads travel
     // with the vi_mu batch, ahead of the previous batch's stores
@@ -1056,7 +1099,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
             lhv[kk] = ONE_ANNOT ? 0.0 : lh[kc];
         }
     };
-    auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0) {
+    auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0, int slot0) {
         double prt[TAB_AHEAD ? KB : 1][P][P], lht[TAB_AHEAD ? KB : 1];
         if (TAB_AHEAD) {
 #pragma unroll
@@ -1122,141 +1165,253 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
 #pragma unroll
                 for (int p = 0; p < P; ++p) ip = fma(-d[p] * mun[p], mun[p], ip);
                 const double ak = 0.5 * quad + lhk;
-                const double dk = ak - mx[c];
-                const double t = exp(-fabs(dk));
-                const bool up = dk > 0.0;
-                const double sc = up ? t : 1.0;
-                const double e = wk * (up ? 1.0 : t);
-                mx[c] = up ? ak : mx[c];
-                Z[c] = fma(Z[c], sc, e);
-                Skl[c] = fma(Skl[c], sc, e * (0.5 * (quad + tr)));
-                Sip[c] = fma(Sip[c], sc, e * ip);
+                amax[c] = fmax(amax[c], ak);
+                const double e = wk * exp(ak - shift[c]);
+                Z[c] += e;
+                Skl[c] = fma(e, 0.5 * (quad + tr), Skl[c]);
+                Sip[c] = fma(e, ip, Sip[c]);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    Sm[c][p] = fma(Sm[c][p], sc, e * mun[p]);
-                    S2[c][p] = fma(S2[c][p], sc, e * (sig[p][p] + mun[p] * mun[p]));
+                    Sm[c][p] = fma(e, mun[p], Sm[c][p]);
+                    S2[c][p] = fma(e, sig[p][p] + mun[p] * mun[p], S2[c][p]);
                 }
+                if (STASH) stash[((slot0 + kk) * NS + c) * SNP_THREADS + threadIdx.x] = e;
             }
         }
     };
 
-    double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
-    fetch(bufA, lhA, 0);
-    for (int k0 = 0; k0 < M; k0 += 2 * KB) {
-        fetch(bufB, lhB, k0 + KB);         // past the end the clamped loads re-read component M-1
-        fold(bufA, lhA, k0);
-        if (k0 + KB >= M) break;           // wave-uniform
-        fetch(bufA, lhA, k0 + 2 * KB);
-        fold(bufB, lhB, k0 + KB);
-    }
-    const bool owner = live;
-    double mpost[P];
+    double invZ[NS];
+    for (int attempt = 0;; ++attempt) {
 #pragma unroll
-    for (int c = 0; c < NS; ++c) {
-        double *m_out = c == 0 ? a.m_out : a.m_out2, *v_out = c == 0 ? a.v_out : a.v_out2;
-        double *pool_out = c == 0 ? a.pool_out : a.pool_out2;
-        double *lse_out = c == 0 ? a.lse_out : a.lse_out2;
-        const double invZ = 1.0 / Z[c];
-        const double lse = mx[c] + log(Z[c]);
-        double part[NT];
+        for (int c = 0; c < NS; ++c) {
+            Z[c] = 0.0; Skl[c] = 0.0; Sip[c] = 0.0; amax[c] = NEG_INF;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const double m = Sm[c][p] * invZ;
-            const double v = S2[c][p] * invZ - m * m;
-            if (c == 0) mpost[p] = m;
-            if (owner) {
-                m_out[p * N64 + i] = m;
-                v_out[p * N64 + i] = v;
-                pool_out[p * N64 + a.invperm[p * N64 + i]] = m / se[p];
-            }
-            part[p] = owner ? m * adj[p] : 0.0;
-            part[P + p] = owner ? sld[p] * v : 0.0;
+            for (int p = 0; p < P; ++p) { Sm[c][p] = 0.0; S2[c][p] = 0.0; }
         }
-        if (owner) lse_out[i] = lse;
-        part[2 * P] = owner ? (Skl[c] * invZ - lse) : 0.0;
-        part[2 * P + 1] = owner ? 0.5 * Sip[c] * invZ : 0.0;
-
-        if (c > 0) __syncthreads();               // red[] is being reused
+        // this wave's batches: b = w, w + 4, ...; its j-th batch covers stash slots j*KB ...
+        double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
+        fetch(bufA, lhA, w * KB);
+        for (int j = 0;; j += 2) {
+            const int k0 = (w + 4 * j) * KB, k1 = k0 + 4 * KB;
+            fetch(bufB, lhB, k1);              // past the end the clamped loads re-read component M-1
+            fold(bufA, lhA, k0, j * KB);
+            if (k1 >= M) break;                // wave-uniform
+            fetch(bufA, lhA, k1 + 4 * KB);
+            fold(bufB, lhB, k1, (j + 1) * KB);
+            if (k1 + 4 * KB >= M) break;
+        }
+        // waves 1..3 hand their partial sums to wave 0, which adds them in wave order
+        if (w > 0) {
+            double *dst = part_lds + (w - 1) * NS * NACC * SNP_TILE + lane;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const double s = wave_sum(part[t]);
-            if (lane == 0) red[w][t] = s;
+            for (int c = 0; c < NS; ++c) {
+                double *dc = dst + c * NACC * SNP_TILE;
+                dc[0 * SNP_TILE] = Z[c]; dc[1 * SNP_TILE] = Skl[c]; dc[2 * SNP_TILE] = Sip[c];
+                dc[3 * SNP_TILE] = amax[c];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    dc[(4 + p) * SNP_TILE] = Sm[c][p];
+                    dc[(4 + P + p) * SNP_TILE] = S2[c][p];
+                }
+            }
         }
         __syncthreads();
-        if (threadIdx.x < NT) {
-            double s = red[0][threadIdx.x];
+        if (w == 0) {
+            bool bad = false;
 #pragma unroll
-            for (int ww = 1; ww < SNP_THREADS / 64; ++ww) s += red[ww][threadIdx.x];
-            // candidate c's columns sit behind the first candidate's (and the 6 statistics columns)
-            a.partials[(int64_t)(c * (NT + 6) + threadIdx.x) * gridDim.x + blockIdx.x] = s;
+            for (int c = 0; c < NS; ++c) {
+#pragma unroll
+                for (int ww = 0; ww < 3; ++ww) {
+                    const double *sc = part_lds + (ww * NS + c) * NACC * SNP_TILE + lane;
+                    Z[c] += sc[0 * SNP_TILE]; Skl[c] += sc[1 * SNP_TILE]; Sip[c] += sc[2 * SNP_TILE];
+                    amax[c] = fmax(amax[c], sc[3 * SNP_TILE]);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        Sm[c][p] += sc[(4 + p) * SNP_TILE];
+                        S2[c][p] += sc[(4 + P + p) * SNP_TILE];
+                    }
+                }
+                const bool ok = Z[c] >= 1e-150 && Z[c] <= 1e150;      // false for NaN too
+                // a tile is redone at most once: with the exact maximum as the shift Z is in range
+                // unless the problem itself is not finite
+                const bool redo = !ok && attempt == 0 && amax[c] > NEG_INF && amax[c] < -NEG_INF;
+                bad = bad || redo;
+                invz_lds[c * SNP_TILE + lane] = 1.0 / Z[c];
+                shift_lds[c * SNP_TILE + lane] = redo ? amax[c] : shift[c];
+            }
+            const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+            if (lane == 0) retry_lds[0] = any_bad ? 1.0 : 0.0;
         }
+        __syncthreads();
+        const bool retry = retry_lds[0] != 0.0;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            invZ[c] = invz_lds[c * SNP_TILE + lane];
+            if (retry) shift[c] = shift_lds[c * SNP_TILE + lane];
+        }
+        if (!retry) break;
+        __syncthreads();                          // part_lds / retry_lds are rewritten next round
     }
-    // Convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
-    // fused into an evaluation the caller accepts unconditionally (the one after the M-step):
-    // the new posterior means are compared with the snapshot and become the snapshot, so no
-    // separate pass over [P][N] (mean_diff_kernel) and no second stream are needed per sweep.
-    if (!BLEND && a.diff) {                       // kernel-uniform
-        double dv[6] = {0, 0, 0, 0, 0, 0};
-        if (owner) {
+
+    if (w == 0) {
+        // per-SNP results and the tile's contributions to the objective sums
+        const bool owner = live;
+        double mpost[P];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            double *m_out = c == 0 ? a.m_out : a.m_out2, *v_out = c == 0 ? a.v_out : a.v_out2;
+            double *pool_out = c == 0 ? a.pool_out : a.pool_out2;
+            double *lse_out = c == 0 ? a.lse_out : a.lse_out2;
+            const double lse = shift[c] + log(Z[c]);
+            constexpr int NTP = (NT + 7) / 8 * 8;
+            double vals[NTP];
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) vals[t] = 0.0;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const double nw = mpost[p] * a.scal[p * N64 + i];
-                const double od = a.snapshot[p * N64 + i];
-                const double df = fabs(nw - od);
-                dv[0] += (df <= 1e-6 + 1e-6 * fabs(od)) ? 0.0 : 1.0;
-                dv[1] += df;
-                dv[2] += df * df;
-                dv[3] = fmax(dv[3], fabs(nw));
-                dv[4] = fmax(dv[4], df);
-                dv[5] = fmax(dv[5], fabs((nw - od) / (od + 1e-100)));
-                a.snapshot[p * N64 + i] = nw;
+                const double m = Sm[c][p] * invZ[c];
+                const double v = S2[c][p] * invZ[c] - m * m;
+                if (c == 0) mpost[p] = m;
+                if (owner) {
+                    m_out[p * N64 + i] = m;
+                    v_out[p * N64 + i] = v;
+                    pool_out[p * N64 + a.invperm[p * N64 + i]] = m / se[p];
+                }
+                vals[p] = owner ? m * adj[p] : 0.0;
+                vals[P + p] = owner ? sld[p] * v : 0.0;
+            }
+            if (owner) lse_out[i] = lse;
+            vals[2 * P] = owner ? (Skl[c] * invZ[c] - lse) : 0.0;
+            vals[2 * P + 1] = owner ? 0.5 * Sip[c] * invZ[c] : 0.0;
+            // candidate c's columns sit behind the first candidate's (and the 6 statistics columns)
+            double *col = a.partials + (int64_t)c * (NT + 6) * gridDim.x + blockIdx.x;
+#pragma unroll
+            for (int h = 0; h < NTP / 8; ++h) {
+                double p8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) p8[t] = vals[8 * h + t];
+                int row;
+                const double tot = tile_sum8(p8, lane, row);
+                if ((lane & 7) == 0 && 8 * h + row < NT) col[(int64_t)(8 * h + row) * gridDim.x] = tot;
             }
         }
-        __syncthreads();                          // red[] is being reused
+        // Convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
+        // fused into an evaluation the caller accepts unconditionally (the one after the M-step):
+        // the new posterior means are compared with the snapshot and become the snapshot, so no
+        // separate pass over [P][N] (mean_diff_kernel) and no second stream are needed per sweep.
+        if (!BLEND && a.diff) {                       // kernel-uniform
+            double dv[6] = {0, 0, 0, 0, 0, 0};
+            if (owner) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const double s = c < 3 ? wave_sum(dv[c]) : wave_max(dv[c]);
-            if (lane == 0) red[w][c] = s;
+                for (int p = 0; p < P; ++p) {
+                    const double nw = mpost[p] * a.scal[p * N64 + i];
+                    const double od = a.snapshot[p * N64 + i];
+                    const double df = fabs(nw - od);
+                    dv[0] += (df <= 1e-6 + 1e-6 * fabs(od)) ? 0.0 : 1.0;
+                    dv[1] += df;
+                    dv[2] += df * df;
+                    dv[3] = fmax(dv[3], fabs(nw));
+                    dv[4] = fmax(dv[4], df);
+                    dv[5] = fmax(dv[5], fabs((nw - od) / (od + 1e-100)));
+                    a.snapshot[p * N64 + i] = nw;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double s = c < 3 ? wave_sum(dv[c]) : wave_max(dv[c]);
+                if (lane == 0) a.partials[(int64_t)(NT + c) * gridDim.x + blockIdx.x] = s;
+            }
         }
-        __syncthreads();
-        if (threadIdx.x < 6) {
-            const int c = threadIdx.x;
-            double s = red[0][c];
+    }
+
+    if (STASH) {
+        // responsibility sums of the tile: delta_k = max(e_k / Z, 1e-100) (invert_nat_cat_2D's clamp,
+        // numerics.py:192-194), summed over the tile's SNPs per annotation, for this wave's
+        // components and every candidate; row = tile, [candidate][annotation][component]
+        const int A = a.A;
+        const int ann = ONE_ANNOT ? 0 : a.annot[ii];
+        const int nslots = ((M + KB - 1) / KB + 3) / 4 * KB;
+        const int AM = A * M;
+        for (int c = 0; c < NS; ++c) {
+            double *prow = a.sum_partials + ((int64_t)c * gridDim.x + blockIdx.x) * AM;
+            for (int s0 = 0; s0 < nslots; s0 += 8) {
+                double e8[8];
 #pragma unroll
-            for (int ww = 1; ww < SNP_THREADS / 64; ++ww)
-                s = c < 3 ? s + red[ww][c] : fmax(s, red[ww][c]);
-            a.partials[(int64_t)(NT + c) * gridDim.x + blockIdx.x] = s;
+                for (int u = 0; u < 8; ++u) {
+                    const int slot = s0 + u;
+                    // slot -> component: batch j = slot / KB of this wave is global batch w + 4 j
+                    const int k = (w + 4 * (slot / KB)) * KB + (slot % KB);
+                    const bool have = slot < nslots && k < M;
+                    const double e = have ? stash[(slot * NS + c) * SNP_THREADS + threadIdx.x] : 0.0;
+                    e8[u] = (live && have) ? fmax(e * invZ[c], 1e-100) : 0.0;
+                }
+                if (ONE_ANNOT) {
+                    int row;
+                    const double tot = tile_sum8(e8, lane, row);
+                    const int slot = s0 + row;
+                    const int k = (w + 4 * (slot / KB)) * KB + (slot % KB);
+                    if ((lane & 7) == 0 && slot < nslots && k < M) prow[k] = tot;
+                } else {
+                    for (int aa = 0; aa < A; ++aa) {
+                        double m8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) m8[u] = ann == aa ? e8[u] : 0.0;
+                        int row;
+                        const double tot = tile_sum8(m8, lane, row);
+                        const int k = (w + 4 * ((s0 + row) / KB)) * KB + ((s0 + row) % KB);
+                        if ((lane & 7) == 0 && s0 + row < nslots && k < M) prow[(int64_t)aa * M + k] = tot;
+                    }
+                }
+            }
         }
     }
 }
 
-int snp_pass_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
+template <int P, bool BLEND, bool ONE_ANNOT, int NS>
+static void launch_snp_pass_s(const SnpKernelArgs &a, bool stash, hipStream_t s) {
+    const dim3 grid(snp_tile_grid(a.N)), block(SNP_THREADS);
+    const size_t lds = snp_pass_lds_bytes(a.M, P, NS, stash);
+    if (stash) {
+        auto kern = snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true>;
+        static bool raised = false;             // more than 64 KB of dynamic LDS needs the attribute
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      96 * 1024);
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+    } else {
+        hipLaunchKernelGGL((snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, false>), grid, block, lds, s, a);
+    }
+}
 
 template <int P>
-static void launch_snp_pass_p(const SnpKernelArgs &a, bool blend, int ns, hipStream_t s) {
-    const dim3 grid(snp_pass_grid(a.N)), block(SNP_THREADS);
+static void launch_snp_pass_p(const SnpKernelArgs &a, bool blend, int ns, bool stash, hipStream_t s) {
     const bool one = a.A == 1;
     if (blend && ns == 2) {
-        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, true, true, 2>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((snp_pass_kernel<P, true, false, 2>), grid, block, 0, s, a);
+        if (one) launch_snp_pass_s<P, true, true, 2>(a, stash, s);
+        else launch_snp_pass_s<P, true, false, 2>(a, stash, s);
     } else if (blend) {
-        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, true, true, 1>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((snp_pass_kernel<P, true, false, 1>), grid, block, 0, s, a);
+        if (one) launch_snp_pass_s<P, true, true, 1>(a, stash, s);
+        else launch_snp_pass_s<P, true, false, 1>(a, stash, s);
     } else {
-        if (one) hipLaunchKernelGGL((snp_pass_kernel<P, false, true, 1>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((snp_pass_kernel<P, false, false, 1>), grid, block, 0, s, a);
+        if (one) launch_snp_pass_s<P, false, true, 1>(a, stash, s);
+        else launch_snp_pass_s<P, false, false, 1>(a, stash, s);
     }
 }
 
-// ns = 1: one candidate (or a plain evaluation); ns = 2: a beta trial at a.step and a.step2
+// ns = 1: one candidate (or a plain evaluation); ns = 2: a beta trial at a.step and a.step2.
+// With a.sum_partials != nullptr (and snp_pass_can_stash) the per-tile responsibility sums of every
+// candidate are written there: [candidate][tile][A*M].
 void launch_snp_pass(const SnpKernelArgs &args, bool blend, int ns, hipStream_t s) {
     SnpKernelArgs a = args;
     a.pred = g_pred;
+    const bool stash = a.sum_partials != nullptr && snp_pass_can_stash(a.M, a.P, ns);
     switch (a.P) {
-        case 1: launch_snp_pass_p<1>(a, blend, ns, s); break;
-        case 2: launch_snp_pass_p<2>(a, blend, ns, s); break;
-        case 3: launch_snp_pass_p<3>(a, blend, ns, s); break;
-        case 4: launch_snp_pass_p<4>(a, blend, ns, s); break;
+        case 1: launch_snp_pass_p<1>(a, blend, ns, stash, s); break;
+        case 2: launch_snp_pass_p<2>(a, blend, ns, stash, s); break;
+        case 3: launch_snp_pass_p<3>(a, blend, ns, stash, s); break;
+        case 4: launch_snp_pass_p<4>(a, blend, ns, stash, s); break;
         default: break;   // rejected in vilma_create
     }
 }
@@ -1373,11 +1528,16 @@ int delta_grid(int64_t N) {
 // interleaved rows with 4 independent accumulators each, fixed combination order.  Launched
 // twice (rows -> RC_CHUNKS partial rows -> 1 row) so the long reduction is spread over the chip.
 #define RC_CHUNK_ROWS 256
+// blockIdx.z = independent problem (candidate): its input / output sit in_zstride / out_zstride
+// doubles behind the first one's.
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const double *__restrict__ in, int rows,
                                                            int ncols, double *__restrict__ out,
+                                                           int64_t in_zstride, int64_t out_zstride,
                                                            const int *pred) {
     __shared__ double red[4][64];
     PRED_EXIT(pred);
+    in += blockIdx.z * in_zstride;
+    out += blockIdx.z * out_zstride;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * RC_CHUNK_ROWS;
@@ -1415,20 +1575,23 @@ int64_t delta_partial_rows(int64_t N) {
     return rows + reduce_cols_scratch_rows(rows);
 }
 
+// nz independent problems in one launch sequence: problem z reads in + z * in_zstride and writes
+// out + z * out_zstride; scratch must hold nz * reduce_cols_scratch_rows(rows) * ncols doubles
 static void reduce_cols(const double *in, int rows, int ncols, double *scratch, double *out,
-                        hipStream_t s) {
-    // scratch must hold reduce_cols_scratch_rows(rows) * ncols doubles
+                        hipStream_t s, int nz = 1, int64_t in_zstride = 0, int64_t out_zstride = 0) {
     const int colblocks = (ncols + 63) / 64;
+    const int64_t sz = reduce_cols_scratch_rows(rows) * ncols;      // per-problem scratch
     while (rows > RC_CHUNK_ROWS) {
         const int chunks = (rows + RC_CHUNK_ROWS - 1) / RC_CHUNK_ROWS;
-        hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, chunks), dim3(256), 0, s, in, rows,
-                           ncols, scratch, g_pred);
+        hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, chunks, nz), dim3(256), 0, s, in, rows,
+                           ncols, scratch, in_zstride, sz, g_pred);
         in = scratch;
+        in_zstride = sz;
         scratch = scratch + (int64_t)chunks * ncols;
         rows = chunks;
     }
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, 1), dim3(256), 0, s, in, rows, ncols, out,
-                       g_pred);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(colblocks, 1, nz), dim3(256), 0, s, in, rows, ncols,
+                       out, in_zstride, out_zstride, g_pred);
 }
 
 template <int P, bool WRITE, int KS>
@@ -1465,6 +1628,18 @@ void launch_delta_sums(const DeltaArgs &a, double *sums_out, hipStream_t s) {
 }
 
 void launch_delta_write(const DeltaArgs &a, hipStream_t s) { launch_delta_any<true>(a, s); }
+
+// Responsibility sums from the per-tile rows a stashing snp_pass left behind ([candidate][tile][AM],
+// launch_snp_pass): candidate z's column sums go to out + z * out_zstride.
+int64_t tile_sums_elems(int64_t N, int AM, int ns) {
+    const int64_t rows = snp_tile_grid(N);
+    return (int64_t)ns * (rows + reduce_cols_scratch_rows(rows)) * AM;
+}
+void launch_tile_sums(const double *tile_rows, int64_t N, int AM, int ns, double *scratch,
+                      double *out, int64_t out_zstride, hipStream_t s) {
+    const int rows = snp_tile_grid(N);
+    reduce_cols(tile_rows, rows, AM, scratch, out, s, ns, (int64_t)rows * AM, out_zstride);
+}
 
 // --------------------------------------------------------------------------------------------
 // _initialize on the device (variational_inference.py:658-692): from the jittered start fake_mu

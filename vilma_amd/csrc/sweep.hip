@@ -94,9 +94,11 @@ struct SweepState {
     bool have_state = false;
     std::vector<double> hyper, totals;
     double objective = 0.0;
-    bool cur_sums = false;                  // results[o_sa..] = all-reduced sums of the current state
+    int cur_sums = -1;                      // offset in the result vector of the all-reduced
+                                            // responsibility sums of the current state, or -1
     // the last beta trial's candidates
-    bool trial_sums = false;                // ... of candidate A of the last trial
+    bool trial_sums = false;                // o_sa holds candidate A's all-reduced sums
+    bool trial_sums_b = false;              // o_sb holds candidate B's
     int candidate = 1;                      // which candidate the objective just looked at belongs to
     bool alt_valid = false;                 // candidate B evaluated, not looked at yet
     double alt_step = 0.0, alt_obj = 0.0;
@@ -212,7 +214,7 @@ int reduce_and_fetch(vilma_ctx *c, SweepState *s, hipStream_t st, int lo, int hi
 int evaluate_current(vilma_ctx *c, SweepState *s, hipStream_t st, double *obj) {
     if (vilma_eval(c, (void *)st, s->results + s->o_tot)) return 1;
     if (reduce_and_fetch(c, s, st, s->o_tot, s->o_tot + s->nt, false)) return 1;
-    s->trial_sums = false;
+    s->trial_sums = s->trial_sums_b = false;
     s->alt_valid = false;
     if (s->stats) { s->stats->n_evaluations += 1; s->stats->n_products += 1; }
     *obj = objective_from(c, s, s->host.data() + s->o_tot);
@@ -224,9 +226,9 @@ int accept(vilma_ctx *c, SweepState *s, int take, double obj, const double *tota
     if (vilma_accept(c, take)) return 1;
     s->objective = obj;
     std::copy(totals, totals + s->nt, s->totals.begin());
-    // responsibility sums fetched with candidate A now describe the current state
-    s->cur_sums = s->trial_sums && take == 1;
-    s->trial_sums = false;
+    // responsibility sums fetched with the candidate now describe the current state
+    s->cur_sums = (take == 1 && s->trial_sums) ? s->o_sa : (take == 2 && s->trial_sums_b) ? s->o_sb : -1;
+    s->trial_sums = s->trial_sums_b = false;
     s->have_state = true;
     return 0;
 }
@@ -238,14 +240,13 @@ int trial(vilma_ctx *c, SweepState *s, hipStream_t st, double step, double next_
     if (s->alt_valid && s->alt_step == step) {
         s->alt_valid = false;
         s->candidate = 2;
-        s->trial_sums = false;          // the sums ride with candidate A only
         if (s->stats) { s->stats->n_evaluations += 1; s->stats->n_trials += 1; }
         *obj = s->alt_obj;
         *totals = s->alt_totals.data();
         return 0;
     }
     s->alt_valid = false;
-    s->cur_sums = false;                // the trial's sums overwrite the device copy
+    s->cur_sums = -1;                   // the trial's sums overwrite the device copy
     const bool two = s->two_step;
     if (two) {
         if (vilma_trial_beta2(c, (void *)st, step, next_step, s->results + s->o_ta, s->results + s->o_tb))
@@ -253,10 +254,21 @@ int trial(vilma_ctx *c, SweepState *s, hipStream_t st, double step, double next_
     } else if (vilma_trial_beta(c, (void *)st, step, s->results + s->o_ta)) {
         return 1;
     }
-    if (vilma_delta_sums(c, (void *)st, s->results + s->o_sa, VILMA_STATE_TRIAL_BETA)) return 1;
-    if (reduce_and_fetch(c, s, st, s->o_ta, s->o_sa + s->am, false)) return 1;
+    // the M-step statistic of the candidates: from the per-tile sums the trial's own per-SNP pass
+    // left behind (both candidates, no second pass over vi_mu) when it stashed them, else by
+    // delta_kernel for candidate A
+    const int avail = vilma_trial_sums_available(c);
+    const bool sums_b = two && avail == 2;
+    if (avail >= 1) {
+        if (vilma_trial_sums(c, (void *)st, s->results + s->o_sa, sums_b ? s->results + s->o_sb : nullptr))
+            return 1;
+    } else if (vilma_delta_sums(c, (void *)st, s->results + s->o_sa, VILMA_STATE_TRIAL_BETA)) {
+        return 1;
+    }
+    if (reduce_and_fetch(c, s, st, s->o_ta, sums_b ? s->o_sb + s->am : s->o_sa + s->am, false)) return 1;
     s->candidate = 1;
     s->trial_sums = true;
+    s->trial_sums_b = sums_b;
     if (two) {
         s->alt_valid = true;
         s->alt_step = next_step;
@@ -298,13 +310,14 @@ int update_beta(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, double o
 // sums (already all-reduced when they came with the accepted beta trial) -> hyper_delta and its
 // table on the device -> re-evaluation.  Unconditional in the reference, so accepted at once.
 int update_hyper(vilma_ctx *c, SweepState *s, hipStream_t st, bool with_diff, double *new_obj) {
-    if (!s->cur_sums) {
-        // no accepted beta step since the last evaluation (or candidate B was taken): the statistic
-        // of the current state is computed now
+    if (s->cur_sums < 0) {
+        // no accepted beta step since the last evaluation (or a candidate without sums was taken):
+        // the statistic of the current state is computed now
         if (vilma_delta_sums(c, (void *)st, s->results + s->o_sa, VILMA_STATE_CURRENT)) return 1;
         if (s->comm_kind && comm_allreduce(c, s, st, s->results + s->o_sa, s->am, 0)) return 1;
+        s->cur_sums = s->o_sa;
     }
-    if (vilma_mstep(c, (void *)st, s->results + s->o_sa, s->results + s->o_hyper)) return 1;
+    if (vilma_mstep(c, (void *)st, s->results + s->cur_sums, s->results + s->o_hyper)) return 1;
     if (with_diff) {
         if (vilma_eval_diff(c, (void *)st, s->results + s->o_tot, s->results + s->o_dsum,
                             s->results + s->o_dmax)) return 1;
@@ -326,7 +339,8 @@ int update_hyper(vilma_ctx *c, SweepState *s, hipStream_t st, bool with_diff, do
     }
     const double orig = s->objective;
     s->objective = objective_from(c, s, s->totals.data());
-    s->cur_sums = s->trial_sums = false;
+    s->cur_sums = -1;
+    s->trial_sums = s->trial_sums_b = false;
     s->alt_valid = false;
     if (s->stats) { s->stats->n_evaluations += 1; s->stats->n_products += 1; }
     event(s, 1, 1, orig, s->objective);
@@ -486,7 +500,7 @@ int vilma_set_state(vilma_ctx *c, void *stream, const double *vi_mu, const doubl
     if (evaluate_current(c, s, st, &obj)) return 1;
     std::vector<double> tot(s->host.begin() + s->o_tot, s->host.begin() + s->o_tot + s->nt);
     if (accept(c, s, 0, obj, tot.data())) return 1;
-    s->cur_sums = false;
+    s->cur_sums = -1;
     s->L_rejected = -1.0;
     if (objective) *objective = obj;
     return 0;

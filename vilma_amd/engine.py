@@ -79,13 +79,14 @@ class HipEngine:
         self._ttotals = self.results[L.ttotals]
         self._ttotals_b = self.results[L.ttotals_b]
         self._sums = self.results[L.sums]
+        self._sums_b = self.results[L.sums_b]
         self._dmax = self.results[L.dmax]
         self._hyper = self.results[L.hyper]
         # device addresses of the fixed result slices, resolved once (a data_ptr() lookup per
         # launch costs about a microsecond of host time on the decision path)
         self._p = {name: C.c_void_p(t.data_ptr()) for name, t in (
             ('results', self.results), ('dsum', self._dsum), ('totals', self._totals),
-            ('ttotals', self._ttotals), ('ttotals_b', self._ttotals_b), ('sums', self._sums), ('dmax', self._dmax),
+            ('ttotals', self._ttotals), ('ttotals_b', self._ttotals_b), ('sums', self._sums), ('sums_b', self._sums_b), ('dmax', self._dmax),
             ('hyper', self._hyper))}
         self.n_totals = nt
         self._host = np.zeros(L.size)
@@ -356,6 +357,16 @@ class HipEngine:
         self._check(self.lib.vilma_delta_sums(self.ctx, self._stream_handle, self._p['sums'],
                                               which))
         return self._sums
+
+    def trial_sums(self, both=False):
+        """Responsibility sums of the last trial's candidate A (and B) from the per-tile sums its
+        per-SNP pass left behind -- no second pass over vi_mu (vilma_trial_sums)."""
+        self._check(self.lib.vilma_trial_sums(self.ctx, self._stream_handle, self._p['sums'],
+                                              self._p['sums_b'] if both else None))
+        return (self._sums, self._sums_b) if both else self._sums
+
+    def trial_sums_available(self):
+        return int(self.lib.vilma_trial_sums_available(self.ctx))
 
     def mean_diff(self):
         self._check(self.lib.vilma_mean_diff(self.ctx, self._stream_handle, self._p['dsum'],
