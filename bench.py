@@ -388,6 +388,9 @@ def main():
             'avg_launch_ms_two_rhs': sym2[0] / sym2[1] if sym2[1] else None,
             'launches_two_rhs': int(sym2[1]),
             'sweep_algorithmic_GBps': (n_prod * (alg_launch + state_bytes)) / elapsed / 1e9,
+            # the per-SNP passes, bracketed the same way
+            'snp_pass_avg_ms': {k: prof[k][0] / prof[k][1] for k in
+                                ('snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2') if prof[k][1]},
         },
     }
     if world == 1 and not args.no_cpu_baseline:

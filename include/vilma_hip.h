@@ -411,7 +411,10 @@ int vilma_sweep_drain(vilma_ctx *ctx);
                                   * launches, the two-pass kernels of blocks over 3 072 SNPs, combine) */
 #define VILMA_PROF_LD_SYM2 2     /* ld_sym_kernel with two right-hand sides (vilma_trial_beta2): one pass
                                   * over the store, two products */
-#define VILMA_PROF_KINDS 3
+#define VILMA_PROF_SNP_EVAL 3    /* snp_pass_kernel of a plain evaluation */
+#define VILMA_PROF_SNP_TRIAL 4   /* ... of a one-step beta trial */
+#define VILMA_PROF_SNP_TRIAL2 5  /* ... of a two-step beta trial */
+#define VILMA_PROF_KINDS 6
 int vilma_prof_enable(vilma_ctx *ctx, int enable);
 int vilma_prof_read(vilma_ctx *ctx, double *ms_total, int64_t *launches, int reset);
 

@@ -48,11 +48,16 @@ def main():
         return (time.perf_counter() - t0) / args.iters * 1e3
     t_eval = timed(lambda: eng.eval())
     t_trial = timed(lambda: eng.trial(0.5))
+    t_trial2 = timed(lambda: eng.trial2(0.5, 0.25))
+    have = eng.trial_sums_available()
+    t_tile = timed(lambda: eng.trial_sums(both=have == 2)) if have else float('nan')
     t_sums = timed(lambda: eng.delta_sums())
     gb = 8e-9 * N * M * P
     print('P=%d N=%d M=%d A=%d' % (P, N, M, A))
     print('  eval  (read mu)        %.3f ms  -> %.0f GB/s' % (t_eval, gb / t_eval * 1e3))
     print('  trial (read+write mu)  %.3f ms  -> %.0f GB/s' % (t_trial, 2 * gb / t_trial * 1e3))
+    print('  trial2 (read, write 2) %.3f ms  -> %.0f GB/s' % (t_trial2, 3 * gb / t_trial2 * 1e3))
+    print('  trial_sums (%d cand.)   %.3f ms' % (have, t_tile))
     print('  delta_sums             %.3f ms  -> %.0f GB/s' % (t_sums, gb / t_sums * 1e3))
     print('  (each includes the tiny LD product + finalize, ~0.03 ms)')
 

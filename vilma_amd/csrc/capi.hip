@@ -381,7 +381,14 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     const bool stash = blend && c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, ns);
     if (stash) a.sum_partials = c->sum_partials;
     c->tile_sums_ns = stash ? ns : 0;
-    launch_snp_pass(a, blend, ns, s);
+    {
+        // bracketed with the LD product that follows (same sampling tick)
+        hipEvent_t e0;
+        c->prof_now = c->prof > 0 && (c->prof_tick % c->prof) == 0;
+        prof_begin(c, s, e0);
+        launch_snp_pass(a, blend, ns, s);
+        prof_end(c, s, e0, !blend ? VILMA_PROF_SNP_EVAL : two ? VILMA_PROF_SNP_TRIAL2 : VILMA_PROF_SNP_TRIAL);
+    }
     if (c->overlap && c->ev_snp) {
         (void)hipEventRecord(c->ev_snp, s);
         c->snp_marked = true;
@@ -442,7 +449,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     if (snp_pass_can_stash(M, P, 1)) {
         const char *st = std::getenv("VILMA_TILE_SUMS");        // =0: always delta_kernel (A/B)
         if (!(st && st[0] == '0'))
-            rc |= dev_alloc(c, &c->sum_partials, tile_sums_elems(N, A * M, 2));
+            rc |= dev_alloc(c, &c->sum_partials, tile_sums_elems(N, A, M, 2));
     }
     // per-wave rows plus the scratch rows of every pass of the column reduction (exact)
     rc |= dev_alloc(c, &c->delta_partials,
@@ -909,16 +916,14 @@ int vilma_trial_sums(vilma_ctx *c, void *stream, double *sums_a_dev, double *sum
     hipStream_t s = (hipStream_t)stream;
     // the rows depend on the trial's per-SNP pass alone: reduce them beside its LD product
     hipStream_t q = side_begin(c, s);
-    const int AM = c->A * c->M;
-    const int64_t rows_elems = (int64_t)snp_tile_grid(c->N) * AM;
-    double *scratch = c->sum_partials + 2 * rows_elems;
+    const int64_t rows_elems = (int64_t)snp_sum_rows(c->N, c->A) * c->A * c->M;
     if (sums_b_dev && sums_b_dev > sums_a_dev) {
-        // both candidates in one launch sequence
-        launch_tile_sums(c->sum_partials, c->N, AM, 2, scratch, sums_a_dev, sums_b_dev - sums_a_dev, q);
+        // both candidates in one launch
+        launch_tile_sums(c->sum_partials, c->N, c->A, c->M, 2, sums_a_dev, sums_b_dev - sums_a_dev, q);
     } else {
-        launch_tile_sums(c->sum_partials, c->N, AM, 1, scratch, sums_a_dev, 0, q);
+        launch_tile_sums(c->sum_partials, c->N, c->A, c->M, 1, sums_a_dev, 0, q);
         if (sums_b_dev)
-            launch_tile_sums(c->sum_partials + rows_elems, c->N, AM, 1, scratch, sums_b_dev, 0, q);
+            launch_tile_sums(c->sum_partials + rows_elems, c->N, c->A, c->M, 1, sums_b_dev, 0, q);
     }
     side_end(c, s, q);
     HIPCHK(c, hipGetLastError());

@@ -197,8 +197,8 @@ struct vilma_ctx {
     struct Pending { hipEvent_t e0, e1; int kind; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[VILMA_PROF_KINDS] = {0, 0, 0};
-    int64_t prof_launches[VILMA_PROF_KINDS] = {0, 0, 0};
+    double prof_ms[VILMA_PROF_KINDS] = {0, 0, 0, 0, 0, 0};
+    int64_t prof_launches[VILMA_PROF_KINDS] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace vilma_detail {

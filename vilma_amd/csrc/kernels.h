@@ -136,14 +136,16 @@ void launch_decide(int P, int check_convergence, const double *totals, const dou
 // ns = 2: a beta trial at the two step sizes a.step / a.step2, second candidate into the *2 outputs
 void launch_snp_pass(const SnpKernelArgs &a, bool blend, int ns, hipStream_t s);
 int snp_pass_grid(int64_t N);       // workgroups of the thread-per-SNP kernels (256 SNPs each)
-int snp_tile_grid(int64_t N);       // workgroups (tiles of 64 SNPs) of launch_snp_pass = rows of its partials
+int snp_tile_grid(int64_t N);       // workgroups of launch_snp_pass (each loops over tiles of 64 SNPs) = rows of its partials
 // can launch_snp_pass deliver the responsibility sums of ns candidates (LDS stash fits)?
 bool snp_pass_can_stash(int M, int P, int ns);
-// doubles to allocate for SnpKernelArgs::sum_partials (rows + reduction scratch), and the reduction
-int64_t tile_sums_elems(int64_t N, int AM, int ns);
-// (layout of the buffer: [candidate A rows][candidate B rows][reduction scratch for two])
-void launch_tile_sums(const double *tile_rows, int64_t N, int AM, int ns, double *scratch,
-                      double *out, int64_t out_zstride, hipStream_t s);
+// rows per candidate of SnpKernelArgs::sum_partials ([candidate][row][A*M]): one per workgroup with
+// a single annotation, one per tile otherwise; doubles to allocate; and the reduction of the rows
+// (candidate z's sums to out + z * out_zstride)
+int snp_sum_rows(int64_t N, int A);
+int64_t tile_sums_elems(int64_t N, int A, int M, int ns);
+void launch_tile_sums(const double *rows_dev, int64_t N, int A, int M, int ns, double *out,
+                      int64_t out_zstride, hipStream_t s);
 
 // keep = true: default cache policy (the stream is read again by launch_ld_rowsum right after);
 // false: non-temporal.  pool1 != nullptr: two right-hand sides per pass over U.

@@ -966,9 +966,10 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 
 // --------------------------------------------------------------------------------------------
 // fused per-SNP pass.  A workgroup of four waves takes a TILE of 64 SNPs (lane = SNP, coalesced
-// along the SNP axis of vi_mu [M][P][N]); the waves split the mixture components between them in
-// batches of KB (batch b belongs to wave b % 4), so the per-component tables stay wave-uniform
-// (scalar loads) while a small shard still gets four times the waves of a thread-per-SNP layout.
+// along the SNP axis of vi_mu [M][P][N]); the waves split the mixture
+// components of the tile between them (wave w owns components [w Q, (w+1) Q), Q = ceil(M / 4)), so
+// the per-component tables stay wave-uniform (scalar loads) while a small shard still gets four
+// times the waves of a thread-per-SNP layout.
 //
 // Softmax over components against a FIXED shift.  Responsibilities delta_k ~ exp(u_k),
 // u_k = 0.5 (quad_k - log det Lam_k) + lh_k, are accumulated as e_k = w_k exp(a_k - s) with
@@ -985,48 +986,62 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 // [min w, M max w].  The decision is uniform over the workgroup and depends on the data only, so
 // results are reproducible.  In the KL terms the log-determinants of fast_delta_kl and
 // fast_beta_kl cancel, so their sum needs only quad_k and tr(Prec_k Sig_k).
+//
 // --------------------------------------------------------------------------------------------
 #define SNP_THREADS 256
-#define SNP_TILE 64
+#ifndef SNP_SPLIT
+#define SNP_SPLIT 4                 // waves sharing a tile's components (1: experiment, no stash)
+#endif
+#define SNP_TILE (SNP_THREADS / SNP_SPLIT)
 #ifndef KU
 #define KU 4
 #endif
 
 int snp_pass_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
-int snp_tile_grid(int64_t N) { return (int)((N + SNP_TILE - 1) / SNP_TILE); }
+// workgroups (= tiles) of launch_snp_pass = rows of its partials
+int snp_tile_grid(int64_t N) { return (int)((N + 63) / 64); }
+int snp_sum_rows(int64_t N, int A) { (void)A; return snp_tile_grid(N); }
 
-static inline int snp_kb(int P) { return P <= 2 ? KU : (KU > 2 ? 2 : KU); }
-// stash slots per wave: components a wave can own (whole batches)
-static inline int snp_slots(int M, int P) {
-    const int kb = snp_kb(P), nb = (M + kb - 1) / kb;
-    return (nb + 3) / 4 * kb;
-}
-// accumulators a wave hands to wave 0 per candidate: Z, Skl, Sip, amax, Sm[P], S2[P]
-static inline int snp_nacc(int P) { return 4 + 2 * P; }
+// components per wave = stash slots per wave
+static inline int snp_slots(int M) { return (M + 3) / 4; }
+// accumulators a wave hands to wave 0 per candidate: Skl, Sip, Sm[P], S2[P]
+static inline int snp_nacc(int P) { return 2 + 2 * P; }
 size_t snp_pass_lds_bytes(int M, int P, int ns, bool stash) {
-    size_t b = (size_t)3 * ns * snp_nacc(P) * SNP_TILE * sizeof(double);      // waves 1..3 -> wave 0
-    b += (size_t)(2 * ns + 1) * SNP_TILE * sizeof(double);                    // 1/Z, shift, retry flag
-    if (stash) b += (size_t)snp_slots(M, P) * ns * SNP_THREADS * sizeof(double);
-    return b;
+    const size_t zx = (size_t)4 * ns * 2 * SNP_TILE * sizeof(double);         // every wave's Z, max a
+    const size_t hand = (size_t)3 * ns * snp_nacc(P) * SNP_TILE * sizeof(double);   // waves 1..3 -> 0
+    const size_t st = stash ? (size_t)snp_slots(M) * ns * SNP_THREADS * sizeof(double) : 0;
+    return zx + std::max(hand, st);      // the hand-over reuses the stash once the sums are formed
 }
-// The stash is used when two workgroups still fit a CU's 160 KB of LDS (one is not enough to hide
-// the pass's latencies: profiles/r02s_ab_snp_pass_occupancy.txt); beyond that (M above ~48 with
-// two candidates, ~100 with one) the sums come from delta_kernel as before.
+// The stash is used when it leaves room for at least two workgroups in a CU's 160 KB of LDS (one
+// is not enough to hide the pass's latencies: profiles/r02s_ab_snp_pass_occupancy.txt); beyond
+// that the sums come from delta_kernel as before.
 bool snp_pass_can_stash(int M, int P, int ns) {
-    return snp_pass_lds_bytes(M, P, ns, true) <= (size_t)80 * 1024;
+    return SNP_SPLIT == 4 && snp_pass_lds_bytes(M, P, ns, true) <= (size_t)78 * 1024;
 }
 
 // sum over the 64 lanes of 8 values at once (halving butterfly, DPP / permlane moves only): the
-// total of value `row` ends up in the lanes with (lane & 7) == 0 of its lane group
+// total of value `row` ends up in every lane whose bits 5..3 spell `row`
 static __device__ __forceinline__ double tile_sum8(const double (&p)[8], int lane, int &row) {
     return sym_rowsum8(p, lane, row);
 }
 
+#ifndef SNP_MIN_WAVES
+#define SNP_MIN_WAVES 2
+#endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
+// store of the wave to be acknowledged (vmcnt(0)): with the pass's vi_mu stores in flight that is
+// microseconds per barrier, and a tile has three.  Nothing in this kernel is handed between
+// waves through global memory.
+static __device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH>
-__global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelArgs a) {
+__global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES) void snp_pass_kernel(const SnpKernelArgs a) {
     static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
     constexpr int NT = 2 * P + 2;
-    constexpr int NACC = 4 + 2 * P;
+    constexpr int NTP = (NT + 7) / 8 * 8;
+    constexpr int NACC = 2 + 2 * P;
     constexpr int KB = P <= 2 ? KU : (KU > 2 ? 2 : KU);
     extern __shared__ double lds[];
     PRED_EXIT(a.pred);
@@ -1034,15 +1049,19 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     const int64_t N64 = N;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = blockIdx.x * SNP_TILE + lane;
+    // this wave's components
+    const int Q = SNP_SPLIT == 4 ? (M + 3) / 4 : M;
+    const int kbeg = SNP_SPLIT == 4 ? w * Q : 0, kend = min(M, kbeg + Q);
+    const int rowid = SNP_SPLIT == 4 ? blockIdx.x : blockIdx.x * 4 + w;     // row of the partials
+    const int nrows = SNP_SPLIT == 4 ? gridDim.x : (N + 63) / 64;
+    // LDS: [4 waves][NS][2][64] Z and max a | stash [Q][NS][256], later the hand-over [3][NS][NACC][64]
+    double *zx_lds = lds;
+    double *stash = zx_lds + 4 * NS * 2 * SNP_TILE;
+    double *hand_lds = stash;
+
+    const int i = SNP_SPLIT == 4 ? blockIdx.x * 64 + lane : blockIdx.x * 256 + threadIdx.x;
     const bool live = i < N;
     const int ii = live ? i : N - 1;
-    // LDS: [3][NS][NACC][64] partials | [NS][64] 1/Z | [NS][64] shift | [64] retry | stash
-    double *part_lds = lds;
-    double *invz_lds = part_lds + 3 * NS * NACC * SNP_TILE;
-    double *shift_lds = invz_lds + NS * SNP_TILE;
-    double *retry_lds = shift_lds + NS * SNP_TILE;
-    double *stash = retry_lds + SNP_TILE;
 
     double d[P], se[P], adj[P], sld[P], g[P];
 #pragma unroll
@@ -1070,11 +1089,6 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
     mu_out[0] = a.mu_out;
     if (NS == 2) { step[NS - 1] = a.step2; mu_out[NS - 1] = a.mu_out2; }
 
-    // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
-    // buffered: the loads of batch b+1 are issued BEFORE batch b is folded in and its new vi_mu
-    // stored.  On gfx9 loads and stores retire through one in-order counter (vmcnt), so a wave that
-    // stores and then loads waits for its own stores to reach HBM before it sees the loaded data;
-    // with the next loads ahead of the stores it only ever waits for loads.
     const const_tab prec_tab = as_table(a.prec);
     const const_tab lh_tab = as_table(a.lh);          // one annotation: the row is wave-uniform
     // tables of a whole batch are fetched up front too (P <= 2: 5 doubles per component fit the
@@ -1088,8 +1102,12 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
         for (int c = 0; c < NS; ++c) shift[c] = s0;
     }
 
-    // with several annotations the log-weight row differs per lane: those (vector) loads travel
-    // with the vi_mu batch, ahead of the previous batch's stores
+    // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
+    // buffered: the loads of batch b+1 are issued BEFORE batch b is folded in and its new vi_mu
+    // stored.  On gfx9 loads and stores retire through one in-order counter (vmcnt), so a wave that
+    // stores and then loads waits for its own stores to reach HBM before it sees the loaded data;
+    // with the next loads ahead of the stores it only ever waits for loads.  With several
+    // annotations the log-weight row differs per lane: those (vector) loads travel with the batch.
     auto fetch = [&](double (&dst)[KB][P], double (&lhv)[KB], int k0) {
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
@@ -1099,7 +1117,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
             lhv[kk] = ONE_ANNOT ? 0.0 : lh[kc];
         }
     };
-    auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0, int slot0) {
+    auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0) {
         double prt[TAB_AHEAD ? KB : 1][P][P], lht[TAB_AHEAD ? KB : 1];
         if (TAB_AHEAD) {
 #pragma unroll
@@ -1113,7 +1131,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
             const int k = k0 + kk;
-            if (k >= M) break;
+            if (k >= kend) break;                      // wave-uniform
             double pr[P][P], lam[P][P], sig[P][P], told[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -1175,12 +1193,12 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                     Sm[c][p] = fma(e, mun[p], Sm[c][p]);
                     S2[c][p] = fma(e, sig[p][p] + mun[p] * mun[p], S2[c][p]);
                 }
-                if (STASH) stash[((slot0 + kk) * NS + c) * SNP_THREADS + threadIdx.x] = e;
+                if (STASH) stash[((k - kbeg) * NS + c) * SNP_THREADS + threadIdx.x] = e;
             }
         }
     };
 
-    double invZ[NS];
+    double invZ[NS], Zt[NS];
     for (int attempt = 0;; ++attempt) {
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
@@ -1188,82 +1206,137 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
 #pragma unroll
             for (int p = 0; p < P; ++p) { Sm[c][p] = 0.0; S2[c][p] = 0.0; }
         }
-        // this wave's batches: b = w, w + 4, ...; its j-th batch covers stash slots j*KB ...
         double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
-        fetch(bufA, lhA, w * KB);
-        for (int j = 0;; j += 2) {
-            const int k0 = (w + 4 * j) * KB, k1 = k0 + 4 * KB;
-            fetch(bufB, lhB, k1);              // past the end the clamped loads re-read component M-1
-            fold(bufA, lhA, k0, j * KB);
-            if (k1 >= M) break;                // wave-uniform
-            fetch(bufA, lhA, k1 + 4 * KB);
-            fold(bufB, lhB, k1, (j + 1) * KB);
-            if (k1 + 4 * KB >= M) break;
+        fetch(bufA, lhA, kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * KB) {
+            fetch(bufB, lhB, k0 + KB);         // past the end the clamped loads re-read component M-1
+            fold(bufA, lhA, k0);
+            if (k0 + KB >= kend) break;        // wave-uniform
+            fetch(bufA, lhA, k0 + 2 * KB);
+            fold(bufB, lhB, k0 + KB);
         }
-        // waves 1..3 hand their partial sums to wave 0, which adds them in wave order
-        if (w > 0) {
-            double *dst = part_lds + (w - 1) * NS * NACC * SNP_TILE + lane;
+        // every wave publishes its part of the normaliser and its largest logit; every wave adds the
+        // four parts in wave order, so all of them hold the same Z and take the same decision
+        if (SNP_SPLIT == 4) {
 #pragma unroll
             for (int c = 0; c < NS; ++c) {
-                double *dc = dst + c * NACC * SNP_TILE;
-                dc[0 * SNP_TILE] = Z[c]; dc[1 * SNP_TILE] = Skl[c]; dc[2 * SNP_TILE] = Sip[c];
-                dc[3 * SNP_TILE] = amax[c];
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    dc[(4 + p) * SNP_TILE] = Sm[c][p];
-                    dc[(4 + P + p) * SNP_TILE] = S2[c][p];
-                }
+                zx_lds[((w * NS + c) * 2 + 0) * 64 + lane] = Z[c];
+                zx_lds[((w * NS + c) * 2 + 1) * 64 + lane] = amax[c];
             }
+            lds_barrier();
         }
-        __syncthreads();
-        if (w == 0) {
-            bool bad = false;
-#pragma unroll
-            for (int c = 0; c < NS; ++c) {
-#pragma unroll
-                for (int ww = 0; ww < 3; ++ww) {
-                    const double *sc = part_lds + (ww * NS + c) * NACC * SNP_TILE + lane;
-                    Z[c] += sc[0 * SNP_TILE]; Skl[c] += sc[1 * SNP_TILE]; Sip[c] += sc[2 * SNP_TILE];
-                    amax[c] = fmax(amax[c], sc[3 * SNP_TILE]);
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        Sm[c][p] += sc[(4 + p) * SNP_TILE];
-                        S2[c][p] += sc[(4 + P + p) * SNP_TILE];
-                    }
-                }
-                const bool ok = Z[c] >= 1e-150 && Z[c] <= 1e150;      // false for NaN too
-                // a tile is redone at most once: with the exact maximum as the shift Z is in range
-                // unless the problem itself is not finite
-                const bool redo = !ok && attempt == 0 && amax[c] > NEG_INF && amax[c] < -NEG_INF;
-                bad = bad || redo;
-                invz_lds[c * SNP_TILE + lane] = 1.0 / Z[c];
-                shift_lds[c * SNP_TILE + lane] = redo ? amax[c] : shift[c];
-            }
-            const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
-            if (lane == 0) retry_lds[0] = any_bad ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        const bool retry = retry_lds[0] != 0.0;
+        bool bad = false;
+        double amx[NS];
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
-            invZ[c] = invz_lds[c * SNP_TILE + lane];
-            if (retry) shift[c] = shift_lds[c * SNP_TILE + lane];
+            double z = SNP_SPLIT == 4 ? zx_lds[((0 * NS + c) * 2 + 0) * 64 + lane] : Z[c];
+            double m = SNP_SPLIT == 4 ? zx_lds[((0 * NS + c) * 2 + 1) * 64 + lane] : amax[c];
+#pragma unroll
+            for (int ww = 1; ww < SNP_SPLIT; ++ww) {
+                z += zx_lds[((ww * NS + c) * 2 + 0) * 64 + lane];
+                m = fmax(m, zx_lds[((ww * NS + c) * 2 + 1) * 64 + lane]);
+            }
+            Zt[c] = z;
+            amx[c] = m;
+            const bool ok = z >= 1e-150 && z <= 1e150;               // false for NaN too
+            // a tile is redone at most once: with the exact maximum as the shift Z is in range
+            // unless the problem itself is not finite
+            bad = bad || (!ok && attempt == 0 && m > NEG_INF && m < -NEG_INF);
         }
+        const bool retry = __builtin_amdgcn_ballot_w64(bad) != 0;     // the same in all four waves
         if (!retry) break;
-        __syncthreads();                          // part_lds / retry_lds are rewritten next round
+        if (SNP_SPLIT != 4) { // (experiment build: waves are independent)
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                const bool ok = Zt[c] >= 1e-150 && Zt[c] <= 1e150;
+                if (!ok && amx[c] > NEG_INF && amx[c] < -NEG_INF) shift[c] = amx[c];
+            }
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const bool ok = Zt[c] >= 1e-150 && Zt[c] <= 1e150;
+            if (!ok && amx[c] > NEG_INF && amx[c] < -NEG_INF) shift[c] = amx[c];
+        }
+        lds_barrier();                          // zx_lds and the stash are rewritten next round
     }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) invZ[c] = 1.0 / Zt[c];
 
-    if (w == 0) {
+    if (STASH) {
+        // responsibility sums of the tile: delta_k = max(e_k / Z, 1e-100) (invert_nat_cat_2D's clamp,
+        // numerics.py:192-194), summed over the tile's SNPs per annotation, for this wave's
+        // components and every candidate; one row of partials per tile:
+        // [candidate][tile][annotation][component]
+        const int A = a.A;
+        const int ann = ONE_ANNOT ? 0 : a.annot[ii];
+        const int AM = A * M;
+        for (int c = 0; c < NS; ++c) {
+            double *prow = a.sum_partials + ((int64_t)c * gridDim.x + blockIdx.x) * AM;
+            for (int s0 = 0; s0 < Q; s0 += 8) {
+                double e8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int slot = s0 + u;
+                    const bool have = kbeg + slot < kend && slot < Q;
+                    const double e = have ? stash[(slot * NS + c) * SNP_THREADS + threadIdx.x] : 0.0;
+                    e8[u] = (live && have) ? fmax(e * invZ[c], 1e-100) : 0.0;
+                }
+                if (ONE_ANNOT) {
+                    int row;
+                    const double tot = tile_sum8(e8, lane, row);
+                    const int k = kbeg + s0 + row;
+                    if ((lane & 7) == 0 && s0 + row < Q && k < kend) prow[k] = tot;
+                } else {
+                    for (int aa = 0; aa < A; ++aa) {
+                        double m8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) m8[u] = ann == aa ? e8[u] : 0.0;
+                        int row;
+                        const double tot = tile_sum8(m8, lane, row);
+                        const int k = kbeg + s0 + row;
+                        if ((lane & 7) == 0 && s0 + row < Q && k < kend) prow[(int64_t)aa * M + k] = tot;
+                    }
+                }
+            }
+        }
+        lds_barrier();                          // the stash is dead: it carries the hand-over now
+    }
+    // waves 1..3 hand their remaining sums to wave 0, which adds them in wave order
+    if (SNP_SPLIT == 4 && w > 0) {
+        double *dst = hand_lds + (w - 1) * NS * NACC * SNP_TILE + lane;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            double *dc = dst + c * NACC * SNP_TILE;
+            dc[0 * SNP_TILE] = Skl[c]; dc[1 * SNP_TILE] = Sip[c];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                dc[(2 + p) * SNP_TILE] = Sm[c][p];
+                dc[(2 + P + p) * SNP_TILE] = S2[c][p];
+            }
+        }
+    }
+    if (SNP_SPLIT == 4) lds_barrier();
+    if (SNP_SPLIT != 4 || w == 0) {
         // per-SNP results and the tile's contributions to the objective sums
         const bool owner = live;
         double mpost[P];
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
+#pragma unroll
+            for (int ww = 0; ww < SNP_SPLIT - 1; ++ww) {
+                const double *sc = hand_lds + (ww * NS + c) * NACC * SNP_TILE + lane;
+                Skl[c] += sc[0 * SNP_TILE]; Sip[c] += sc[1 * SNP_TILE];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    Sm[c][p] += sc[(2 + p) * SNP_TILE];
+                    S2[c][p] += sc[(2 + P + p) * SNP_TILE];
+                }
+            }
             double *m_out = c == 0 ? a.m_out : a.m_out2, *v_out = c == 0 ? a.v_out : a.v_out2;
             double *pool_out = c == 0 ? a.pool_out : a.pool_out2;
             double *lse_out = c == 0 ? a.lse_out : a.lse_out2;
-            const double lse = shift[c] + log(Z[c]);
-            constexpr int NTP = (NT + 7) / 8 * 8;
+            const double lse = shift[c] + log(Zt[c]);
             double vals[NTP];
 #pragma unroll
             for (int t = 0; t < NTP; ++t) vals[t] = 0.0;
@@ -1284,7 +1357,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
             vals[2 * P] = owner ? (Skl[c] * invZ[c] - lse) : 0.0;
             vals[2 * P + 1] = owner ? 0.5 * Sip[c] * invZ[c] : 0.0;
             // candidate c's columns sit behind the first candidate's (and the 6 statistics columns)
-            double *col = a.partials + (int64_t)c * (NT + 6) * gridDim.x + blockIdx.x;
+            double *col = a.partials + (int64_t)c * (NT + 6) * nrows + rowid;
 #pragma unroll
             for (int h = 0; h < NTP / 8; ++h) {
                 double p8[8];
@@ -1292,7 +1365,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                 for (int t = 0; t < 8; ++t) p8[t] = vals[8 * h + t];
                 int row;
                 const double tot = tile_sum8(p8, lane, row);
-                if ((lane & 7) == 0 && 8 * h + row < NT) col[(int64_t)(8 * h + row) * gridDim.x] = tot;
+                if ((lane & 7) == 0 && 8 * h + row < NT) col[(int64_t)(8 * h + row) * nrows] = tot;
             }
         }
         // Convergence statistics of real_posterior_mean (variational_inference.py:374-382, 292-314)
@@ -1317,51 +1390,9 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const double s = c < 3 ? wave_sum(dv[c]) : wave_max(dv[c]);
-                if (lane == 0) a.partials[(int64_t)(NT + c) * gridDim.x + blockIdx.x] = s;
-            }
-        }
-    }
-
-    if (STASH) {
-        // responsibility sums of the tile: delta_k = max(e_k / Z, 1e-100) (invert_nat_cat_2D's clamp,
-        // numerics.py:192-194), summed over the tile's SNPs per annotation, for this wave's
-        // components and every candidate; row = tile, [candidate][annotation][component]
-        const int A = a.A;
-        const int ann = ONE_ANNOT ? 0 : a.annot[ii];
-        const int nslots = ((M + KB - 1) / KB + 3) / 4 * KB;
-        const int AM = A * M;
-        for (int c = 0; c < NS; ++c) {
-            double *prow = a.sum_partials + ((int64_t)c * gridDim.x + blockIdx.x) * AM;
-            for (int s0 = 0; s0 < nslots; s0 += 8) {
-                double e8[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int slot = s0 + u;
-                    // slot -> component: batch j = slot / KB of this wave is global batch w + 4 j
-                    const int k = (w + 4 * (slot / KB)) * KB + (slot % KB);
-                    const bool have = slot < nslots && k < M;
-                    const double e = have ? stash[(slot * NS + c) * SNP_THREADS + threadIdx.x] : 0.0;
-                    e8[u] = (live && have) ? fmax(e * invZ[c], 1e-100) : 0.0;
-                }
-                if (ONE_ANNOT) {
-                    int row;
-                    const double tot = tile_sum8(e8, lane, row);
-                    const int slot = s0 + row;
-                    const int k = (w + 4 * (slot / KB)) * KB + (slot % KB);
-                    if ((lane & 7) == 0 && slot < nslots && k < M) prow[k] = tot;
-                } else {
-                    for (int aa = 0; aa < A; ++aa) {
-                        double m8[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) m8[u] = ann == aa ? e8[u] : 0.0;
-                        int row;
-                        const double tot = tile_sum8(m8, lane, row);
-                        const int k = (w + 4 * ((s0 + row) / KB)) * KB + ((s0 + row) % KB);
-                        if ((lane & 7) == 0 && s0 + row < nslots && k < M) prow[(int64_t)aa * M + k] = tot;
-                    }
-                }
+            for (int q = 0; q < 6; ++q) {
+                const double t = q < 3 ? wave_sum(dv[q]) : wave_max(dv[q]);
+                if (lane == 0) a.partials[(int64_t)(NT + q) * nrows + rowid] = t;
             }
         }
     }
@@ -1369,7 +1400,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_pass_kernel(const SnpKernelAr
 
 template <int P, bool BLEND, bool ONE_ANNOT, int NS>
 static void launch_snp_pass_s(const SnpKernelArgs &a, bool stash, hipStream_t s) {
-    const dim3 grid(snp_tile_grid(a.N)), block(SNP_THREADS);
+    const dim3 grid(SNP_SPLIT == 4 ? snp_tile_grid(a.N) : snp_pass_grid(a.N)), block(SNP_THREADS);
     const size_t lds = snp_pass_lds_bytes(a.M, P, NS, stash);
     if (stash) {
         auto kern = snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true>;
@@ -1629,16 +1660,37 @@ void launch_delta_sums(const DeltaArgs &a, double *sums_out, hipStream_t s) {
 
 void launch_delta_write(const DeltaArgs &a, hipStream_t s) { launch_delta_any<true>(a, s); }
 
-// Responsibility sums from the per-tile rows a stashing snp_pass left behind ([candidate][tile][AM],
-// launch_snp_pass): candidate z's column sums go to out + z * out_zstride.
-int64_t tile_sums_elems(int64_t N, int AM, int ns) {
-    const int64_t rows = snp_tile_grid(N);
-    return (int64_t)ns * (rows + reduce_cols_scratch_rows(rows)) * AM;
+// Responsibility sums from the partial rows a stashing snp_pass left behind ([candidate][row][AM],
+// launch_snp_pass): one workgroup per (column, candidate) adds the rows in a fixed order.  The rows
+// were written a moment ago by the pass; a column is rows x 8 B spread over rows lines.
+__global__ __launch_bounds__(256) void tile_sums_kernel(const double *__restrict__ in, int rows, int AM,
+                                                         double *__restrict__ out, int64_t out_zstride,
+                                                         const int *pred) {
+    __shared__ double sh[4];
+    PRED_EXIT(pred);
+    const int col = blockIdx.x, z = blockIdx.y;
+    const double *src = in + (int64_t)z * rows * AM + col;
+    double acc = 0.0;
+    for (int r0 = threadIdx.x; r0 < rows; r0 += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)min(r0 + u * 256, rows - 1) * AM];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (r0 + u * 256 < rows) ? t[u] : 0.0;
+        acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(int64_t)z * out_zstride + col] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-void launch_tile_sums(const double *tile_rows, int64_t N, int AM, int ns, double *scratch,
-                      double *out, int64_t out_zstride, hipStream_t s) {
-    const int rows = snp_tile_grid(N);
-    reduce_cols(tile_rows, rows, AM, scratch, out, s, ns, (int64_t)rows * AM, out_zstride);
+int64_t tile_sums_elems(int64_t N, int A, int M, int ns) {
+    return (int64_t)ns * snp_sum_rows(N, A) * A * M;
+}
+void launch_tile_sums(const double *rows_dev, int64_t N, int A, int M, int ns, double *out,
+                      int64_t out_zstride, hipStream_t s) {
+    hipLaunchKernelGGL(tile_sums_kernel, dim3(A * M, ns), dim3(256), 0, s, rows_dev,
+                       snp_sum_rows(N, A), A * M, out, out_zstride, g_pred);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -486,7 +486,8 @@ class HipEngine:
         of stream time, which matters on small shards)."""
         self._check(self.lib.vilma_prof_enable(self.ctx, max(1, int(every)) if on else 0))
 
-    PROF_KINDS = ('ld_sym_kernel', 'ld_eig_fused_kernel', 'ld_sym_kernel_two_rhs')
+    PROF_KINDS = ('ld_sym_kernel', 'ld_eig_fused_kernel', 'ld_sym_kernel_two_rhs',
+                  'snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2')
 
     def prof_read(self, reset=True):
         """{kernel: (milliseconds, launches)} accumulated by the library's HIP events."""
