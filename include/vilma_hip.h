@@ -381,9 +381,10 @@ typedef struct {
 #define VILMA_SWEEP_LOOKAHEAD 2   /* the caller promises to call vilma_sweep again: the next sweep
                                      may be queued (and decided on the device) before this call
                                      returns */
-#define VILMA_SWEEP_VETO 4        /* a stage already running ahead must not proceed if no posterior
-                                     mean moved in the sweep before it (optimize() would stop) */
-#define VILMA_SWEEP_VETO_NEXT 8   /* ... the same for the stage queued by this call */
+#define VILMA_SWEEP_VETO 4        /* the sweep queued ahead by this call must not proceed if no
+                                     posterior mean moved in THIS sweep (optimize() stops then,
+                                     variational_inference.py:374-382): checked on the device */
+#define VILMA_SWEEP_VETO_NEXT 8   /* reserved */
 #define VILMA_SWEEP_VERBOSE 16    /* record events; all-reduce the convergence maxima as well */
 
 /* One outer iteration: _optimize_step (variational_inference.py:396-410) = _nat_grad_step

@@ -327,6 +327,57 @@ def _sweep_trace(monkeypatch, two_step, lookahead, n_sweeps=35):
     return trace, mu, counts
 
 
+def test_reading_the_state_between_sweeps_queued_ahead(monkeypatch):
+    """A caller that promises another sweep (lookahead) and then reads the state instead gets the
+    state of the sweep that was REPORTED: the library waits for the sweep it queued ahead and puts
+    the reported state back (the vi_mu is still in its buffer, the moments are re-derived), and the
+    fit goes on from there like one that never looked (same L trajectory; the re-derived moments
+    may differ from the originals in the last bit, which shows in the ELBO and the convergence
+    statistics at 1e-15)."""
+    import torch
+    from vilma_amd.synthetic import SyntheticShard, WORKLOADS
+    from vilma_amd.engine import HipEngine
+    from vilma_amd.sharding import Comm
+    from vilma_amd.variational_inference import SweepDriver
+    device = torch.device('cuda', 0)
+
+    def run(peek_at):
+        sh = SyntheticShard(seed=3, **WORKLOADS['tiny']).build(device)
+        sh.finish_init(sh.inv_se2_local)
+        eng = HipEngine(sh.P, sh.N, sh.M, 1)
+        eng.set_snp_data(sh.adj, sh.se, sh.sld, sh.scalings, sh.annot)
+        eng.set_mixture(np.linalg.inv(sh.covs), np.linalg.slogdet(sh.covs)[1])
+        for p in range(sh.P):
+            eng.load_ld(p, sh.ld_blocks_torch(p, device), sh.perm, sh.n_ld, specs=sh.block_specs())
+        drv = SweepDriver()
+        drv._setup_driver(eng, Comm(), sh.P, sh.M, 1, sh.chi_local, sh.rank_local, [sh.N_global],
+                          np.linalg.slogdet(sh.covs)[1], scale_se=False, num_its=100)
+        drv.initialize_from(sh.fake_mu)
+        state, trace, peeks = None, [], {}
+        for k in range(14):
+            state, stats = drv.sweep(state, lookahead=True)
+            trace.append((state['elbo'], tuple(state['L']), tuple(stats)))
+            if k in peek_at:
+                params = drv._params()
+                peeks[k] = (params[0].copy(), params[1].copy(), eng.get_moments()[0].copy(),
+                            drv._objective)
+        mu = eng.get_mu()
+        eng.close()
+        return trace, peeks, mu
+    plain, _, mu_plain = run(())
+    peeked, peeks, mu_peeked = run((3, 4, 9))
+    for a, b in zip(peeked, plain):
+        assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) and a[1] == b[1]
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-8)     # (the max RELATIVE change divides by ~0)
+    np.testing.assert_allclose(mu_peeked, mu_plain, rtol=1e-9, atol=1e-300)
+    # what was read at sweep k is the state after sweep k: the same as a run that stops there
+    for k, (vi_mu, vi_delta, mean, obj) in peeks.items():
+        assert obj == plain[k][0] or abs(obj - plain[k][0]) < 1e-9 * abs(obj)
+        assert np.all(np.isfinite(vi_mu)) and np.all(np.isfinite(vi_delta)) and np.all(np.isfinite(mean))
+    stop, peeks4, _ = run((4,))
+    np.testing.assert_allclose(peeks4[4][0], peeks[4][0], rtol=1e-9, atol=1e-300)
+
+
 def test_two_step_and_lookahead_change_no_bit(monkeypatch):
     """Two line-search steps per device pass and the stage queued ahead of the device's decision
     are pure scheduling: ELBO, L, convergence statistics after every sweep and the final vi_mu are

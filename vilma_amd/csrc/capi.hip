@@ -332,6 +332,7 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
     a.pool_cur = c->pool[cur]; a.m_cur = c->m[cur];
     a.pool_out = c->pool[tr]; a.m_out = c->m[tr]; a.v_out = c->v[tr]; a.lse_out = c->lse[tr];
     a.partials = c->snp_partials;
+    a.pp = nullptr;
     a.lse_ref = c->have_moments ? c->lse[cur] : nullptr;
     a.sum_partials = nullptr;
     a.scal = c->scal; a.snapshot = c->snapshot; a.diff = 0;
@@ -365,11 +366,14 @@ void side_end(vilma_ctx *c, hipStream_t s, hipStream_t used) {
 }
 
 // blend: a beta trial at `step`; with totals2_dev also at `step2` in the same pass (candidate B)
+// phase >= 0: a phase of a sweep queued ahead (device-resident roles, sweep.hip): the kernels take
+// their buffers and step sizes from the context's control block, the host-side roles stay as they are
 int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *totals_dev,
              double *dsum_dev = nullptr, double *dmax_dev = nullptr, double step2 = 0.0,
-             double *totals2_dev = nullptr) {
+             double *totals2_dev = nullptr, int phase = -1) {
     if (ensure_ready(c)) return 1;
-    if (blend && !c->have_moments)
+    const bool queued = phase >= 0;
+    if (blend && !queued && !c->have_moments)
         return fail(c, "vilma_trial_beta needs an accepted evaluation of the current state");
     const bool two = blend && totals2_dev != nullptr;
     SnpKernelArgs a;
@@ -380,7 +384,8 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     const int ns = two ? 2 : 1;
     const bool stash = blend && c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, ns);
     if (stash) a.sum_partials = c->sum_partials;
-    c->tile_sums_ns = stash ? ns : 0;
+    if (!queued) c->tile_sums_ns = stash ? ns : 0;
+    if (queued) set_launch_phase(&c->ctl->phase[phase]);
     {
         // bracketed with the LD product that follows (same sampling tick)
         hipEvent_t e0;
@@ -394,6 +399,7 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
         c->snp_marked = true;
     }
     run_ld(c, s, c->pool[c->mom_ta], two ? c->pool[c->mom_tb] : nullptr, -1);
+    if (queued) set_launch_phase(nullptr);
     const int grid = snp_tile_grid(c->N);
     launch_finalize(c->snp_partials, grid, c->P, c->dot_partials, c->dot_start.data(),
                     totals_dev, a.diff ? dsum_dev : nullptr, a.diff ? dmax_dev : nullptr, s);
@@ -401,12 +407,51 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
         launch_finalize(c->snp_partials + (int64_t)(2 * c->P + 2 + 6) * grid, grid, c->P,
                         c->dot_partials + c->dot_stride, c->dot_start.data(), totals2_dev, nullptr,
                         nullptr, s);
-    c->have_b = two;
+    if (!queued) c->have_b = two;
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
+// the per-tile responsibility sums of the last trial's candidates -> sums_a_dev (, sums_b_dev),
+// beside the trial's LD product when a side stream is available
+void reduce_tile_sums(vilma_ctx *c, hipStream_t s, double *sums_a_dev, double *sums_b_dev) {
+    hipStream_t q = side_begin(c, s);
+    const int64_t rows_elems = (int64_t)snp_sum_rows(c->N, c->A) * c->A * c->M;
+    if (sums_b_dev && sums_b_dev > sums_a_dev) {
+        // both candidates in one launch
+        launch_tile_sums(c->sum_partials, c->N, c->A, c->M, 2, sums_a_dev, sums_b_dev - sums_a_dev, q);
+    } else {
+        launch_tile_sums(c->sum_partials, c->N, c->A, c->M, 1, sums_a_dev, 0, q);
+        if (sums_b_dev)
+            launch_tile_sums(c->sum_partials + rows_elems, c->N, c->A, c->M, 1, sums_b_dev, 0, q);
+    }
+    side_end(c, s, q);
+}
+
 }  // namespace
+
+// the pieces of a sweep queued ahead (sweep.hip); kernels launched by these honour the launch
+// predicate of the calling thread
+int vilma_detail::queue_trial_phase(vilma_ctx *c, hipStream_t s, bool two, double *totals_a,
+                                    double *totals_b, double *sums_a, double *sums_b) {
+    if (evaluate(c, s, true, 0.0, totals_a, nullptr, nullptr, 0.0, two ? totals_b : nullptr,
+                 VILMA_PHASE_TRIAL)) return 1;
+    reduce_tile_sums(c, s, sums_a, two ? sums_b : nullptr);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int vilma_detail::queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, double *dsum,
+                                   double *dmax) {
+    return evaluate(c, s, false, 0.0, totals, dsum, dmax, 0.0, nullptr, VILMA_PHASE_EVAL);
+}
+size_t vilma_detail::prof_pending(vilma_ctx *c) { return c->pending.size(); }
+void vilma_detail::prof_truncate(vilma_ctx *c, size_t mark) {
+    while (c->pending.size() > mark) {
+        c->event_pool.push_back(c->pending.back().e0);
+        c->event_pool.push_back(c->pending.back().e1);
+        c->pending.pop_back();
+    }
+}
 
 extern "C" {
 
@@ -549,6 +594,7 @@ void vilma_destroy(vilma_ctx *c) {
 int vilma_set_snp_data(vilma_ctx *c, const double *adj, const double *se, const double *sld,
                        const double *scalings, const int32_t *annot) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     const size_t b = (size_t)c->P * c->N * sizeof(double);
     HIPCHK(c, hipMemcpy(c->adj, adj, b, hipMemcpyDefault));
     HIPCHK(c, hipMemcpy(c->se, se, b, hipMemcpyDefault));
@@ -561,6 +607,7 @@ int vilma_set_snp_data(vilma_ctx *c, const double *adj, const double *se, const 
 
 int vilma_set_mixture(vilma_ctx *c, const double *prec, const double *log_det) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     HIPCHK(c, hipMemcpy(c->prec, prec, (size_t)c->M * c->P * c->P * sizeof(double), hipMemcpyDefault));
     HIPCHK(c, hipMemcpy(c->log_det, log_det, (size_t)c->M * sizeof(double), hipMemcpyDefault));
     HIPCHK(c, hipMemcpy(c->log_det_host.data(), log_det, (size_t)c->M * sizeof(double), hipMemcpyDefault));
@@ -570,6 +617,7 @@ int vilma_set_mixture(vilma_ctx *c, const double *prec, const double *log_det) {
 
 int vilma_set_tau(vilma_ctx *c, const double *tau) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     for (int p = 0; p < c->P; ++p) {
         if (!(tau[p] > 0.0) || !std::isfinite(tau[p])) return fail(c, "error_scaling must be positive");
         c->tau[p] = tau[p];
@@ -579,6 +627,7 @@ int vilma_set_tau(vilma_ctx *c, const double *tau) {
 
 int vilma_set_hyper(vilma_ctx *c, const double *hyper) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     std::vector<double> lh((size_t)c->A * c->M);
     for (int a = 0; a < c->A; ++a)
         for (int k = 0; k < c->M; ++k) {
@@ -734,6 +783,7 @@ int vilma_ld_bytes(const vilma_ctx *c, int64_t *alg, int64_t *stored) {
 
 int vilma_ld_matvec(vilma_ctx *c, void *stream, int cohort, const double *x, double *y) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (cohort >= c->P) return fail(c, "cohort out of range");
     if (ensure_ready(c)) return 1;
     hipStream_t s = (hipStream_t)stream;
@@ -747,6 +797,7 @@ int vilma_ld_matvec(vilma_ctx *c, void *stream, int cohort, const double *x, dou
 
 int vilma_set_mu(vilma_ctx *c, const double *vi_mu) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(c->mu[c->mu_cur], vi_mu, (size_t)c->M * c->P * c->N * sizeof(double),
                         hipMemcpyDefault));
@@ -756,6 +807,7 @@ int vilma_set_mu(vilma_ctx *c, const double *vi_mu) {
 
 int vilma_get_mu(vilma_ctx *c, double *vi_mu) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(vi_mu, c->mu[c->mu_cur], (size_t)c->M * c->P * c->N * sizeof(double),
                         hipMemcpyDefault));
@@ -764,6 +816,7 @@ int vilma_get_mu(vilma_ctx *c, double *vi_mu) {
 
 int vilma_get_delta(vilma_ctx *c, double *vi_delta) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     HIPCHK(c, hipDeviceSynchronize());
     // the trial vi_mu buffer ([M][P][N] >= [M][N]) is free between evaluations: use it as scratch
@@ -781,6 +834,7 @@ int vilma_get_delta(vilma_ctx *c, double *vi_delta) {
 
 int vilma_get_moments(vilma_ctx *c, double *mean, double *var) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     HIPCHK(c, hipDeviceSynchronize());
     const size_t b = (size_t)c->P * c->N * sizeof(double);
@@ -791,6 +845,7 @@ int vilma_get_moments(vilma_ctx *c, double *mean, double *var) {
 
 int vilma_eval(vilma_ctx *c, void *stream, double *totals_dev) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     c->trial_tainted = false;
     return evaluate(c, (hipStream_t)stream, false, 0.0, totals_dev);
 }
@@ -798,6 +853,7 @@ int vilma_eval(vilma_ctx *c, void *stream, double *totals_dev) {
 int vilma_eval_diff(vilma_ctx *c, void *stream, double *totals_dev, double *out_sum3_dev,
                     double *out_max3_dev) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (!out_sum3_dev || !out_max3_dev) return fail(c, "vilma_eval_diff needs both outputs");
     c->trial_tainted = false;
     return evaluate(c, (hipStream_t)stream, false, 0.0, totals_dev, out_sum3_dev, out_max3_dev);
@@ -806,6 +862,7 @@ int vilma_eval_diff(vilma_ctx *c, void *stream, double *totals_dev, double *out_
 int vilma_eval_given_delta(vilma_ctx *c, void *stream, const double *delta_km_dev,
                            double *totals_dev) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (ensure_ready(c)) return 1;
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     hipStream_t s = (hipStream_t)stream;
@@ -834,6 +891,7 @@ int vilma_get_trial_moments(vilma_ctx *c, double *mean, double *var) {
 
 int vilma_init_state(vilma_ctx *c, void *stream, const double *fake_mu, double *sums_dev) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipDeviceSynchronize());
     // the snapshot buffer ([P][N]) is free until the sweep loop starts: staging for fake_mu
@@ -853,6 +911,7 @@ int vilma_init_state(vilma_ctx *c, void *stream, const double *fake_mu, double *
 
 int vilma_trial_beta(vilma_ctx *c, void *stream, double step, double *totals_dev) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     c->trial_tainted = false;
     return evaluate(c, (hipStream_t)stream, true, step, totals_dev);
 }
@@ -860,6 +919,7 @@ int vilma_trial_beta(vilma_ctx *c, void *stream, double step, double *totals_dev
 int vilma_trial_beta2(vilma_ctx *c, void *stream, double step_a, double step_b,
                       double *totals_a_dev, double *totals_b_dev) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (!totals_a_dev || !totals_b_dev) return fail(c, "vilma_trial_beta2 needs both outputs");
     c->trial_tainted = false;
     return evaluate(c, (hipStream_t)stream, true, step_a, totals_a_dev, nullptr, nullptr, step_b,
@@ -868,6 +928,7 @@ int vilma_trial_beta2(vilma_ctx *c, void *stream, double step_a, double step_b,
 
 int vilma_accept(vilma_ctx *c, int take_mu) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (!c->ready) return fail(c, "nothing to accept");
     if (take_mu < 0 || take_mu > 2) return fail(c, "vilma_accept: take_mu must be 0, 1 or 2");
     if (c->trial_tainted)
@@ -888,6 +949,7 @@ int vilma_accept(vilma_ctx *c, int take_mu) {
 
 int vilma_delta_sums(vilma_ctx *c, void *stream, double *sums_dev, int which) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (which == VILMA_STATE_CURRENT && !c->have_moments)
         return fail(c, "no accepted evaluation of the current state");
     if (which != VILMA_STATE_CURRENT && !c->ready) return fail(c, "no trial state");
@@ -910,28 +972,18 @@ int vilma_trial_sums_available(const vilma_ctx *c) { return c ? c->tile_sums_ns 
 
 int vilma_trial_sums(vilma_ctx *c, void *stream, double *sums_a_dev, double *sums_b_dev) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (c->tile_sums_ns < 1) return fail(c, "the last trial left no per-tile sums (use vilma_delta_sums)");
     if (!sums_a_dev) return fail(c, "vilma_trial_sums: sums_a_dev is required");
     if (sums_b_dev && c->tile_sums_ns < 2) return fail(c, "no second candidate");
-    hipStream_t s = (hipStream_t)stream;
-    // the rows depend on the trial's per-SNP pass alone: reduce them beside its LD product
-    hipStream_t q = side_begin(c, s);
-    const int64_t rows_elems = (int64_t)snp_sum_rows(c->N, c->A) * c->A * c->M;
-    if (sums_b_dev && sums_b_dev > sums_a_dev) {
-        // both candidates in one launch
-        launch_tile_sums(c->sum_partials, c->N, c->A, c->M, 2, sums_a_dev, sums_b_dev - sums_a_dev, q);
-    } else {
-        launch_tile_sums(c->sum_partials, c->N, c->A, c->M, 1, sums_a_dev, 0, q);
-        if (sums_b_dev)
-            launch_tile_sums(c->sum_partials + rows_elems, c->N, c->A, c->M, 1, sums_b_dev, 0, q);
-    }
-    side_end(c, s, q);
+    reduce_tile_sums(c, (hipStream_t)stream, sums_a_dev, sums_b_dev);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
 int vilma_mean_diff(vilma_ctx *c, void *stream, double *out_sum3_dev, double *out_max3_dev) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     hipStream_t s = (hipStream_t)stream;
     hipStream_t q = side_begin(c, s);
@@ -944,6 +996,7 @@ int vilma_mean_diff(vilma_ctx *c, void *stream, double *out_sum3_dev, double *ou
 
 int vilma_snapshot_mean(vilma_ctx *c, void *stream) {
     if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     c->snp_marked = false;      // the snapshot is written on `stream`: a following mean_diff stays there
     launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,

@@ -105,6 +105,7 @@ struct SweepState;      // sweep.hip: the sweep state machine's host-side bookke
 struct vilma_ctx {
     int P = 0, M = 0, A = 0, device = 0;
     SweepState *sw = nullptr;
+    SweepCtl *ctl = nullptr;        // device: the control block of sweeps queued ahead (sweep.hip)
     int64_t N = 0;
     std::string err;
 
@@ -228,5 +229,13 @@ inline void dev_free(void *p) { if (p) (void)hipFree(p); }
 
 // sweep.hip
 void sweep_destroy(vilma_ctx *c);
+// capi.hip, for sweep.hip: one phase of a sweep queued ahead of the decision that assigns the
+// buffers their roles (the kernels read them from c->ctl->phase[] when they start); prof_*: the
+// HIP-event brackets recorded since a mark (dropped when the work turned out dead)
+int queue_trial_phase(vilma_ctx *c, hipStream_t s, bool two, double *totals_a, double *totals_b,
+                      double *sums_a, double *sums_b);
+int queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, double *dsum, double *dmax);
+size_t prof_pending(vilma_ctx *c);
+void prof_truncate(vilma_ctx *c, size_t mark);
 
 }  // namespace vilma_detail

@@ -90,6 +90,57 @@ struct SymCombItem {
 
 struct TauArg { double v[VILMA_MAX_P]; };
 
+// ---- device-resident sweep (sweep.hip): what changes from sweep to sweep lives on the device ----
+// The buffers one phase of a queued sweep works on.  Kernels launched while a phase is set
+// (set_launch_phase) take these instead of the pointers in their arguments, so the host can queue
+// a sweep before it knows which candidate the previous line search accepted.
+struct PhasePtrs {
+    const double *mu_in;
+    double *mu_out, *mu_out2;
+    const double *pool_cur, *m_cur, *lse_ref;
+    double *pool_out, *m_out, *v_out, *lse_out;
+    double *pool_out2, *m_out2, *v_out2, *lse_out2;
+    double step, step2;
+};
+#define VILMA_PHASE_EVAL 0      // the evaluation after the M-step
+#define VILMA_PHASE_TRIAL 1     // the next sweep's beta trial
+struct SweepCtl {
+    int32_t alive;              // 0: every kernel queued under this block exits at once
+    int32_t choice;             // last decision: 1 = candidate A accepted, 2 = B, 0 = none
+    int32_t stage;              // decisions taken since the block was armed
+    int32_t running_none;       // running ELBO change not defined yet (first sweep)
+    int32_t have_prev;          // a sweep has completed on the device since the block was armed
+    int32_t pad;
+    int32_t mu_role[3], mom_role[3];    // buffer indices in the roles current / candidate A / B
+    double L_try;               // L[0] of the queued trial's candidate A (B: L_try * rate)
+    double L0;                  // L[0] after the last accepted line search
+    double obj_start;           // objective the last accepted beta step started from
+    double obj_beta;            // objective of the candidate it accepted
+    double running;             // running ELBO change (after the sweep before the last decision)
+    PhasePtrs phase[2];
+};
+// base pointers of the three buffers of each kind
+struct BufferBases { double *mu[3], *pool[3], *m[3], *v[3], *lse[3]; };
+// The pointers of a phase from the roles at the start of its stage (cur, ta, tb).  The
+// evaluation reads the current vi_mu and writes the moments of role ta; the trial that follows
+// treats those as current (the evaluation is accepted unconditionally), writes candidate A into
+// the old current moments and role ta of vi_mu, candidate B into role tb.
+static __host__ __device__ inline void phase_ptrs(const BufferBases &b, const int32_t (&mu)[3],
+                                                  const int32_t (&mom)[3], int phase, double step,
+                                                  double step2, PhasePtrs &o) {
+    const int cur = phase == VILMA_PHASE_EVAL ? mom[0] : mom[1];      // moments treated as current
+    const int ta = phase == VILMA_PHASE_EVAL ? mom[1] : mom[0];       // ... written as candidate A
+    const int tb = mom[2];
+    o.mu_in = b.mu[mu[0]]; o.mu_out = b.mu[mu[1]]; o.mu_out2 = b.mu[mu[2]];
+    o.pool_cur = b.pool[cur]; o.m_cur = b.m[cur]; o.lse_ref = b.lse[cur];
+    o.pool_out = b.pool[ta]; o.m_out = b.m[ta]; o.v_out = b.v[ta]; o.lse_out = b.lse[ta];
+    o.pool_out2 = b.pool[tb]; o.m_out2 = b.m[tb]; o.v_out2 = b.v[tb]; o.lse_out2 = b.lse[tb];
+    o.step = step; o.step2 = step2;
+}
+// launch attribute of the calling thread like set_launch_predicate: kernels launched while it is
+// set work on *pp's buffers (read on the device when the kernel starts); nullptr = their arguments
+void set_launch_phase(const PhasePtrs *pp);
+
 struct SnpKernelArgs {
     int32_t N, M, A, P;
     const double *mu_in;      // [M][P][N]
@@ -120,6 +171,7 @@ struct SnpKernelArgs {
     double *sum_partials;
     TauArg tau;
     const int *pred;          // filled by the launcher (set_launch_predicate)
+    const PhasePtrs *pp;      // filled by the launcher (set_launch_phase)
 };
 
 // launch attribute of the calling thread: kernels launched while it is set exit at once when
@@ -237,3 +289,20 @@ void launch_mean_diff(const double *m_cur, const double *scalings, double *snaps
                       double *partials, double *out_sum3, double *out_max3, bool compare,
                       hipStream_t s);
 int mean_diff_grid(int64_t PN);
+
+// ---- device-resident sweep: the decision kernel (see kernels.hip) ----
+#define VILMA_SNAP_EXTRA 18     // scalars of the control block behind the result vector in a snapshot
+struct SweepDecideParams {
+    int P, A, M;
+    int check_convergence, have_b, have_sums_b;
+    const double *chi, *tau, *half_rank_log_tau;      // host [P]
+    double rel_tol, abs_tol, rate, l_max;
+    SweepCtl *ctl;
+    double *results;
+    int o_dsum, o_tot, o_ta, o_tb, o_sa, o_sb, o_hyper, n_results;
+    double *lh;
+    const double *counts, *log_det;
+    double *snap;
+    BufferBases bases;
+};
+void launch_sweep_decide(const SweepDecideParams &p, hipStream_t s);

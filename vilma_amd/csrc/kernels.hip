@@ -104,6 +104,10 @@ typedef const v2d __attribute__((address_space(1))) *gd2_ptr;
 // The flag pointer is a per-thread launch attribute (set_launch_predicate), nullptr = always run.
 static thread_local const int *g_pred = nullptr;
 void set_launch_predicate(const int *flag) { g_pred = flag; }
+// Buffers of a queued sweep's phase (device-resident sweep, kernels.h): the LD kernels take their
+// vector pools, the per-SNP pass all of its state pointers and step sizes from *g_phase.
+static thread_local const PhasePtrs *g_phase = nullptr;
+void set_launch_phase(const PhasePtrs *pp) { g_phase = pp; }
 #define PRED_EXIT(pred) do { if ((pred) != nullptr && *(pred) == 0) return; } while (0)
 
 typedef const double __attribute__((address_space(4))) *const_tab;
@@ -116,9 +120,12 @@ struct PoolPairRW { double *p[2]; };
 // is read from pool r and its t' written there; every element of U is loaded once for both.
 template <bool KEEP, int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
-    const LdItem *__restrict__ items, const PoolPairRW pools, const int *pred) {
+    const LdItem *__restrict__ items, const PoolPairRW pools_arg, const int *pred,
+    const PhasePtrs *pp) {
     __shared__ double red[NR][CS_WAVES][128];
     PRED_EXIT(pred);
+    PoolPairRW pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
     const LdItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -191,11 +198,11 @@ void launch_ld_colsum(const LdItem *items, int n_items, double *pool0, double *p
     pp.p[1] = pool1 ? pool1 : pool0;
     const dim3 grid(n_items), block(CS_WAVES * 64);
     if (pool1) {
-        if (keep) hipLaunchKernelGGL((ld_colsum_kernel<true, 2>), grid, block, 0, s, items, pp, g_pred);
-        else hipLaunchKernelGGL((ld_colsum_kernel<false, 2>), grid, block, 0, s, items, pp, g_pred);
+        if (keep) hipLaunchKernelGGL((ld_colsum_kernel<true, 2>), grid, block, 0, s, items, pp, g_pred, g_phase);
+        else hipLaunchKernelGGL((ld_colsum_kernel<false, 2>), grid, block, 0, s, items, pp, g_pred, g_phase);
     } else {
-        if (keep) hipLaunchKernelGGL((ld_colsum_kernel<true, 1>), grid, block, 0, s, items, pp, g_pred);
-        else hipLaunchKernelGGL((ld_colsum_kernel<false, 1>), grid, block, 0, s, items, pp, g_pred);
+        if (keep) hipLaunchKernelGGL((ld_colsum_kernel<true, 1>), grid, block, 0, s, items, pp, g_pred, g_phase);
+        else hipLaunchKernelGGL((ld_colsum_kernel<false, 1>), grid, block, 0, s, items, pp, g_pred, g_phase);
     }
 }
 
@@ -343,11 +350,13 @@ static __device__ __forceinline__ void sym_group_diag(const v2d (&v)[CS_ROWS],
 #endif
 template <int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
-    const SymItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
-    int64_t s_stride, const int *pred) {
+    const SymItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double red[NR][CS_WAVES][128];
     __shared__ double rs_diag[NR][128];
     PRED_EXIT(pred);
+    PoolPair pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
     const SymItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -464,11 +473,13 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
 // order -- with the chunk's y.z partial.  The slab index is wave-uniform; eight loads in flight.
 // blockIdx.y = right-hand side (its own pool, scratch and partials behind the first one's).
 __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
-    const SymCombItem *__restrict__ items, const PoolPairRW pools,
+    const SymCombItem *__restrict__ items, const PoolPairRW pools_arg,
     const double *__restrict__ scratch0, int64_t s_stride, double *__restrict__ dot_partials0,
-    int dot_stride, const int *pred) {
+    int dot_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double dred[4];
     PRED_EXIT(pred);
+    PoolPairRW pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = pp->pool_out2; }
     const int rhs = blockIdx.y;
     const double *__restrict__ xpool = pools.p[rhs];
     double *__restrict__ ypool = pools.p[rhs];
@@ -514,10 +525,10 @@ void launch_ld_sym(const SymItem *items, int n_items, const double *pool0, const
     pp.p[1] = pool1 ? pool1 : pool0;
     if (pool1)
         hipLaunchKernelGGL(ld_sym_kernel<2>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pp,
-                           scratch, s_stride, g_pred);
+                           scratch, s_stride, g_pred, g_phase);
     else
         hipLaunchKernelGGL(ld_sym_kernel<1>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pp,
-                           scratch, s_stride, g_pred);
+                           scratch, s_stride, g_pred, g_phase);
 }
 
 void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0, double *pool1,
@@ -528,7 +539,7 @@ void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0,
     pp.p[0] = pool0;
     pp.p[1] = pool1 ? pool1 : pool0;
     hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items, pool1 ? 2 : 1), dim3(256), 0, s, items,
-                       pp, scratch, s_stride, dot_partials, dot_stride, g_pred);
+                       pp, scratch, s_stride, dot_partials, dot_stride, g_pred, g_phase);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -539,9 +550,11 @@ void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0,
 // --------------------------------------------------------------------------------------------
 template <int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_rowsum_kernel(
-    const RowItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
-    int64_t s_stride, const int *pred) {
+    const RowItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred, const PhasePtrs *pp) {
     PRED_EXIT(pred);
+    PoolPair pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
     const RowItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -581,11 +594,13 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_rowsum_kernel(
 
 // blockIdx.y = right-hand side
 __global__ __launch_bounds__(256) void ld_rowsum_combine_kernel(
-    const RowCombItem *__restrict__ items, const PoolPairRW pools,
+    const RowCombItem *__restrict__ items, const PoolPairRW pools_arg,
     const double *__restrict__ scratch0, int64_t s_stride, double *__restrict__ dot_partials0,
-    int dot_stride, const int *pred) {
+    int dot_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double dred[4];
     PRED_EXIT(pred);
+    PoolPairRW pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = pp->pool_out2; }
     const int rhs = blockIdx.y;
     const double *__restrict__ xpool = pools.p[rhs];
     double *__restrict__ ypool = pools.p[rhs];
@@ -620,10 +635,10 @@ void launch_ld_rowsum(const RowItem *items, int n_items, const double *pool0, co
     pp.p[1] = pool1 ? pool1 : pool0;
     if (pool1)
         hipLaunchKernelGGL(ld_rowsum_kernel<2>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pp,
-                           scratch, s_stride, g_pred);
+                           scratch, s_stride, g_pred, g_phase);
     else
         hipLaunchKernelGGL(ld_rowsum_kernel<1>, dim3(n_items), dim3(CS_WAVES * 64), 0, s, items, pp,
-                           scratch, s_stride, g_pred);
+                           scratch, s_stride, g_pred, g_phase);
 }
 
 void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *pool0, double *pool1,
@@ -634,7 +649,7 @@ void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *poo
     pp.p[0] = pool0;
     pp.p[1] = pool1 ? pool1 : pool0;
     hipLaunchKernelGGL(ld_rowsum_combine_kernel, dim3(n_items, pool1 ? 2 : 1), dim3(256), 0, s,
-                       items, pp, scratch, s_stride, dot_partials, dot_stride, g_pred);
+                       items, pp, scratch, s_stride, dot_partials, dot_stride, g_pred, g_phase);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -773,10 +788,12 @@ static __device__ __forceinline__ void eig_fused_body(
 // tallest (172 VGPRs: 2 waves per SIMD instead of 3-4).
 template <int R, int NR>
 __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_kernel(
-    const EigItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
-    int64_t s_stride, const int *pred) {
+    const EigItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double red[2][EIG_THREADS / 64][EIG_RED_SLOTS];
     PRED_EXIT(pred);
+    PoolPair pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
     const EigItem it = items[blockIdx.x];
     eig_fused_body<R, NR>(it, pools, scratch, s_stride, red);
 }
@@ -787,10 +804,12 @@ __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_kernel(
 // instead of four; launch_ld_eig_fused_all is used below EIG_MERGE_BELOW items.
 template <int NR>
 __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_all_kernel(
-    const EigItem *__restrict__ items, const PoolPair pools, double *__restrict__ scratch,
-    int64_t s_stride, const int *pred) {
+    const EigItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double red[2][EIG_THREADS / 64][EIG_RED_SLOTS];
     PRED_EXIT(pred);
+    PoolPair pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
     const EigItem it = items[blockIdx.x];
     if (it.n <= 2 * EIG_THREADS) eig_fused_body<2, NR>(it, pools, scratch, s_stride, red);
     else if (it.n <= 4 * EIG_THREADS) eig_fused_body<4, NR>(it, pools, scratch, s_stride, red);
@@ -808,10 +827,10 @@ void launch_ld_eig_fused_all(const EigItem *items, int n_items, const double *po
     const dim3 grid(n_items), block(EIG_THREADS);
     if (pool1)
         hipLaunchKernelGGL((ld_eig_fused_all_kernel<2>), grid, block, 0, s, items, pp, scratch,
-                           s_stride, g_pred);
+                           s_stride, g_pred, g_phase);
     else
         hipLaunchKernelGGL((ld_eig_fused_all_kernel<1>), grid, block, 0, s, items, pp, scratch,
-                           s_stride, g_pred);
+                           s_stride, g_pred, g_phase);
 }
 
 template <int R>
@@ -820,10 +839,10 @@ static void launch_eig_r(const EigItem *items, int n_items, const PoolPair &pp, 
     const dim3 grid(n_items), block(EIG_THREADS);
     if (two)
         hipLaunchKernelGGL((ld_eig_fused_kernel<R, 2>), grid, block, 0, s, items, pp, scratch,
-                           s_stride, g_pred);
+                           s_stride, g_pred, g_phase);
     else
         hipLaunchKernelGGL((ld_eig_fused_kernel<R, 1>), grid, block, 0, s, items, pp, scratch,
-                           s_stride, g_pred);
+                           s_stride, g_pred, g_phase);
 }
 
 void launch_ld_eig_fused(const EigItem *items, int n_items, int R, const double *pool0,
@@ -1025,8 +1044,12 @@ static __device__ __forceinline__ double tile_sum8(const double (&p)[8], int lan
     return sym_rowsum8(p, lane, row);
 }
 
+// Register budget: three waves per SIMD for up to two cohorts (168 VGPRs; the two-step trial with
+// the stash then spills 6 registers and still gains: C3 trial pass 0.54 -> 0.48 ms,
+// profiles/r03c_ab_snp_pass.txt); with the Cholesky of three or four cohorts that budget spills
+// dozens, so those keep two.
 #ifndef SNP_MIN_WAVES
-#define SNP_MIN_WAVES 2
+#define SNP_MIN_WAVES(P) ((P) <= 2 ? 3 : 2)
 #endif
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
 // store of the wave to be acknowledged (vmcnt(0)): with the pass's vi_mu stores in flight that is
@@ -1037,7 +1060,7 @@ static __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH>
-__global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES) void snp_pass_kernel(const SnpKernelArgs a) {
+__global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel(const SnpKernelArgs a) {
     static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
     constexpr int NT = 2 * P + 2;
     constexpr int NTP = (NT + 7) / 8 * 8;
@@ -1045,6 +1068,18 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES) void snp_pass_kernel(co
     constexpr int KB = P <= 2 ? KU : (KU > 2 ? 2 : KU);
     extern __shared__ double lds[];
     PRED_EXIT(a.pred);
+    // the buffers and step sizes: from the arguments, or -- for a sweep queued ahead of the
+    // decision that assigns the buffers their roles -- from the device-resident phase block
+    PhasePtrs q;
+    if (a.pp != nullptr) {
+        q = *a.pp;
+    } else {
+        q.mu_in = a.mu_in; q.mu_out = a.mu_out; q.mu_out2 = a.mu_out2;
+        q.pool_cur = a.pool_cur; q.m_cur = a.m_cur; q.lse_ref = a.lse_ref;
+        q.pool_out = a.pool_out; q.m_out = a.m_out; q.v_out = a.v_out; q.lse_out = a.lse_out;
+        q.pool_out2 = a.pool_out2; q.m_out2 = a.m_out2; q.v_out2 = a.v_out2; q.lse_out2 = a.lse_out2;
+        q.step = a.step; q.step2 = a.step2;
+    }
     const int N = a.N, M = a.M;
     const int64_t N64 = N;
     const int lane = threadIdx.x & 63;
@@ -1077,17 +1112,17 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES) void snp_pass_kernel(co
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int pos = a.invperm[p * N64 + ii];
-            const double linked = a.pool_cur[(int64_t)(P + p) * N64 + pos];
-            const double m = a.m_cur[p * N64 + ii];
+            const double linked = q.pool_cur[(int64_t)(P + p) * N64 + pos];
+            const double m = q.m_cur[p * N64 + ii];
             g[p] = (adj[p] - (linked / se[p] - m * sld[p])) / a.tau.v[p];
         }
     }
     const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
     double step[NS];
     double *mu_out[NS];
-    step[0] = a.step;
-    mu_out[0] = a.mu_out;
-    if (NS == 2) { step[NS - 1] = a.step2; mu_out[NS - 1] = a.mu_out2; }
+    step[0] = q.step;
+    mu_out[0] = q.mu_out;
+    if (NS == 2) { step[NS - 1] = q.step2; mu_out[NS - 1] = q.mu_out2; }
 
     const const_tab prec_tab = as_table(a.prec);
     const const_tab lh_tab = as_table(a.lh);          // one annotation: the row is wave-uniform
@@ -1097,7 +1132,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES) void snp_pass_kernel(co
 
     double shift[NS], Z[NS], Skl[NS], Sip[NS], amax[NS], Sm[NS][P], S2[NS][P];
     {
-        const double s0 = a.lse_ref != nullptr ? a.lse_ref[ii] : 0.0;
+        const double s0 = q.lse_ref != nullptr ? q.lse_ref[ii] : 0.0;
 #pragma unroll
         for (int c = 0; c < NS; ++c) shift[c] = s0;
     }
@@ -1113,7 +1148,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES) void snp_pass_kernel(co
         for (int kk = 0; kk < KB; ++kk) {
             const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
 #pragma unroll
-            for (int p = 0; p < P; ++p) dst[kk][p] = MU_LOAD(&a.mu_in[((int64_t)kc * P + p) * N64 + ii]);
+            for (int p = 0; p < P; ++p) dst[kk][p] = MU_LOAD(&q.mu_in[((int64_t)kc * P + p) * N64 + ii]);
             lhv[kk] = ONE_ANNOT ? 0.0 : lh[kc];
         }
     };
@@ -1333,9 +1368,9 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES) void snp_pass_kernel(co
                     S2[c][p] += sc[(2 + P + p) * SNP_TILE];
                 }
             }
-            double *m_out = c == 0 ? a.m_out : a.m_out2, *v_out = c == 0 ? a.v_out : a.v_out2;
-            double *pool_out = c == 0 ? a.pool_out : a.pool_out2;
-            double *lse_out = c == 0 ? a.lse_out : a.lse_out2;
+            double *m_out = c == 0 ? q.m_out : q.m_out2, *v_out = c == 0 ? q.v_out : q.v_out2;
+            double *pool_out = c == 0 ? q.pool_out : q.pool_out2;
+            double *lse_out = c == 0 ? q.lse_out : q.lse_out2;
             const double lse = shift[c] + log(Zt[c]);
             double vals[NTP];
 #pragma unroll
@@ -1437,6 +1472,7 @@ static void launch_snp_pass_p(const SnpKernelArgs &a, bool blend, int ns, bool s
 void launch_snp_pass(const SnpKernelArgs &args, bool blend, int ns, hipStream_t s) {
     SnpKernelArgs a = args;
     a.pred = g_pred;
+    a.pp = g_phase;
     const bool stash = a.sum_partials != nullptr && snp_pass_can_stash(a.M, a.P, ns);
     switch (a.P) {
         case 1: launch_snp_pass_p<1>(a, blend, ns, stash, s); break;
@@ -2207,18 +2243,18 @@ void launch_mean_diff(const double *m_cur, const double *scalings, double *snaps
 // (variational_inference.py:832-842) and lh = log hyper - 0.5 log_det (numerics.py:149-164).
 // One workgroup per annotation row; fixed-order sum.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mstep_kernel(const double *__restrict__ sums,
-                                                     const double *__restrict__ counts,
-                                                     const double *__restrict__ log_det, int M,
-                                                     double *__restrict__ hyper,
-                                                     double *__restrict__ lh, const int *pred) {
-    __shared__ double red[4];
-    PRED_EXIT(pred);
-    const int a = blockIdx.x;
+// one annotation row of the M-step by a 256-thread workgroup (shared by mstep_kernel and the
+// device-resident sweep's decision kernel, so both give the same bits)
+static __device__ __forceinline__ void mstep_row(const double *__restrict__ sums,
+                                                 const double *__restrict__ counts,
+                                                 const double *__restrict__ log_det, int M, int a,
+                                                 double *__restrict__ hyper, double *__restrict__ lh,
+                                                 double *red /*[4] shared*/) {
     const double inv = 1.0 / (counts[a] + 1e-100);
     double part = 0.0;
     for (int k = threadIdx.x; k < M; k += 256) part += fmax(sums[(int64_t)a * M + k] * inv, 1e-100);
     part = wave_sum(part);
+    __syncthreads();                                // red[] may still be read from the previous row
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
     const double total = (red[0] + red[1]) + (red[2] + red[3]);
@@ -2227,6 +2263,16 @@ __global__ __launch_bounds__(256) void mstep_kernel(const double *__restrict__ s
         hyper[(int64_t)a * M + k] = h;
         lh[(int64_t)a * M + k] = log(h) - 0.5 * log_det[k];
     }
+}
+
+__global__ __launch_bounds__(256) void mstep_kernel(const double *__restrict__ sums,
+                                                     const double *__restrict__ counts,
+                                                     const double *__restrict__ log_det, int M,
+                                                     double *__restrict__ hyper,
+                                                     double *__restrict__ lh, const int *pred) {
+    __shared__ double red[4];
+    PRED_EXIT(pred);
+    mstep_row(sums, counts, log_det, M, blockIdx.x, hyper, lh, red);
 }
 
 void launch_mstep(const double *sums, const double *counts, const double *log_det, int A, int M,
@@ -2346,4 +2392,156 @@ void launch_decide(int P, int check_convergence, const double *totals, const dou
     a.pred = g_pred; a.out_flag = out_flag; a.out_obj = out_obj;
     a.results = results; a.n_results = n_results; a.snap = snap; a.flags = flags;
     hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, s, a);
+}
+
+// --------------------------------------------------------------------------------------------
+// The decision of a device-resident sweep (sweep.hip).  One workgroup, run behind a queued beta
+// trial (candidates A at L = L_try and B at L_try * rate) and the all-reduce of its sums:
+//   - the line search of _update_beta (variational_inference.py:777-800) on the two candidates:
+//     A if it passes the accept test, else B; neither -> the block goes dead and the host, which
+//     reads the snapshot taken here, carries on with its own line search;
+//   - _nat_grad_step's break rule after the accepted step (:432-435) with the running ELBO change
+//     of _optimize_step (:406-409), both in the host's operation order without fused multiply-add,
+//     so host and device can never disagree; an inner loop that has to go on -> dead;
+//   - optimize()'s "no posterior mean moved" stop (:374-382) as a veto -> dead;
+//   - on success: buffers swap roles (vilma_accept's bookkeeping, here on the device), the M-step
+//     of _update_hyper_delta (:837-848) from the accepted candidate's responsibility sums, the
+//     step sizes of the NEXT trial (L / 1.25 floored at 1, :424) and the pointers both phases of
+//     the next stage will work on.
+// Before anything is overwritten the result vector and the block's scalars are copied aside for
+// the host (one snapshot per decision, fetched on the copy stream).
+// --------------------------------------------------------------------------------------------
+struct SweepDecideArgs {
+    int32_t P, A, M;
+    int32_t check_convergence;       // veto when dsum[0] == 0
+    int32_t have_b, have_sums_b;     // candidate B evaluated / its responsibility sums available
+    double chi[VILMA_MAX_P], tau[VILMA_MAX_P], half_rank_log_tau[VILMA_MAX_P];
+    double rel_tol, abs_tol, rate, l_max;
+    SweepCtl *ctl;
+    const double *results;           // the context's result vector (include/vilma_hip.h layout)
+    int32_t o_dsum, o_tot, o_ta, o_tb, o_sa, o_sb, o_hyper, n_results;
+    double *hyper;                   // results + o_hyper
+    double *lh;
+    const double *counts, *log_det;
+    double *snap;                    // [n_results + VILMA_SNAP_EXTRA]
+    BufferBases bases;
+};
+
+static __device__ double sweep_objective(const SweepDecideArgs &a, const double *t) {
+#pragma clang fp contract(off)
+    const int P = a.P;
+    double lik = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const double inner = ((-0.5 * (t[P + p] + t[2 * P + p]) + t[p]) - 0.5 * a.chi[p]) / a.tau[p];
+        lik = lik + (inner - a.half_rank_log_tau[p]);
+    }
+    return lik - (t[3 * P] + t[3 * P + 1]);
+}
+
+__global__ __launch_bounds__(256) void sweep_decide_kernel(const SweepDecideArgs a) {
+#pragma clang fp contract(off)
+    __shared__ double red[4];
+    __shared__ int sh_choice;
+    SweepCtl *ctl = a.ctl;
+    double orig = 0.0, fa = 0.0, fb = 0.0;
+    if (threadIdx.x == 0) {
+        int choice = 0;
+        if (ctl->alive) {
+            orig = sweep_objective(a, a.results + a.o_tot);
+            fa = sweep_objective(a, a.results + a.o_ta);
+            fb = a.have_b ? sweep_objective(a, a.results + a.o_tb) : 0.0;
+            // running ELBO change: as armed by the host, or updated with the sweep that has just
+            // completed on the device (its beta step obj_start -> obj_beta, its M-step -> orig)
+            double r = ctl->running;
+            int r_none = ctl->running_none;
+            if (ctl->have_prev) {
+                const double delta_beta = 0.0 + (ctl->obj_beta - ctl->obj_start);
+                const double change = delta_beta + (orig - ctl->obj_beta);
+                r = r_none ? change : r;
+                r = r * 0.5;
+                r = r + 0.5 * (change > 0.0 ? change : 0.0);
+                r_none = 0;
+            }
+            const double L = ctl->L_try;
+            double Lacc = L, fresh = fa;
+            if (fa >= (orig - a.rel_tol * fabs(orig)) - a.abs_tol) {
+                choice = 1;
+            } else if (a.have_b && !(L > a.l_max)) {
+                const double L2 = L * a.rate;
+                if (fb >= (orig - a.rel_tol * fabs(orig)) - a.abs_tol) {
+                    choice = a.have_sums_b ? 2 : 0;
+                    Lacc = L2;
+                    fresh = fb;
+                }
+            }
+            bool ok = choice != 0 && !(Lacc > a.l_max);
+            const bool ends = Lacc == 1.0 || (!r_none && fabs(fresh - orig) <= 0.1 * r) || r_none;
+            ok = ok && ends;
+            if (a.check_convergence && a.results[a.o_dsum] == 0.0) ok = false;
+            if (ok) {
+                // vilma_accept(0) of the evaluation behind the last M-step, then of the candidate
+                const int mc = ctl->mom_role[0], ma = ctl->mom_role[1], mb = ctl->mom_role[2];
+                const int uc = ctl->mu_role[0], ua = ctl->mu_role[1], ub = ctl->mu_role[2];
+                if (choice == 1) {
+                    ctl->mom_role[0] = mc; ctl->mom_role[1] = ma; ctl->mom_role[2] = mb;
+                    ctl->mu_role[0] = ua; ctl->mu_role[1] = uc; ctl->mu_role[2] = ub;
+                } else {
+                    ctl->mom_role[0] = mb; ctl->mom_role[1] = mc; ctl->mom_role[2] = ma;
+                    ctl->mu_role[0] = ub; ctl->mu_role[1] = ua; ctl->mu_role[2] = uc;
+                }
+                ctl->obj_start = orig;
+                ctl->obj_beta = fresh;
+                ctl->running = r;
+                ctl->running_none = r_none;
+                ctl->have_prev = 1;
+                ctl->L0 = Lacc;
+                double Lnext = Lacc / 1.25;
+                Lnext = Lnext > 1.0 ? Lnext : 1.0;
+                ctl->L_try = Lnext;
+                phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_EVAL, 0.0, 0.0, ctl->phase[0]);
+                phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_TRIAL, 1.0 / Lnext,
+                           1.0 / (Lnext * a.rate), ctl->phase[1]);
+            } else {
+                ctl->alive = 0;
+            }
+            ctl->choice = choice;
+            ctl->stage += 1;
+        }
+        sh_choice = ctl->alive ? choice : 0;
+    }
+    __syncthreads();
+    // snapshot for the host: the result vector as the decision saw it (hyper_delta still the one
+    // of the sweep just completed), then the block's scalars after the decision
+    for (int t = threadIdx.x; t < a.n_results; t += blockDim.x) a.snap[t] = a.results[t];
+    if (threadIdx.x == 0) {
+        double *x = a.snap + a.n_results;
+        x[0] = (double)ctl->alive; x[1] = (double)ctl->choice; x[2] = (double)ctl->stage;
+        x[3] = ctl->L_try; x[4] = ctl->L0; x[5] = ctl->obj_start; x[6] = ctl->obj_beta;
+        x[7] = ctl->running; x[8] = (double)ctl->running_none;
+        x[9] = orig; x[10] = fa; x[11] = fb;
+        for (int q = 0; q < 3; ++q) { x[12 + q] = (double)ctl->mu_role[q]; x[15 + q] = (double)ctl->mom_role[q]; }
+    }
+    __syncthreads();
+    const int choice = sh_choice;
+    if (choice == 0) return;
+    const double *sums = a.results + (choice == 1 ? a.o_sa : a.o_sb);
+    for (int an = 0; an < a.A; ++an) mstep_row(sums, a.counts, a.log_det, a.M, an, a.hyper, a.lh, red);
+}
+
+void launch_sweep_decide(const SweepDecideParams &p, hipStream_t s) {
+    SweepDecideArgs a;
+    a.P = p.P; a.A = p.A; a.M = p.M;
+    a.check_convergence = p.check_convergence; a.have_b = p.have_b; a.have_sums_b = p.have_sums_b;
+    for (int q = 0; q < VILMA_MAX_P; ++q) {
+        a.chi[q] = q < p.P ? p.chi[q] : 0.0;
+        a.tau[q] = q < p.P ? p.tau[q] : 1.0;
+        a.half_rank_log_tau[q] = q < p.P ? p.half_rank_log_tau[q] : 0.0;
+    }
+    a.rel_tol = p.rel_tol; a.abs_tol = p.abs_tol; a.rate = p.rate; a.l_max = p.l_max;
+    a.ctl = p.ctl; a.results = p.results;
+    a.o_dsum = p.o_dsum; a.o_tot = p.o_tot; a.o_ta = p.o_ta; a.o_tb = p.o_tb; a.o_sa = p.o_sa;
+    a.o_sb = p.o_sb; a.o_hyper = p.o_hyper; a.n_results = p.n_results;
+    a.hyper = p.results + p.o_hyper; a.lh = p.lh; a.counts = p.counts; a.log_det = p.log_det;
+    a.snap = p.snap; a.bases = p.bases;
+    hipLaunchKernelGGL(sweep_decide_kernel, dim3(1), dim3(256), 0, s, a);
 }

@@ -106,6 +106,31 @@ struct SweepState {
     bool two_step = true;                   // VILMA_TWO_STEP / default P <= 2
     double L_rejected = -1.0;
 
+    // a beta trial evaluated on the device but not looked at by the host's line search yet
+    // (left by a queued sweep whose decision went to the host): candidate A's sums are in `host`
+    bool pend_valid = false;
+    double pend_step = 0.0;
+
+    // ---- sweeps queued ahead: [trial, decision, evaluation] per sweep, roles on the device ----
+    bool armed = false;                     // the control block drives the stream
+    hipStream_t pipe_stream = nullptr;      // ... this one
+    bool cur_decided = false;               // the decision of the sweep about to be reported is known
+    bool next_queued = false;               // ... and the sweep after it is queued too
+    bool pipe_diff = false;                 // queued evaluations carry the convergence statistics
+    double pipe_rate = 2.0;
+    int slot = 0;                           // snapshot buffer of the next decision queued
+    int cur_slot = 0, next_slot = 0;
+    double *snap_dev[2] = {nullptr, nullptr};
+    double *land[2] = {nullptr, nullptr};   // pinned
+    hipEvent_t ev_dec[2] = {nullptr, nullptr}, ev_land[2] = {nullptr, nullptr};
+    size_t mark_eval[2] = {0, 0};           // profiling brackets pending before a sweep's evaluation
+    SweepCtl *ctl_host = nullptr;           // pinned staging of the control block
+    // what the decision of the sweep being reported found (from its snapshot)
+    double cur_orig = 0.0, cur_new = 0.0, cur_L0 = 1.0, cur_running = 0.0;
+    int cur_choice = 0;
+    bool cur_running_none = true;
+    int mu_state_before = 0;                // vi_mu buffer of the state before that decision
+
     // per-call
     int flags = 0;
     vilma_sweep_stats *stats = nullptr;
@@ -117,6 +142,15 @@ void vilma_detail::sweep_destroy(vilma_ctx *c) {
     SweepState *s = c->sw;
     if (!s) return;
     if (s->nccl_comm && rccl().CommDestroy) (void)rccl().CommDestroy(s->nccl_comm);
+    for (int b = 0; b < 2; ++b) {
+        dev_free(s->snap_dev[b]);
+        if (s->land[b]) (void)hipHostFree(s->land[b]);
+        if (s->ev_dec[b]) (void)hipEventDestroy(s->ev_dec[b]);
+        if (s->ev_land[b]) (void)hipEventDestroy(s->ev_land[b]);
+    }
+    if (s->ctl_host) (void)hipHostFree(s->ctl_host);
+    dev_free(c->ctl);
+    c->ctl = nullptr;
     dev_free(s->results);
     delete s;
     c->sw = nullptr;
@@ -245,6 +279,17 @@ int trial(vilma_ctx *c, SweepState *s, hipStream_t st, double step, double next_
         *totals = s->alt_totals.data();
         return 0;
     }
+    if (s->pend_valid && s->pend_step == step) {
+        // the trial a queued sweep already ran for this very step (its decision came back to the
+        // host): candidate A's sums are in s->host, B's in the alt cache
+        s->pend_valid = false;
+        s->candidate = 1;
+        if (s->stats) { s->stats->n_evaluations += 1; s->stats->n_trials += 1; s->stats->n_products += 1; }
+        *obj = objective_from(c, s, s->host.data() + s->o_ta);
+        *totals = s->host.data() + s->o_ta;
+        return 0;
+    }
+    s->pend_valid = false;
     s->alt_valid = false;
     s->cur_sums = -1;                   // the trial's sums overwrite the device copy
     const bool two = s->two_step;
@@ -406,6 +451,346 @@ int nat_grad_step(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, double
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Sweeps queued ahead.  With VILMA_SWEEP_LOOKAHEAD the stream always holds one more sweep than the
+// host has reported: [beta trial at the device's L (two candidates) -> all-reduce -> decision
+// kernel (line search, break rule, veto, role swap, M-step, next steps) -> evaluation].  Nothing of
+// it needs the host: buffer roles, step sizes, L and the running ELBO change live in the control
+// block (SweepCtl) on the device.  The host reads one snapshot per decision (copy stream) and
+// replays the decision with the same arithmetic; a decision the device cannot take alone (both
+// candidates rejected, an inner loop that goes on, L beyond L_MAX, the convergence veto) turns the
+// block dead -- every kernel queued behind exits at once -- and the host's own line search
+// continues from the trial already evaluated.
+// ---------------------------------------------------------------------------------------------
+bool lookahead_enabled() {
+    const char *e = std::getenv("VILMA_LOOKAHEAD");
+    return !(e && e[0] == '0');
+}
+
+// can this sweep run from the control block?
+bool pipeline_eligible(const vilma_ctx *c, const SweepState *s, int flags) {
+    if (!(flags & VILMA_SWEEP_LOOKAHEAD) || (flags & VILMA_SWEEP_VERBOSE) || s->scale_se) return false;
+    if (!lookahead_enabled()) return false;
+    // the decision kernel needs the responsibility sums of every candidate it may accept
+    return c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, s->two_step ? 2 : 1);
+}
+
+int pipeline_buffers(vilma_ctx *c, SweepState *s) {
+    if (c->ctl) return 0;
+    if (dev_alloc(c, &c->ctl, 1)) return 1;
+    HIPCHK(c, hipHostMalloc((void **)&s->ctl_host, sizeof(SweepCtl), hipHostMallocDefault));
+    for (int b = 0; b < 2; ++b) {
+        if (dev_alloc(c, &s->snap_dev[b], s->size + VILMA_SNAP_EXTRA)) return 1;
+        HIPCHK(c, hipHostMalloc((void **)&s->land[b], (size_t)(s->size + VILMA_SNAP_EXTRA) * sizeof(double),
+                                hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&s->ev_dec[b], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&s->ev_land[b], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+BufferBases buffer_bases(const vilma_ctx *c) {
+    BufferBases b;
+    for (int q = 0; q < 3; ++q) {
+        b.mu[q] = c->mu[q]; b.pool[q] = c->pool[q]; b.m[q] = c->m[q]; b.v[q] = c->v[q]; b.lse[q] = c->lse[q];
+    }
+    return b;
+}
+
+// [trial, decision, evaluation] of one sweep, all behind the control block
+int queue_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool first = false) {
+    const bool two = s->two_step;
+    const int b = s->slot;
+    s->slot ^= 1;
+    set_launch_predicate(&c->ctl->alive);
+    int rc = queue_trial_phase(c, st, two, s->results + s->o_ta, s->results + s->o_tb,
+                               s->results + s->o_sa, s->results + s->o_sb);
+    // one all-reduce per sweep: the previous evaluation's sums and statistics and this trial's (the
+    // evaluation in front of the FIRST queued sweep was the host's: its sums are reduced already)
+    if (!rc && s->comm_kind) {
+        const int lo = first ? s->o_ta : s->o_dsum;
+        rc = comm_allreduce(c, s, st, s->results + lo, (two ? s->o_sb + s->am : s->o_sa + s->am) - lo, 0);
+    }
+    if (!rc) {
+        SweepDecideParams p;
+        double hrl[VILMA_MAX_P];
+        for (int q = 0; q < c->P; ++q) hrl[q] = 0.5 * s->ranks[q] * std::log(c->tau[q]);
+        p.P = c->P; p.A = c->A; p.M = c->M;
+        p.check_convergence = veto ? 1 : 0; p.have_b = two ? 1 : 0; p.have_sums_b = two ? 1 : 0;
+        p.chi = s->chi.data(); p.tau = c->tau; p.half_rank_log_tau = hrl;
+        p.rel_tol = REL_TOL; p.abs_tol = ABS_TOL; p.rate = s->pipe_rate; p.l_max = L_MAX;
+        p.ctl = c->ctl; p.results = s->results;
+        p.o_dsum = s->o_dsum; p.o_tot = s->o_tot; p.o_ta = s->o_ta; p.o_tb = s->o_tb;
+        p.o_sa = s->o_sa; p.o_sb = s->o_sb; p.o_hyper = s->o_hyper; p.n_results = s->size;
+        p.lh = c->lh; p.counts = c->counts; p.log_det = c->log_det;
+        p.snap = s->snap_dev[b]; p.bases = buffer_bases(c);
+        launch_sweep_decide(p, st);
+        // the snapshot leaves on the copy stream; the compute stream goes straight on
+        if (hipEventRecord(s->ev_dec[b], st) != hipSuccess ||
+            hipStreamWaitEvent(c->copy_stream, s->ev_dec[b], 0) != hipSuccess ||
+            hipMemcpyAsync(s->land[b], s->snap_dev[b], (size_t)(s->size + VILMA_SNAP_EXTRA) * sizeof(double),
+                           hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
+            hipEventRecord(s->ev_land[b], c->copy_stream) != hipSuccess)
+            rc = fail(c, "cannot queue the decision snapshot");
+    }
+    if (!rc) {
+        s->mark_eval[b] = prof_pending(c);
+        rc = queue_eval_phase(c, st, s->results + s->o_tot, s->pipe_diff ? s->results + s->o_dsum : nullptr,
+                              s->pipe_diff ? s->results + s->o_dmax : nullptr);
+    }
+    set_launch_predicate(nullptr);
+    return rc;
+}
+
+// Write the host's state into the control block and queue the first sweep behind it.
+int pipeline_arm(vilma_ctx *c, SweepState *s, hipStream_t st, const double *L, double running,
+                 double rate, bool diff, bool veto) {
+    if (pipeline_buffers(c, s)) return 1;
+    SweepCtl &k = *s->ctl_host;
+    std::memset(&k, 0, sizeof(k));
+    k.alive = 1;
+    k.running_none = std::isnan(running) ? 1 : 0;
+    k.running = std::isnan(running) ? 0.0 : running;
+    k.have_prev = 0;
+    // the trial phase treats the moments of role "ta" as current (the evaluation queued in front
+    // of it is accepted unconditionally); the host's current moments take that place
+    k.mu_role[0] = c->mu_cur; k.mu_role[1] = c->mu_ta; k.mu_role[2] = c->mu_tb;
+    k.mom_role[0] = c->mom_ta; k.mom_role[1] = c->mom_cur; k.mom_role[2] = c->mom_tb;
+    k.L0 = L[0];
+    k.L_try = std::max(1.0, L[0] / 1.25);
+    const BufferBases bases = buffer_bases(c);
+    phase_ptrs(bases, k.mu_role, k.mom_role, VILMA_PHASE_EVAL, 0.0, 0.0, k.phase[0]);
+    phase_ptrs(bases, k.mu_role, k.mom_role, VILMA_PHASE_TRIAL, 1.0 / k.L_try, 1.0 / (k.L_try * rate),
+               k.phase[1]);
+    HIPCHK(c, hipMemcpyAsync(c->ctl, &k, sizeof(k), hipMemcpyHostToDevice, st));
+    s->pipe_rate = rate;
+    s->pipe_diff = diff;
+    s->pipe_stream = st;
+    s->slot = 0;
+    s->armed = true;
+    s->cur_decided = false;
+    s->next_queued = false;
+    s->cur_slot = s->slot;
+    return queue_sweep(c, s, st, veto, /*first=*/true);
+}
+
+struct Snapshot {
+    const double *r;            // result vector as the decision saw it
+    bool alive;
+    int choice;
+    double L_try, L0, obj_start, obj_beta, running, orig, fa, fb;
+    bool running_none;
+    int mu_role[3], mom_role[3];
+};
+
+int wait_snapshot(vilma_ctx *c, SweepState *s, int b, Snapshot *o) {
+    HIPCHK(c, hipEventSynchronize(s->ev_land[b]));
+    const double *x = s->land[b] + s->size;
+    o->r = s->land[b];
+    o->alive = x[0] != 0.0; o->choice = (int)x[1];
+    o->L_try = x[3]; o->L0 = x[4]; o->obj_start = x[5]; o->obj_beta = x[6];
+    o->running = x[7]; o->running_none = x[8] != 0.0;
+    o->orig = x[9]; o->fa = x[10]; o->fb = x[11];
+    for (int q = 0; q < 3; ++q) { o->mu_role[q] = (int)x[12 + q]; o->mom_role[q] = (int)x[15 + q]; }
+    return 0;
+}
+
+// The decision in snapshot `sn` went to the host: everything queued behind it has exited.  Make the
+// host-side roles and caches those of the device (state before the trial, both candidates
+// evaluated) so that the host's line search continues from there.
+int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const Snapshot &sn, int b) {
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    prof_truncate(c, s->mark_eval[b]);              // the brackets of launches that exited at once
+    c->mu_cur = sn.mu_role[0]; c->mu_ta = sn.mu_role[1]; c->mu_tb = sn.mu_role[2];
+    c->mom_cur = sn.mom_role[1]; c->mom_ta = sn.mom_role[0]; c->mom_tb = sn.mom_role[2];
+    c->have_moments = true;
+    c->have_b = s->two_step;
+    c->tile_sums_ns = s->two_step ? 2 : 1;
+    c->snp_marked = false;
+    c->trial_tainted = false;
+    // the device copy of the summed part may have gone through the all-reduces of dead sweeps
+    if (s->comm_kind)
+        HIPCHK(c, hipMemcpy(s->results + s->o_dsum, sn.r + s->o_dsum,
+                            (size_t)(s->reduce_end - s->o_dsum) * sizeof(double), hipMemcpyHostToDevice));
+    std::copy(sn.r, sn.r + s->size, s->host.begin());
+    std::copy(sn.r + s->o_tot, sn.r + s->o_tot + s->nt, s->totals.begin());
+    s->hyper.assign(sn.r + s->o_hyper, sn.r + s->o_hyper + s->am);
+    s->objective = objective_from(c, s, s->totals.data());
+    s->cur_sums = -1;
+    s->pend_valid = true;
+    s->pend_step = 1.0 / sn.L_try;
+    s->trial_sums = true;
+    s->trial_sums_b = s->two_step;
+    s->alt_valid = s->two_step;
+    if (s->two_step) {
+        s->alt_step = 1.0 / (sn.L_try * s->pipe_rate);
+        std::copy(sn.r + s->o_tb, sn.r + s->o_tb + s->nt, s->alt_totals.begin());
+        s->alt_obj = objective_from(c, s, s->alt_totals.data());
+    }
+    s->armed = false;
+    s->cur_decided = s->next_queued = false;
+    return 0;
+}
+
+// The caller does not go on with the sweep queued ahead: wait for it and put the state the last
+// reported sweep ended in back (the vi_mu it ended with is still in its buffer; its moments are
+// re-derived by one evaluation).
+int pipeline_rollback(vilma_ctx *c, SweepState *s, hipStream_t st) {
+    if (!s->armed) return 0;
+    Snapshot sn;
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    // the last decision the device took (or refused)
+    const int b = s->cur_slot;
+    if (wait_snapshot(c, s, b, &sn)) return 1;
+    s->armed = false;
+    if (!sn.alive) {
+        // it went dead at that decision: nothing behind it ran
+        if (pipeline_takeover(c, s, st, sn, b)) return 1;
+        s->pend_valid = false;          // the caller is not going to use the trial
+        s->alt_valid = false;
+        s->trial_sums = s->trial_sums_b = false;
+        return 0;
+    }
+    // the device accepted a candidate and evaluated the state after its M-step: one sweep beyond
+    // what was reported.  The reported state's vi_mu: role ta (candidate A taken) or tb (B).
+    prof_truncate(c, s->mark_eval[b]);
+    const int before = sn.choice == 1 ? sn.mu_role[1] : sn.mu_role[2];
+    const int other1 = sn.mu_role[0], other2 = sn.choice == 1 ? sn.mu_role[2] : sn.mu_role[1];
+    c->mu_cur = before; c->mu_ta = other1; c->mu_tb = other2;
+    c->mom_cur = sn.mom_role[0]; c->mom_ta = sn.mom_role[1]; c->mom_tb = sn.mom_role[2];
+    c->have_moments = false;
+    c->have_b = false;
+    c->tile_sums_ns = 0;
+    c->snp_marked = false;
+    s->cur_decided = s->next_queued = false;
+    s->pend_valid = s->alt_valid = false;
+    if (vilma_set_hyper(c, s->hyper.data())) return 1;
+    vilma_sweep_stats *keep = s->stats;
+    s->stats = nullptr;
+    double obj;
+    int rc = evaluate_current(c, s, st, &obj);
+    s->stats = keep;
+    if (rc) return 1;
+    std::vector<double> tot(s->host.begin() + s->o_tot, s->host.begin() + s->o_tot + s->nt);
+    if (accept(c, s, 0, obj, tot.data())) return 1;
+    s->cur_sums = -1;
+    if (s->pipe_diff && vilma_snapshot_mean(c, (void *)st)) return 1;
+    return 0;
+}
+
+// One sweep from the control block: see the comment above.  *done = false: the sweep has to be run
+// (or finished) by the host's own line search (the caches say where it stands).
+int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, double *elbo,
+                   double *running_delta, double rate, int flags, vilma_sweep_stats *out, bool *done) {
+    *done = false;
+    const bool ahead = pipeline_eligible(c, s, flags);
+    const bool diff = (flags & VILMA_SWEEP_DIFF) != 0;
+    if (s->armed && (rate != s->pipe_rate || diff != s->pipe_diff)) {
+        if (pipeline_rollback(c, s, st)) return 1;
+    }
+    if (!s->armed) {
+        if (!ahead || s->pend_valid) return 0;              // host path
+        // (no veto on the first decision: the host has looked at the statistics in front of it)
+        if (pipeline_arm(c, s, st, L, *running_delta, rate, diff, false)) return 1;
+    }
+    // the sweep to report ("this" sweep) is queued; keep one more behind it if the caller promised
+    if (ahead && !s->next_queued) {
+        s->next_slot = s->slot;
+        // its decision sits behind THIS sweep's evaluation: the veto is about this sweep's statistics
+        if (queue_sweep(c, s, st, (flags & VILMA_SWEEP_VETO) != 0)) return 1;
+        s->next_queued = true;
+    }
+    Snapshot sn;
+    if (!s->cur_decided) {
+        if (wait_snapshot(c, s, s->cur_slot, &sn)) return 1;
+        if (!sn.alive) return pipeline_takeover(c, s, st, sn, s->cur_slot);     // host path from here
+        s->cur_orig = sn.orig; s->cur_new = sn.choice == 1 ? sn.fa : sn.fb; s->cur_L0 = sn.L0;
+        s->cur_choice = sn.choice;
+        s->cur_decided = true;
+    }
+    // this sweep's beta step was taken on the device.  The same decision with the host's arithmetic:
+    {
+        const double orig = s->objective;
+        const double nw = s->cur_new;
+        if (!(nw >= orig - REL_TOL * std::fabs(orig) - ABS_TOL) || s->cur_orig != orig)
+            return fail(c, "device and host line-search decisions disagree");
+    }
+    // its evaluation after the M-step: in the next decision's snapshot, or fetched directly
+    const double *r;
+    bool next_dead = false;
+    Snapshot nx;
+    if (s->next_queued) {
+        if (wait_snapshot(c, s, s->next_slot, &nx)) return 1;
+        r = nx.r;
+        next_dead = !nx.alive;
+    } else {
+        // no decision behind it whose all-reduce would cover it: reduce it here
+        if (reduce_and_fetch(c, s, st, diff ? s->o_dsum : s->o_tot, s->o_tot + s->nt, false)) return 1;
+        r = s->host.data();
+    }
+    const double obj_start = s->objective, obj_beta = s->cur_new;
+    std::copy(r + s->o_tot, r + s->o_tot + s->nt, s->totals.begin());
+    s->hyper.assign(r + s->o_hyper, r + s->o_hyper + s->am);
+    s->objective = objective_from(c, s, s->totals.data());
+    // _nat_grad_step's bookkeeping (variational_inference.py:419-450) for a one-step inner loop
+    double change = 0.0;
+    change += obj_beta - obj_start;
+    change += s->objective - obj_beta;
+    double running = std::isnan(*running_delta) ? change : *running_delta;
+    running *= ELBO_MOMENTUM;
+    running += (1 - ELBO_MOMENTUM) * std::max(change, 0.0);
+    L[0] = s->cur_L0;
+    L[1] = std::max(1.0, L[1] / 1.25);
+    L[2] = std::max(1.0, L[2] / 1.25);
+    *elbo = *elbo + change;
+    *running_delta = running;
+    out->n_trials = s->cur_choice == 1 ? 1 : 2;
+    out->n_evaluations = out->n_trials + 1;
+    out->n_products = 2;
+    out->ran_ahead = 1;
+    if (diff)
+        for (int q = 0; q < 3; ++q) {
+            out->diff_sum[q] = r[s->o_dsum + q];
+            out->diff_max[q] = r[s->o_dmax + q];
+        }
+    s->have_diff = diff;
+    s->cur_sums = -1;
+    s->trial_sums = s->trial_sums_b = false;
+    s->alt_valid = false;
+    // advance: the sweep queued behind becomes the one to report
+    if (s->next_queued) {
+        s->cur_slot = s->next_slot;
+        s->next_queued = false;
+        if (next_dead) {
+            out->skipped_ahead = 1;
+            if (pipeline_takeover(c, s, st, nx, s->cur_slot)) return 1;
+        } else {
+            s->cur_orig = nx.orig; s->cur_new = nx.choice == 1 ? nx.fa : nx.fb; s->cur_L0 = nx.L0;
+            s->cur_choice = nx.choice;
+            s->cur_decided = true;
+        }
+    } else {
+        // nothing queued behind: the host-side roles become the device's (after this sweep's
+        // evaluation, which is accepted unconditionally)
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        Snapshot last;
+        if (wait_snapshot(c, s, s->cur_slot, &last)) return 1;
+        c->mu_cur = last.mu_role[0]; c->mu_ta = last.mu_role[1]; c->mu_tb = last.mu_role[2];
+        c->mom_cur = last.mom_role[1]; c->mom_ta = last.mom_role[0]; c->mom_tb = last.mom_role[2];
+        c->have_moments = true;
+        c->have_b = false;
+        c->tile_sums_ns = 0;
+        c->snp_marked = false;
+        s->armed = false;
+        s->cur_decided = false;
+    }
+    *done = true;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -509,7 +894,9 @@ int vilma_set_state(vilma_ctx *c, void *stream, const double *vi_mu, const doubl
 int vilma_get_state(vilma_ctx *c, double *vi_mu, double *vi_delta, double *hyper, double *tau) {
     if (!c) return 1;
     SW(c);
-    if (vilma_sweep_drain(c)) return 1;
+    // hyper_delta and error_scaling of the last reported sweep are known to the host; only the
+    // per-SNP arrays need the device to stand at that state
+    if ((vi_mu || vi_delta) && vilma_sweep_drain(c)) return 1;
     if (vi_mu && vilma_get_mu(c, vi_mu)) return 1;
     if (vi_delta && vilma_get_delta(c, vi_delta)) return 1;
     if (hyper) {
@@ -563,7 +950,9 @@ int vilma_posterior(vilma_ctx *c, double *mean, double *var) {
 
 int vilma_sweep_drain(vilma_ctx *c) {
     if (!c) return 1;
-    return 0;
+    SweepState *s = c->sw;
+    if (!s || !s->armed) return 0;
+    return pipeline_rollback(c, s, s->pipe_stream);
 }
 
 int vilma_sweep(vilma_ctx *c, void *stream, double L[5], double *elbo, double *running_delta,
@@ -582,6 +971,21 @@ int vilma_sweep(vilma_ctx *c, void *stream, double L[5], double *elbo, double *r
     s->lsr = line_search_rate;
     s->have_diff = false;
     event(s, 3, 0, *elbo, 0.0);
+    {
+        bool done = false;
+        if (pipeline_sweep(c, s, st, L, elbo, running_delta, line_search_rate, flags, out, &done)) {
+            s->stats = nullptr;
+            return 1;
+        }
+        if (done) {
+            s->stats = nullptr;
+            out->elbo = *elbo;
+            out->running = *running_delta;
+            for (int q = 0; q < 5; ++q) out->L[q] = L[q];
+            for (int p = 0; p < c->P; ++p) out->error_scaling[p] = c->tau[p];
+            return 0;
+        }
+    }
     double change = 0.0;
     const int rc = nat_grad_step(c, s, st, L, *running_delta, &change);
     s->stats = nullptr;
