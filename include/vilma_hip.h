@@ -362,6 +362,10 @@ int vilma_posterior(vilma_ctx *ctx, double *mean, double *var);
 #define VILMA_SWEEP_EVENTS 48
 typedef struct {
     double elbo, running;            /* after the sweep (the call's *elbo / *running_delta) */
+    double objective;                /* ELBO of the state the sweep ended in as evaluated on the
+                                        device (vilma_elbo); `elbo` accumulates the sweep's changes
+                                        on the caller's value like the reference does, so the two
+                                        agree to rounding */
     double L[5];
     double diff_sum[3], diff_max[3]; /* convergence statistics of vilma_mean_diff for this sweep
                                         (filled with VILMA_SWEEP_DIFF) */

@@ -11,11 +11,14 @@ skip = float(sys.argv[3]) if len(sys.argv) > 3 else 0.7
 f = glob.glob(os.path.join(src, '**', '*kernel_trace.csv'), recursive=True)[0]
 df = pd.read_csv(f).sort_values('Start_Timestamp').reset_index(drop=True)
 qcol = 'Queue_Id' if 'Queue_Id' in df.columns else None
-first = df.index[df.Kernel_Name.str.contains('mstep')][0]
-last = df.index[df.Kernel_Name.str.contains('mstep')][-1]
+# a decision = the device-resident sweep's decision kernel (r03) or the M-step kernel behind a
+# host decision (earlier rounds)
+mark = 'sweep_decide' if df.Kernel_Name.str.contains('sweep_decide').any() else 'mstep'
+first = df.index[df.Kernel_Name.str.contains(mark)][0]
+last = df.index[df.Kernel_Name.str.contains(mark)][-1]
 start = int(first + skip * (last - first))
-# align on an mstep launch so the window starts at a decision
-while start < len(df) and 'mstep' not in df.Kernel_Name[start]:
+# align on a decision so the window starts at a sweep boundary
+while start < len(df) and mark not in df.Kernel_Name[start]:
     start += 1
 w = df.iloc[start:start + n].copy()
 t0 = w.Start_Timestamp.iloc[0]

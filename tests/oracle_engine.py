@@ -393,4 +393,5 @@ class OracleEngine:
             running = delta_sum
         running = 0.5 * running + 0.5 * max(delta_sum, 0)
         st.error_scaling = list(self.tau) + [1.] * (8 - self.P)
+        st.objective = self._obj
         return elbo + delta_sum, running, st

@@ -33,7 +33,8 @@ class SweepEvent(C.Structure):
 
 class SweepStats(C.Structure):
     """vilma_sweep_stats of include/vilma_hip.h."""
-    _fields_ = [('elbo', C.c_double), ('running', C.c_double), ('L', C.c_double * 5),
+    _fields_ = [('elbo', C.c_double), ('running', C.c_double), ('objective', C.c_double),
+                ('L', C.c_double * 5),
                 ('diff_sum', C.c_double * 3), ('diff_max', C.c_double * 3),
                 ('error_scaling', C.c_double * MAX_COHORTS),
                 ('n_evaluations', C.c_int32), ('n_trials', C.c_int32), ('n_products', C.c_int32),

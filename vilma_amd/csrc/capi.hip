@@ -370,7 +370,8 @@ void side_end(vilma_ctx *c, hipStream_t s, hipStream_t used) {
 // their buffers and step sizes from the context's control block, the host-side roles stay as they are
 int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *totals_dev,
              double *dsum_dev = nullptr, double *dmax_dev = nullptr, double step2 = 0.0,
-             double *totals2_dev = nullptr, int phase = -1) {
+             double *totals2_dev = nullptr, int phase = -1, double *sums_a_dev = nullptr,
+             double *sums_b_dev = nullptr) {
     if (ensure_ready(c)) return 1;
     const bool queued = phase >= 0;
     if (blend && !queued && !c->have_moments)
@@ -384,6 +385,7 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     const int ns = two ? 2 : 1;
     const bool stash = blend && c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, ns);
     if (stash) a.sum_partials = c->sum_partials;
+    if (sums_a_dev && !stash) return fail(c, "this trial cannot deliver the responsibility sums");
     if (!queued) c->tile_sums_ns = stash ? ns : 0;
     if (queued) set_launch_phase(&c->ctl->phase[phase]);
     {
@@ -394,19 +396,19 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
         launch_snp_pass(a, blend, ns, s);
         prof_end(c, s, e0, !blend ? VILMA_PROF_SNP_EVAL : two ? VILMA_PROF_SNP_TRIAL2 : VILMA_PROF_SNP_TRIAL);
     }
-    if (c->overlap && c->ev_snp) {
+    // (a queued sweep puts nothing on the side stream: its sums are part of the finalize launch,
+    // and an event between the pass and the LD product costs microseconds of stream time)
+    if (!queued && c->overlap && c->ev_snp) {
         (void)hipEventRecord(c->ev_snp, s);
         c->snp_marked = true;
     }
     run_ld(c, s, c->pool[c->mom_ta], two ? c->pool[c->mom_tb] : nullptr, -1);
     if (queued) set_launch_phase(nullptr);
-    const int grid = snp_tile_grid(c->N);
-    launch_finalize(c->snp_partials, grid, c->P, c->dot_partials, c->dot_start.data(),
-                    totals_dev, a.diff ? dsum_dev : nullptr, a.diff ? dmax_dev : nullptr, s);
-    if (two)        // candidate B: its partial columns sit behind A's and the statistics columns
-        launch_finalize(c->snp_partials + (int64_t)(2 * c->P + 2 + 6) * grid, grid, c->P,
-                        c->dot_partials + c->dot_stride, c->dot_start.data(), totals2_dev, nullptr,
-                        nullptr, s);
+    // every candidate's totals (and, when asked for, responsibility sums) in one launch
+    launch_finalize(c->snp_partials, snp_tile_grid(c->N), c->P, c->dot_partials, c->dot_stride,
+                    c->dot_start.data(), ns, totals_dev, totals2_dev, a.diff ? dsum_dev : nullptr,
+                    a.diff ? dmax_dev : nullptr, sums_a_dev ? c->sum_partials : nullptr,
+                    snp_sum_rows(c->N, c->A), c->A * c->M, sums_a_dev, sums_b_dev, s);
     if (!queued) c->have_b = two;
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -434,11 +436,8 @@ void reduce_tile_sums(vilma_ctx *c, hipStream_t s, double *sums_a_dev, double *s
 // predicate of the calling thread
 int vilma_detail::queue_trial_phase(vilma_ctx *c, hipStream_t s, bool two, double *totals_a,
                                     double *totals_b, double *sums_a, double *sums_b) {
-    if (evaluate(c, s, true, 0.0, totals_a, nullptr, nullptr, 0.0, two ? totals_b : nullptr,
-                 VILMA_PHASE_TRIAL)) return 1;
-    reduce_tile_sums(c, s, sums_a, two ? sums_b : nullptr);
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    return evaluate(c, s, true, 0.0, totals_a, nullptr, nullptr, 0.0, two ? totals_b : nullptr,
+                    VILMA_PHASE_TRIAL, sums_a, two ? sums_b : nullptr);
 }
 int vilma_detail::queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, double *dsum,
                                    double *dmax) {
@@ -872,8 +871,9 @@ int vilma_eval_given_delta(vilma_ctx *c, void *stream, const double *delta_km_de
     launch_snp_given_delta(a, delta_km_dev, c->lse[c->mom_cur], c->diff_partials,
                            totals_dev + VILMA_NTOTALS(c->P), s);
     run_ld(c, s, c->pool[c->mom_ta], nullptr, -1);
-    launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_start.data(),
-                    totals_dev, nullptr, nullptr, s);
+    launch_finalize(c->snp_partials, snp_pass_grid(c->N), c->P, c->dot_partials, c->dot_stride,
+                    c->dot_start.data(), 1, totals_dev, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                    nullptr, nullptr, s);
     HIPCHK(c, hipGetLastError());
     c->trial_tainted = true;        // these moments belong to no state the line search may accept
     return 0;

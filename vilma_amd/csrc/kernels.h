@@ -232,12 +232,17 @@ void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0,
                            const double *scratch, int64_t s_stride, double *dot_partials,
                            int dot_stride, hipStream_t s);
 
-// totals[0..2P) and [3P..3P+3) from the per-SNP partials, totals[2P..3P) from the matvec dots
-// with dsum/dmax non-null also the six fused convergence statistics (columns 2P+2..2P+7 of the
-// per-SNP partials): three sums -> dsum[3], three maxima -> dmax[3]
+// For each of ncand candidates (its per-SNP partial columns / y.z partials sit behind the first
+// one's): totals[0..2P) and [3P..3P+2) from the per-SNP partials, totals[2P..3P) from the matvec
+// dots.  With dsum/dmax non-null also the six fused convergence statistics (columns 2P+2..2P+7 of
+// the first candidate's partials): three sums -> dsum[3], three maxima -> dmax[3].  With sum_rows
+// non-null also the responsibility sums of each candidate from the per-tile rows of a stashing
+// pass ([ncand][sum_nrows][AM]) -> sums_a / sums_b.  One launch.
 void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
-                     const int32_t *dot_start /*[P+1] host*/, double *totals, double *dsum,
-                     double *dmax, hipStream_t s);
+                     int dot_stride, const int32_t *dot_start /*[P+1] host*/, int ncand,
+                     double *totals_a, double *totals_b, double *dsum, double *dmax,
+                     const double *sum_rows, int sum_nrows, int AM, double *sums_a, double *sums_b,
+                     hipStream_t s);
 
 struct DeltaArgs {
     int32_t N, M, A, P;
@@ -291,7 +296,8 @@ void launch_mean_diff(const double *m_cur, const double *scalings, double *snaps
 int mean_diff_grid(int64_t PN);
 
 // ---- device-resident sweep: the decision kernel (see kernels.hip) ----
-#define VILMA_SNAP_EXTRA 18     // scalars of the control block behind the result vector in a snapshot
+#define VILMA_SNAP_EXTRA 20     // scalars of the control block behind the result vector in a
+                                // snapshot; the last one is the serial number that completes it
 struct SweepDecideParams {
     int P, A, M;
     int check_convergence, have_b, have_sums_b;
@@ -302,7 +308,8 @@ struct SweepDecideParams {
     int o_dsum, o_tot, o_ta, o_tb, o_sa, o_sb, o_hyper, n_results;
     double *lh;
     const double *counts, *log_det;
-    double *snap;
+    double *snap;                   // host memory the device can write (hipHostMallocMapped)
+    double serial;
     BufferBases bases;
 };
 void launch_sweep_decide(const SweepDecideParams &p, hipStream_t s);

@@ -108,6 +108,12 @@ void set_launch_predicate(const int *flag) { g_pred = flag; }
 // vector pools, the per-SNP pass all of its state pointers and step sizes from *g_phase.
 static thread_local const PhasePtrs *g_phase = nullptr;
 void set_launch_phase(const PhasePtrs *pp) { g_phase = pp; }
+// The block is written by an EARLIER kernel (the decision) and only read here: through the
+// constant address space its fields come in by scalar loads and stay in SGPRs -- read through a
+// generic pointer they are vector loads, and every pointer derived from them costs two VGPRs per
+// lane (ld_sym_kernel<2>: 108 -> 140 VGPRs, one wave per SIMD less).
+typedef const PhasePtrs __attribute__((address_space(4))) *phase_tab;
+#define PHASE(pp) ((phase_tab)(pp))
 #define PRED_EXIT(pred) do { if ((pred) != nullptr && *(pred) == 0) return; } while (0)
 
 typedef const double __attribute__((address_space(4))) *const_tab;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_colsum_kernel(
     __shared__ double red[NR][CS_WAVES][128];
     PRED_EXIT(pred);
     PoolPairRW pools = pools_arg;
-    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
+    if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const LdItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     __shared__ double rs_diag[NR][128];
     PRED_EXIT(pred);
     PoolPair pools = pools_arg;
-    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
+    if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const SymItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -478,11 +484,12 @@ __global__ __launch_bounds__(256) void ld_sym_combine_kernel(
     int dot_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double dred[4];
     PRED_EXIT(pred);
-    PoolPairRW pools = pools_arg;
-    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = pp->pool_out2; }
     const int rhs = blockIdx.y;
-    const double *__restrict__ xpool = pools.p[rhs];
-    double *__restrict__ ypool = pools.p[rhs];
+    // (selected with a conditional: indexing a local copy of the pair would put it in scratch)
+    double *const pool_r = pp != nullptr ? (rhs == 0 ? PHASE(pp)->pool_out : PHASE(pp)->pool_out2)
+                                         : (rhs == 0 ? pools_arg.p[0] : pools_arg.p[1]);
+    const double *__restrict__ xpool = pool_r;
+    double *__restrict__ ypool = pool_r;
     const double *__restrict__ scratch = scratch0 + rhs * s_stride;
     double *__restrict__ dot_partials = dot_partials0 + (int64_t)rhs * dot_stride;
     const SymCombItem it = items[blockIdx.x];
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_rowsum_kernel(
     int64_t s_stride, const int *pred, const PhasePtrs *pp) {
     PRED_EXIT(pred);
     PoolPair pools = pools_arg;
-    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
+    if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const RowItem it = items[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -599,11 +606,12 @@ __global__ __launch_bounds__(256) void ld_rowsum_combine_kernel(
     int dot_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double dred[4];
     PRED_EXIT(pred);
-    PoolPairRW pools = pools_arg;
-    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = pp->pool_out2; }
     const int rhs = blockIdx.y;
-    const double *__restrict__ xpool = pools.p[rhs];
-    double *__restrict__ ypool = pools.p[rhs];
+    // (selected with a conditional: indexing a local copy of the pair would put it in scratch)
+    double *const pool_r = pp != nullptr ? (rhs == 0 ? PHASE(pp)->pool_out : PHASE(pp)->pool_out2)
+                                         : (rhs == 0 ? pools_arg.p[0] : pools_arg.p[1]);
+    const double *__restrict__ xpool = pool_r;
+    double *__restrict__ ypool = pool_r;
     const double *__restrict__ scratch = scratch0 + rhs * s_stride;
     double *__restrict__ dot_partials = dot_partials0 + (int64_t)rhs * dot_stride;
     const RowCombItem it = items[blockIdx.x];
@@ -793,7 +801,7 @@ __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_kernel(
     __shared__ double red[2][EIG_THREADS / 64][EIG_RED_SLOTS];
     PRED_EXIT(pred);
     PoolPair pools = pools_arg;
-    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
+    if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const EigItem it = items[blockIdx.x];
     eig_fused_body<R, NR>(it, pools, scratch, s_stride, red);
 }
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_all_kernel(
     __shared__ double red[2][EIG_THREADS / 64][EIG_RED_SLOTS];
     PRED_EXIT(pred);
     PoolPair pools = pools_arg;
-    if (pp != nullptr) { pools.p[0] = pp->pool_out; pools.p[1] = NR == 2 ? pp->pool_out2 : pp->pool_out; }
+    if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const EigItem it = items[blockIdx.x];
     if (it.n <= 2 * EIG_THREADS) eig_fused_body<2, NR>(it, pools, scratch, s_stride, red);
     else if (it.n <= 4 * EIG_THREADS) eig_fused_body<4, NR>(it, pools, scratch, s_stride, red);
@@ -1072,7 +1080,12 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     // decision that assigns the buffers their roles -- from the device-resident phase block
     PhasePtrs q;
     if (a.pp != nullptr) {
-        q = *a.pp;
+        const phase_tab t = PHASE(a.pp);
+        q.mu_in = t->mu_in; q.mu_out = t->mu_out; q.mu_out2 = t->mu_out2;
+        q.pool_cur = t->pool_cur; q.m_cur = t->m_cur; q.lse_ref = t->lse_ref;
+        q.pool_out = t->pool_out; q.m_out = t->m_out; q.v_out = t->v_out; q.lse_out = t->lse_out;
+        q.pool_out2 = t->pool_out2; q.m_out2 = t->m_out2; q.v_out2 = t->v_out2; q.lse_out2 = t->lse_out2;
+        q.step = t->step; q.step2 = t->step2;
     } else {
         q.mu_in = a.mu_in; q.mu_out = a.mu_out; q.mu_out2 = a.mu_out2;
         q.pool_cur = a.pool_cur; q.m_cur = a.m_cur; q.lse_ref = a.lse_ref;
@@ -1699,26 +1712,16 @@ void launch_delta_write(const DeltaArgs &a, hipStream_t s) { launch_delta_any<tr
 // Responsibility sums from the partial rows a stashing snp_pass left behind ([candidate][row][AM],
 // launch_snp_pass): one workgroup per (column, candidate) adds the rows in a fixed order.  The rows
 // were written a moment ago by the pass; a column is rows x 8 B spread over rows lines.
+static __device__ __forceinline__ double block_column_sum(const double *__restrict__ src, int rows,
+                                                          int64_t stride, double *sh);
 __global__ __launch_bounds__(256) void tile_sums_kernel(const double *__restrict__ in, int rows, int AM,
                                                          double *__restrict__ out, int64_t out_zstride,
                                                          const int *pred) {
     __shared__ double sh[4];
     PRED_EXIT(pred);
     const int col = blockIdx.x, z = blockIdx.y;
-    const double *src = in + (int64_t)z * rows * AM + col;
-    double acc = 0.0;
-    for (int r0 = threadIdx.x; r0 < rows; r0 += 8 * 256) {
-        double t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)min(r0 + u * 256, rows - 1) * AM];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = (r0 + u * 256 < rows) ? t[u] : 0.0;
-        acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-    }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) out[(int64_t)z * out_zstride + col] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    const double tot = block_column_sum(in + (int64_t)z * rows * AM + col, rows, AM, sh);
+    if (threadIdx.x == 0) out[(int64_t)z * out_zstride + col] = tot;
 }
 int64_t tile_sums_elems(int64_t N, int A, int M, int ns) {
     return (int64_t)ns * snp_sum_rows(N, A) * A * M;
@@ -2050,40 +2053,84 @@ static __device__ double block_strided_sum_1024(const double *__restrict__ v, in
     return block_sum_1024(acc, sh);
 }
 
-// One 256-thread workgroup per output: workgroups 0..2P+1 reduce a column of the per-SNP
-// partials (stored column-major, so the loads are contiguous), workgroups 2P+2.. reduce a cohort's
-// y.z partials.  Eight independent loads per thread per pass, fixed-order combination.
+// One 256-thread workgroup per output.  For each of `ncand` candidates (one, or the two of a
+// two-step trial): workgroups reduce a column of the per-SNP partials (stored column-major, so the
+// loads are contiguous) or a cohort's y.z partials; then the six convergence statistics (fused
+// diff, evaluations only); then -- when the pass stashed them -- the responsibility sums, one
+// workgroup per (component, candidate) over the per-tile rows.  Eight independent loads per thread
+// per pass, fixed-order combination; everything in ONE launch.
 struct DotStart { int32_t v[VILMA_MAX_P + 1]; };
-__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ snp_partials,
-                                                        int snp_rows, int P,
-                                                        const double *__restrict__ dot_partials,
-                                                        const DotStart dot_start,
-                                                        double *__restrict__ totals,
-                                                        double *__restrict__ dsum,
-                                                        double *__restrict__ dmax, const int *pred) {
+struct FinalizeArgs {
+    const double *snp_partials;     // [ncand][NT + 6][rows]
+    int32_t snp_rows, P, ncand;
+    const double *dot_partials;     // candidate c at + c * dot_stride
+    int32_t dot_stride;
+    DotStart dot_start;
+    double *totals[2];
+    double *dsum, *dmax;            // both or neither
+    const double *sum_rows;         // [ncand][tile rows][AM], or nullptr
+    int32_t sum_nrows, AM;
+    double *sums[2];
+    const int *pred;
+};
+
+// column sum over `rows` rows spaced `stride` doubles by a 256-thread workgroup (shared by
+// tile_sums_kernel and finalize_kernel so both produce the same bits)
+static __device__ __forceinline__ double block_column_sum(const double *__restrict__ src, int rows,
+                                                          int64_t stride, double *sh /*[4]*/) {
+    double acc = 0.0;
+    for (int r0 = threadIdx.x; r0 < rows; r0 += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)min(r0 + u * 256, rows - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (r0 + u * 256 < rows) ? t[u] : 0.0;
+        acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
     __shared__ double sh[4];
-    PRED_EXIT(pred);
-    const int NT = 2 * P + 2;
-    const int c = blockIdx.x;
+    PRED_EXIT(a.pred);
+    const int P = a.P, NT = 2 * P + 2, per_cand = NT + P;
+    int c = blockIdx.x;
+    if (c >= a.ncand * per_cand + (a.dsum != nullptr ? 6 : 0)) {
+        // responsibility sums
+        c -= a.ncand * per_cand + (a.dsum != nullptr ? 6 : 0);
+        const int z = c / a.AM, col = c % a.AM;
+        const double tot = block_column_sum(a.sum_rows + (int64_t)z * a.sum_nrows * a.AM + col,
+                                            a.sum_nrows, a.AM, sh);
+        if (threadIdx.x == 0) a.sums[z][col] = tot;
+        return;
+    }
     const double *src;
     double *dst;
     int n;
     bool is_max = false;
-    if (c < NT) {
-        src = snp_partials + (int64_t)c * snp_rows;
-        n = snp_rows;
-        dst = totals + (c < 2 * P ? c : 3 * P + (c - 2 * P));
-    } else if (c < NT + P) {
-        const int p = c - NT;
-        src = dot_partials + dot_start.v[p];
-        n = dot_start.v[p + 1] - dot_start.v[p];
-        dst = totals + 2 * P + p;
+    if (c < a.ncand * per_cand) {
+        const int z = c / per_cand;
+        c -= z * per_cand;
+        double *totals = a.totals[z];
+        if (c < NT) {
+            src = a.snp_partials + ((int64_t)z * (NT + 6) + c) * a.snp_rows;
+            n = a.snp_rows;
+            dst = totals + (c < 2 * P ? c : 3 * P + (c - 2 * P));
+        } else {
+            const int p = c - NT;
+            src = a.dot_partials + (int64_t)z * a.dot_stride + a.dot_start.v[p];
+            n = a.dot_start.v[p + 1] - a.dot_start.v[p];
+            dst = totals + 2 * P + p;
+        }
     } else {                                    // the six convergence statistics (fused diff)
-        const int q = c - NT - P;
-        src = snp_partials + (int64_t)(NT + q) * snp_rows;
-        n = snp_rows;
+        const int q = c - a.ncand * per_cand;
+        src = a.snp_partials + (int64_t)(NT + q) * a.snp_rows;
+        n = a.snp_rows;
         is_max = q >= 3;
-        dst = q < 3 ? dsum + q : dmax + (q - 3);
+        dst = q < 3 ? a.dsum + q : a.dmax + (q - 3);
     }
     double acc = 0.0;                           // every maximum here is of non-negative numbers
     for (int r0 = threadIdx.x; r0 < n; r0 += 8 * 256) {
@@ -2107,13 +2154,21 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict_
 }
 
 void launch_finalize(const double *snp_partials, int snp_rows, int P, const double *dot_partials,
-                     const int32_t *dot_start, double *totals, double *dsum, double *dmax,
-                     hipStream_t s) {
-    DotStart ds;
-    for (int p = 0; p <= VILMA_MAX_P; ++p) ds.v[p] = p <= P ? dot_start[p] : 0;
-    const int extra = (dsum != nullptr && dmax != nullptr) ? 6 : 0;
-    hipLaunchKernelGGL(finalize_kernel, dim3(3 * P + 2 + extra), dim3(256), 0, s, snp_partials,
-                       snp_rows, P, dot_partials, ds, totals, dsum, dmax, g_pred);
+                     int dot_stride, const int32_t *dot_start, int ncand, double *totals_a,
+                     double *totals_b, double *dsum, double *dmax, const double *sum_rows,
+                     int sum_nrows, int AM, double *sums_a, double *sums_b, hipStream_t s) {
+    FinalizeArgs a;
+    a.snp_partials = snp_partials; a.snp_rows = snp_rows; a.P = P; a.ncand = ncand;
+    a.dot_partials = dot_partials; a.dot_stride = dot_stride;
+    for (int p = 0; p <= VILMA_MAX_P; ++p) a.dot_start.v[p] = p <= P ? dot_start[p] : 0;
+    a.totals[0] = totals_a; a.totals[1] = totals_b;
+    const bool diff = dsum != nullptr && dmax != nullptr;
+    a.dsum = diff ? dsum : nullptr; a.dmax = diff ? dmax : nullptr;
+    a.sum_rows = sum_rows; a.sum_nrows = sum_nrows; a.AM = AM;
+    a.sums[0] = sums_a; a.sums[1] = sums_b;
+    a.pred = g_pred;
+    const int blocks = ncand * (3 * P + 2) + (diff ? 6 : 0) + (sum_rows != nullptr ? ncand * AM : 0);
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(256), 0, s, a);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2408,8 +2463,9 @@ void launch_decide(int P, int check_convergence, const double *totals, const dou
 //     of _update_hyper_delta (:837-848) from the accepted candidate's responsibility sums, the
 //     step sizes of the NEXT trial (L / 1.25 floored at 1, :424) and the pointers both phases of
 //     the next stage will work on.
-// Before anything is overwritten the result vector and the block's scalars are copied aside for
-// the host (one snapshot per decision, fetched on the copy stream).
+// Before anything is overwritten the result vector and the block's scalars are written straight
+// into host memory (one snapshot per decision; the host polls the serial number behind it -- no
+// copy kernel, no event).
 // --------------------------------------------------------------------------------------------
 struct SweepDecideArgs {
     int32_t P, A, M;
@@ -2423,7 +2479,8 @@ struct SweepDecideArgs {
     double *hyper;                   // results + o_hyper
     double *lh;
     const double *counts, *log_det;
-    double *snap;                    // [n_results + VILMA_SNAP_EXTRA]
+    double *snap;                    // [n_results + VILMA_SNAP_EXTRA], host memory mapped for the device
+    double serial;                   // written behind the snapshot when it is complete
     BufferBases bases;
 };
 
@@ -2521,7 +2578,14 @@ __global__ __launch_bounds__(256) void sweep_decide_kernel(const SweepDecideArgs
         x[9] = orig; x[10] = fa; x[11] = fb;
         for (int q = 0; q < 3; ++q) { x[12 + q] = (double)ctl->mu_role[q]; x[15 + q] = (double)ctl->mom_role[q]; }
     }
+    // the snapshot lives in host memory the device writes directly: data first, then the serial
+    // number the host polls for
+    __threadfence_system();
     __syncthreads();
+    if (threadIdx.x == 0) {
+        *(volatile double *)(a.snap + a.n_results + VILMA_SNAP_EXTRA - 1) = a.serial;
+        __threadfence_system();
+    }
     const int choice = sh_choice;
     if (choice == 0) return;
     const double *sums = a.results + (choice == 1 ? a.o_sa : a.o_sb);
@@ -2542,6 +2606,6 @@ void launch_sweep_decide(const SweepDecideParams &p, hipStream_t s) {
     a.o_dsum = p.o_dsum; a.o_tot = p.o_tot; a.o_ta = p.o_ta; a.o_tb = p.o_tb; a.o_sa = p.o_sa;
     a.o_sb = p.o_sb; a.o_hyper = p.o_hyper; a.n_results = p.n_results;
     a.hyper = p.results + p.o_hyper; a.lh = p.lh; a.counts = p.counts; a.log_det = p.log_det;
-    a.snap = p.snap; a.bases = p.bases;
+    a.snap = p.snap; a.serial = p.serial; a.bases = p.bases;
     hipLaunchKernelGGL(sweep_decide_kernel, dim3(1), dim3(256), 0, s, a);
 }

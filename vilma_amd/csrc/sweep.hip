@@ -120,9 +120,9 @@ struct SweepState {
     double pipe_rate = 2.0;
     int slot = 0;                           // snapshot buffer of the next decision queued
     int cur_slot = 0, next_slot = 0;
-    double *snap_dev[2] = {nullptr, nullptr};
-    double *land[2] = {nullptr, nullptr};   // pinned
-    hipEvent_t ev_dec[2] = {nullptr, nullptr}, ev_land[2] = {nullptr, nullptr};
+    double *land[2] = {nullptr, nullptr};   // snapshots: host memory the decision kernel writes
+    double land_serial[2] = {0.0, 0.0};     // the serial number that completes each
+    double serial = 0.0;
     size_t mark_eval[2] = {0, 0};           // profiling brackets pending before a sweep's evaluation
     SweepCtl *ctl_host = nullptr;           // pinned staging of the control block
     // what the decision of the sweep being reported found (from its snapshot)
@@ -142,12 +142,8 @@ void vilma_detail::sweep_destroy(vilma_ctx *c) {
     SweepState *s = c->sw;
     if (!s) return;
     if (s->nccl_comm && rccl().CommDestroy) (void)rccl().CommDestroy(s->nccl_comm);
-    for (int b = 0; b < 2; ++b) {
-        dev_free(s->snap_dev[b]);
+    for (int b = 0; b < 2; ++b)
         if (s->land[b]) (void)hipHostFree(s->land[b]);
-        if (s->ev_dec[b]) (void)hipEventDestroy(s->ev_dec[b]);
-        if (s->ev_land[b]) (void)hipEventDestroy(s->ev_land[b]);
-    }
     if (s->ctl_host) (void)hipHostFree(s->ctl_host);
     dev_free(c->ctl);
     c->ctl = nullptr;
@@ -481,11 +477,9 @@ int pipeline_buffers(vilma_ctx *c, SweepState *s) {
     if (dev_alloc(c, &c->ctl, 1)) return 1;
     HIPCHK(c, hipHostMalloc((void **)&s->ctl_host, sizeof(SweepCtl), hipHostMallocDefault));
     for (int b = 0; b < 2; ++b) {
-        if (dev_alloc(c, &s->snap_dev[b], s->size + VILMA_SNAP_EXTRA)) return 1;
         HIPCHK(c, hipHostMalloc((void **)&s->land[b], (size_t)(s->size + VILMA_SNAP_EXTRA) * sizeof(double),
-                                hipHostMallocDefault));
-        HIPCHK(c, hipEventCreateWithFlags(&s->ev_dec[b], hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&s->ev_land[b], hipEventDisableTiming));
+                                hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(s->land[b], 0, (size_t)(s->size + VILMA_SNAP_EXTRA) * sizeof(double));
     }
     return 0;
 }
@@ -524,15 +518,16 @@ int queue_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fir
         p.o_dsum = s->o_dsum; p.o_tot = s->o_tot; p.o_ta = s->o_ta; p.o_tb = s->o_tb;
         p.o_sa = s->o_sa; p.o_sb = s->o_sb; p.o_hyper = s->o_hyper; p.n_results = s->size;
         p.lh = c->lh; p.counts = c->counts; p.log_det = c->log_det;
-        p.snap = s->snap_dev[b]; p.bases = buffer_bases(c);
-        launch_sweep_decide(p, st);
-        // the snapshot leaves on the copy stream; the compute stream goes straight on
-        if (hipEventRecord(s->ev_dec[b], st) != hipSuccess ||
-            hipStreamWaitEvent(c->copy_stream, s->ev_dec[b], 0) != hipSuccess ||
-            hipMemcpyAsync(s->land[b], s->snap_dev[b], (size_t)(s->size + VILMA_SNAP_EXTRA) * sizeof(double),
-                           hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
-            hipEventRecord(s->ev_land[b], c->copy_stream) != hipSuccess)
-            rc = fail(c, "cannot queue the decision snapshot");
+        // the kernel writes its snapshot straight into host memory and stamps it with this serial
+        // number: no copy, no event; the compute stream goes straight on
+        s->serial += 1.0;
+        s->land_serial[b] = s->serial;
+        void *dptr = nullptr;
+        if (hipHostGetDevicePointer(&dptr, s->land[b], 0) != hipSuccess)
+            rc = fail(c, "the snapshot buffer is not mapped for the device");
+        p.snap = (double *)dptr; p.serial = s->serial; p.bases = buffer_bases(c);
+        if (!rc) launch_sweep_decide(p, st);
+        s->pipe_stream = st;
     }
     if (!rc) {
         s->mark_eval[b] = prof_pending(c);
@@ -585,7 +580,21 @@ struct Snapshot {
 };
 
 int wait_snapshot(vilma_ctx *c, SweepState *s, int b, Snapshot *o) {
-    HIPCHK(c, hipEventSynchronize(s->ev_land[b]));
+    // poll the serial number the decision kernel writes behind its snapshot
+    volatile double *stamp = s->land[b] + s->size + VILMA_SNAP_EXTRA - 1;
+    const double want = s->land_serial[b];
+    for (uint64_t spins = 0; *stamp != want; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfffff) == 0xfffff) {
+            // a long wait: has the stream died (a failed launch would never write the stamp)?
+            const hipError_t q = hipStreamQuery(s->pipe_stream);
+            if (q != hipSuccess && q != hipErrorNotReady)
+                return fail(c, std::string("the queued sweep failed: ") + hipGetErrorString(q));
+            if (q == hipSuccess && *stamp != want)
+                return fail(c, "the queued sweep finished without writing its decision");
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const double *x = s->land[b] + s->size;
     o->r = s->land[b];
     o->alive = x[0] != 0.0; o->choice = (int)x[1];
@@ -601,7 +610,6 @@ int wait_snapshot(vilma_ctx *c, SweepState *s, int b, Snapshot *o) {
 // evaluated) so that the host's line search continues from there.
 int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const Snapshot &sn, int b) {
     HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     prof_truncate(c, s->mark_eval[b]);              // the brackets of launches that exited at once
     c->mu_cur = sn.mu_role[0]; c->mu_ta = sn.mu_role[1]; c->mu_tb = sn.mu_role[2];
     c->mom_cur = sn.mom_role[1]; c->mom_ta = sn.mom_role[0]; c->mom_tb = sn.mom_role[2];
@@ -641,7 +649,6 @@ int pipeline_rollback(vilma_ctx *c, SweepState *s, hipStream_t st) {
     if (!s->armed) return 0;
     Snapshot sn;
     HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     // the last decision the device took (or refused)
     const int b = s->cur_slot;
     if (wait_snapshot(c, s, b, &sn)) return 1;
@@ -775,7 +782,6 @@ int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, doubl
     } else {
         // nothing queued behind: the host-side roles become the device's (after this sweep's
         // evaluation, which is accepted unconditionally)
-        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
         Snapshot last;
         if (wait_snapshot(c, s, s->cur_slot, &last)) return 1;
         c->mu_cur = last.mu_role[0]; c->mu_ta = last.mu_role[1]; c->mu_tb = last.mu_role[2];
@@ -981,6 +987,7 @@ int vilma_sweep(vilma_ctx *c, void *stream, double L[5], double *elbo, double *r
             s->stats = nullptr;
             out->elbo = *elbo;
             out->running = *running_delta;
+            out->objective = s->objective;
             for (int q = 0; q < 5; ++q) out->L[q] = L[q];
             for (int p = 0; p < c->P; ++p) out->error_scaling[p] = c->tau[p];
             return 0;
@@ -1008,6 +1015,7 @@ int vilma_sweep(vilma_ctx *c, void *stream, double L[5], double *elbo, double *r
     }
     out->elbo = *elbo;
     out->running = running;
+    out->objective = s->objective;
     for (int q = 0; q < 5; ++q) out->L[q] = L[q];
     for (int p = 0; p < c->P; ++p) out->error_scaling[p] = c->tau[p];
     return 0;

@@ -91,6 +91,7 @@ class HipEngine:
         self.n_totals = nt
         self._host = np.zeros(L.size)
         self._host_ptr = _ptr(self._host)
+        self._sweep_box = None
         self._comm_cb = None        # keeps the ctypes callback of bind_comm alive
         self.collective = 'none'
 
@@ -469,12 +470,16 @@ class HipEngine:
         """One outer iteration inside the library (vilma_sweep).  L: float64[5], updated in
         place; running None = first sweep.  Returns (elbo, running, stats)."""
         assert L.dtype == np.float64 and L.shape == (5,) and L.flags.c_contiguous
-        e = C.c_double(float(elbo))
-        r = C.c_double(float('nan') if running is None else float(running))
-        stats = _lib.SweepStats()
-        self._check(self.lib.vilma_sweep(self.ctx, self._stream_handle, _ptr(L), C.byref(e),
-                                         C.byref(r), float(line_search_rate), int(flags),
-                                         C.byref(stats)))
+        box = self._sweep_box
+        if box is None:         # argument boxes are reused: this call sits in the fit's inner loop
+            box = self._sweep_box = (C.c_double(), C.c_double(), _lib.SweepStats())
+            self._sweep_refs = (C.byref(box[0]), C.byref(box[1]), C.byref(box[2]))
+        e, r, stats = box
+        e.value = elbo
+        r.value = float('nan') if running is None else running
+        if self.lib.vilma_sweep(self.ctx, self._stream_handle, L.ctypes.data, self._sweep_refs[0],
+                                self._sweep_refs[1], line_search_rate, flags, self._sweep_refs[2]):
+            self._check(1)
         return e.value, r.value, stats
 
     def drain(self):

@@ -76,10 +76,19 @@ class DeviceParams:
     """(vi_mu, vi_delta, hyper_delta) of a state held on the GPU; arrays are downloaded (and
     gathered across ranks) only when indexed, so sweeps do not pay PCIe traffic."""
 
-    def __init__(self, owner, version, hyper):
+    def __init__(self, owner, version):
         self._owner, self._version = owner, version
-        self.hyper_delta = np.array(hyper)
         self._cache = {}
+
+    @property
+    def hyper_delta(self):
+        """[A, M]; host-side state, fetched from the library the first time it is looked at."""
+        if 'hyper' not in self._cache:
+            if self._owner._version != self._version:
+                raise RuntimeError('these parameters are no longer resident on the device; '
+                                   'index the tuple before taking further steps')
+            self._cache['hyper'] = np.array(self._owner._hyper)
+        return self._cache['hyper']
 
     def _fetch(self, which):
         if which not in self._cache:
@@ -143,7 +152,8 @@ class SweepDriver:
         self._look_ok = False       # the caller promises another sweep after this one
         self._veto = self._veto_next = False    # convergence vetoes of this / the next sweep
         self._version = 0           # bumped whenever the device state moves
-        self._hyper = None
+        self._hyper_stale = False
+        self._hyper_value = None
         self._objective = None
         self.n_evaluations = 0      # candidate points whose objective was looked at
         self.n_products = 0         # passes over the LD store (a two-step trial is one)
@@ -265,7 +275,7 @@ class SweepDriver:
         return self.engine.N
 
     def _params(self):
-        return DeviceParams(self, self._version, self._hyper)
+        return DeviceParams(self, self._version)
 
     def _download(self, which):
         """This shard's vi_mu / vi_delta (MultiPopVI gathers them across ranks)."""
@@ -305,17 +315,24 @@ class SweepDriver:
             self.engine.refresh_stream()
         self._upload(params)
         self._require_fixed_point('_optimize_step')
-        if self._hyper is None:
+        L, elbo, running = self._step(L, curr_elbo, running_elbo_delta, line_search_rate, want_diff)
+        return self._params(), L, elbo, running
+
+    def _step(self, L, curr_elbo, running, line_search_rate, want_diff):
+        """One vilma_sweep from the state the device holds; the host-side copies of what it changed
+        (hyper_delta on demand)."""
+        if self._hyper_value is None and not self._hyper_stale:
             raise RuntimeError('nat_grad_vi_delta must always be set prior to running '
                                '_update_beta')
         log_info = logging.getLogger().isEnabledFor(logging.INFO)
         if log_info:
             logging.info('Current ELBO = %f and L = %f,%f,%f,%f,%f', curr_elbo, *L[:5])
-        L = np.ascontiguousarray(L, dtype=np.float64)
+        if L.dtype != np.float64 or not L.flags.c_contiguous:
+            L = np.ascontiguousarray(L, dtype=np.float64)
         was_verbose, self._verbose = self._verbose, self._verbose or log_info
         try:
-            elbo, running, stats = self.engine.sweep(L, curr_elbo, running_elbo_delta,
-                                                     line_search_rate, self._sweep_flags(want_diff))
+            elbo, running, stats = self.engine.sweep(L, curr_elbo, running, line_search_rate,
+                                                     self._sweep_flags(want_diff))
         except RuntimeError as exc:
             # the reference's line-search failure (variational_inference.py:790-799)
             if 'Encountered a numerical error.' in str(exc):
@@ -330,13 +347,26 @@ class SweepDriver:
         self.n_products += stats.n_products
         self.n_stages_ahead += stats.ran_ahead
         self.n_stages_skipped += stats.skipped_ahead
-        self.error_scaling = np.array(stats.error_scaling[:self.num_pops])
-        self._last_diff = (np.array(list(stats.diff_sum) + list(stats.diff_max))
-                           if want_diff else None)
-        self._install_hyper(self.engine.get_hyper())
-        self._objective = self.engine.elbo()
+        if self.scale_se:
+            self.error_scaling = np.array(stats.error_scaling[:self.num_pops])
+        self._last_diff = (np.array(stats.diff_sum[:] + stats.diff_max[:]) if want_diff else None)
+        self._hyper_stale = True        # fetched from the library when somebody looks at it
+        self._nat_table = None
+        self._objective = stats.objective
         self._version += 1
-        return self._params(), L, elbo, running
+        return L, elbo, running
+
+    @property
+    def _hyper(self):
+        if self._hyper_stale:
+            self._hyper_stale = False
+            self._hyper_value = self.engine.get_hyper()
+        return self._hyper_value
+
+    @_hyper.setter
+    def _hyper(self, value):
+        self._hyper_stale = False
+        self._hyper_value = value
 
     def sweep(self, state=None, lookahead=False):
         """One outer iteration as optimize() runs it: _optimize_step + convergence statistics.
@@ -348,10 +378,8 @@ class SweepDriver:
             self.engine.snapshot_mean()
             state = {'L': np.ones(5), 'elbo': self._objective, 'running': None}
         self._look_ok, self._veto, self._veto_next = bool(lookahead), False, False
-        _, L, elbo, running = self._optimize_step(self._params(), L=state['L'],
-                                                   curr_elbo=state['elbo'], line_search_rate=2.,
-                                                   running_elbo_delta=state['running'],
-                                                   want_diff=True)
+        self._given = None
+        L, elbo, running = self._step(state['L'], state['elbo'], state['running'], 2., True)
         return {'L': L, 'elbo': elbo, 'running': running}, self._last_diff
 
     # ------------------------------------------------------------------ driver
