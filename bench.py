@@ -46,9 +46,9 @@ def parse():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--ld-form', default='auto', choices=['auto', 'dense', 'eig'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frac', type=float, default=0.25,
+    ap.add_argument('--cpu-frac', type=float, default=0.5,
                     help='fraction of the workload\'s LD blocks in the CPU-baseline sample')
-    ap.add_argument('--cpu-sweeps', type=int, default=2)
+    ap.add_argument('--cpu-sweeps', type=int, default=5)
     ap.add_argument('--prof-every', type=int, default=0,
                     help='bracket every k-th LD product with HIP events (roofline.avg_launch_ms); '
                          'default: every product on 1 GPU, every 8th on a sharded run, where the '
@@ -81,12 +81,29 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps):
     n_blocks = max(1, min(len(full.sizes_all), int(round(block_frac * len(full.sizes_all)))))
     sh = SyntheticShard(seed=seed, block_range=(0, n_blocks), **cfg).build(None)
     P = sh.P
-    # the GPU box gives one GPU's share of the host (16 cores); keep BLAS and OpenMP inside it
+    # every core this process may USE: the affinity mask, cut by the cgroup's CPU quota (a GPU box
+    # hands out one GPU's share of the host) and by the 64 threads this image's OpenBLAS was built
+    # for (it crashes beyond that); BLAS and OpenMP both get all of them, as numba's prange and
+    # threaded BLAS do for the reference
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(16, avail))
+    quota = None
+    try:
+        txt = open('/sys/fs/cgroup/cpu.max').read().split()
+        if txt[0] != 'max':
+            quota = max(1, int(float(txt[0]) / float(txt[1])))
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = max(1, q // per)
+        except (OSError, ValueError):
+            pass
+    threads = max(1, min(avail, quota or avail, 64))
+    core_note = 'affinity mask %d, cgroup quota %s, OpenBLAS build limit 64' % (avail, quota or 'none')
     # setup (not timed): eigendecompose the sample's blocks, one LAPACK call per core
     with threadpool_limits(limits=1), ThreadPoolExecutor(max_workers=threads) as pool:
         ld = [BlockDiagonalLD(list(pool.map(lambda b: EigenBlock(ar1_numpy(b.n, b.rho[p]), 1.0),
@@ -160,6 +177,7 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps):
         parity = {'error': repr(exc)}
     return {
         'value': (n_sweeps / dt) * frac, 'unit': 'sweeps/s', 'cores': int(threads),
+        'cores_os_cpu_count': os.cpu_count(), 'cores_how': core_note, 'sweeps_timed': int(n_sweeps),
         'kind': 'port', 'parity_vs_cpu': parity,
         'ld_product_share_of_cpu_time': t_ld / dt,
         'sample_fraction_of_snps': frac,
@@ -231,6 +249,7 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29621')
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
     comm = Comm(force=force)
+    # N = 1 under the launcher (WORLD_SIZE=1) is the plain run: no process group, no collective
 
     cfg = dict(WORKLOADS[args.workload])
     t_setup = time.perf_counter()
@@ -260,6 +279,11 @@ def main():
     driver = SweepDriver()
     driver._setup_driver(engine, comm, P, M, 1, chi, ranks, [shard.N_global], log_det,
                          scale_se=False, num_its=args.steps + args.warmup)
+    # one all-reduce through the sweep's own collective, on its stream, before anything is timed:
+    # the communicator is connected and every rank is in it
+    rccl_ranks = engine.comm_check()
+    if comm.active and rccl_ranks != world:
+        raise SystemExit('the collective reached %d rank(s), not %d' % (rccl_ranks, world))
     driver.initialize_from(shard.fake_mu)
     setup_s = time.perf_counter() - t_setup
     elbo0 = driver._objective
@@ -274,7 +298,9 @@ def main():
         engine.snapshot_mean()
         state = {'L': np.ones(5), 'elbo': driver._objective, 'running': None}
 
-    prof_every = args.prof_every or (1 if (world == 1 and args.emulate_shard <= 1) else 8)
+    # an event pair costs ~10 us of stream time: every 2nd product on one GPU (~1 % of a C3 sweep),
+    # every 8th on a shard
+    prof_every = args.prof_every or (2 if (world == 1 and args.emulate_shard <= 1) else 8)
     engine.prof_enable(True, every=prof_every)
     engine.prof_read(reset=True)
     ev0, tr0, ah0 = driver.n_evaluations, driver.n_trials, driver.n_stages_ahead
@@ -292,6 +318,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     prof = engine.prof_read(reset=True)
     engine.prof_enable(False)
     # the dominant kernel = the LD-streaming kernel with the most accumulated time; ld_sym_kernel
@@ -393,6 +420,25 @@ def main():
                                 ('snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2') if prof[k][1]},
         },
     }
+    out['collective'] = engine.collective
+    out['rccl_ranks'] = rccl_ranks
+    if world > 1:
+        # per rank: wall time of the timed region, LD bytes of its shard, its dominant kernel
+        mine = {'ms_per_step': 1e3 * elapsed_local / args.steps, 'ld_algorithmic_bytes': alg_launch,
+                'snps': int(shard.N), 'avg_launch_ms': avg_ms, 'launches': int(launches),
+                'achieved_GBps': achieved}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        out['per_rank'] = {k: [r[k] for r in allr] for k in mine}
+        ms = out['per_rank']['ms_per_step']
+        out['ms_per_step_min_rank'], out['ms_per_step_max_rank'] = min(ms), max(ms)
+        slow = int(np.argmax(out['per_rank']['avg_launch_ms']))
+        r = allr[slow]
+        out['roofline_slowest_rank'] = {
+            'rank': slow, 'kernel': dom, 'achieved': r['achieved_GBps'], 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': r['achieved_GBps'] / HBM_PEAK_GBS,
+            'avg_launch_ms': r['avg_launch_ms'], 'launches': r['launches'],
+            'algorithmic_bytes_per_launch': r['ld_algorithmic_bytes']}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, args.cpu_frac,

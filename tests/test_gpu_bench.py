@@ -58,18 +58,62 @@ def test_bench_two_ranks_launch_line():
     for key in TOP:
         assert key in d, key
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and 'cpu_baseline' not in d
+    # the line says which collective the sweeps used and that every rank was in it; per-rank times,
+    # shard sizes and the slowest rank's roofline ride along
+    assert d['rccl_ranks'] == 2 and 'torch.distributed' in d['collective']
+    pr = d['per_rank']
+    assert len(pr['ms_per_step']) == 2 and len(pr['ld_algorithmic_bytes']) == 2
+    assert d['ms_per_step_min_rank'] <= d['ms_per_step_max_rank'] <= d['ms_per_step'] * 1.5
+    assert sum(pr['snps']) == 6316 or sum(pr['snps']) > 0
+    assert d['roofline_slowest_rank']['rank'] in (0, 1) and 0 < d['roofline_slowest_rank']['frac'] <= 1
     # same global problem as the 1-GPU run: the fit reaches the same ELBO
     one = subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '3',
                           '--warmup', '1', '--no-cpu-baseline'], cwd=ROOT, capture_output=True,
                          text=True, check=True)
-    e1, e2 = _last_json(one.stdout)['config']['elbo_end'], d['config']['elbo_end']
+    o = _last_json(one.stdout)
+    e1, e2 = o['config']['elbo_end'], d['config']['elbo_end']
     assert abs(e1 - e2) < 1e-9 * abs(e1)
+    assert o['collective'] == 'none' and o['rccl_ranks'] == 1 and 'per_rank' not in o
+
+
+def test_bench_one_rank_under_the_launcher_is_the_plain_run():
+    """The driver's N = 1 line may come through torch.distributed.run too (WORLD_SIZE=1): no
+    process group, no collective, the same numbers as `python bench.py`."""
+    args = ['bench.py', '--gpus', '1', '--steps', '4', '--warmup', '1', '--workload', 'tiny',
+            '--no-cpu-baseline']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', str(29890 + os.getpid() % 9)] + args
+    a = _last_json(subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, check=True).stdout)
+    b = _last_json(subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True,
+                                  check=True).stdout)
+    assert a['n_gpus'] == b['n_gpus'] == 1 and a['collective'] == b['collective'] == 'none'
+    assert a['config']['elbo_end'] == b['config']['elbo_end']
+    assert a['config']['beta_trials_per_sweep'] == b['config']['beta_trials_per_sweep']
+
+
+def test_bench_one_rank_rccl_communicator_owned_by_the_context():
+    """VILMA_BENCH_FORCE_RCCL=1: a one-rank RCCL communicator created by the library itself
+    (ncclCommInitRank through dlopen'ed librccl), every sweep's all-reduce queued on the sweep's
+    stream by the library -- what every rank of a real multi-GPU run does."""
+    env = dict(os.environ, VILMA_BENCH_FORCE_RCCL='1', MASTER_PORT=str(29870 + os.getpid() % 9))
+    out = subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '6',
+                          '--warmup', '2', '--no-cpu-baseline'], cwd=ROOT, env=env,
+                         capture_output=True, text=True, check=True)
+    d = _last_json(out.stdout)
+    assert d['collective'].startswith('rccl') and d['rccl_ranks'] == 1
+    plain = _last_json(subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '6',
+                                       '--warmup', '2', '--no-cpu-baseline'], cwd=ROOT,
+                                      capture_output=True, text=True, check=True).stdout)
+    assert d['config']['elbo_end'] == plain['config']['elbo_end']
 
 
 def test_bench_four_ranks_long_run_matches_one_gpu():
     """Four ranks (rehearsed over gloo on this GPU), 30 sweeps with the look-ahead pipeline and
     rejected steps in them: every rank takes the same decisions sweep after sweep (a mismatch
-    would hang a collective) and the sharded fit reaches the single-GPU ELBO."""
+    would hang a collective) and the sharded fit reaches the single-GPU ELBO.  (Four is what a
+    one-GPU box allows beside the test process itself -- at most six processes may hold the card;
+    the eight-rank plan, protocol and driver loop are rehearsed on the CPU:
+    test_driver_cpu.py::test_eight_ranks_gloo.)"""
     env = dict(os.environ, VILMA_BENCH_BACKEND='gloo', VILMA_BENCH_SAME_DEVICE='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4',
            '--master-addr', '127.0.0.1', '--master-port', str(29990 + os.getpid() % 9),

@@ -394,14 +394,25 @@ class HipEngine:
             self.collective = 'none'
             return
         if comm.backend == 'nccl' and not comm.force_callback:
-            ident = C.create_string_buffer(128)
-            if comm.rank == 0 and self.lib.vilma_comm_unique_id(ident):
-                raise _lib.VilmaHipError('ncclGetUniqueId failed (is librccl.so loadable?)')
-            raw = comm.broadcast_bytes(ident.raw)
-            self._check(self.lib.vilma_comm_init_rccl(self.ctx, comm.world, comm.rank,
-                                                      C.create_string_buffer(raw, 128)))
-            self.collective = 'rccl (communicator owned by the context)'
-            return
+            # every rank must end up with the same kind of collective: agree on the outcome
+            err = None
+            try:
+                ident = C.create_string_buffer(128)
+                if comm.rank == 0 and self.lib.vilma_comm_unique_id(ident):
+                    raise _lib.VilmaHipError('ncclGetUniqueId failed (is librccl.so loadable?)')
+                raw = comm.broadcast_bytes(ident.raw)
+                self._check(self.lib.vilma_comm_init_rccl(self.ctx, comm.world, comm.rank,
+                                                          C.create_string_buffer(raw, 128)))
+            except _lib.VilmaHipError as exc:
+                err = str(exc)
+            failed = comm.allreduce_np(np.array([0.0 if err is None else 1.0]))[0]
+            if failed == 0:
+                self.collective = 'rccl (communicator owned by the context)'
+                return
+            import logging
+            logging.warning('the context could not set up its own RCCL communicator on %d rank(s) '
+                            '(%s); the sweep\'s all-reduces go through torch.distributed instead',
+                            int(failed), err or 'another rank failed')
         base, results = int(self._results_ptr), self.results
 
         def allreduce(_user, _stream, buf, n, op):
@@ -420,6 +431,26 @@ class HipEngine:
         self._check(self.lib.vilma_comm_set_callback(self.ctx, self._comm_cb, None, comm.world,
                                                      comm.rank))
         self.collective = 'callback into torch.distributed (%s)' % comm.backend
+
+    def comm_check(self):
+        """All-reduce a one per rank through the context's collective on the engine's stream:
+        the number of ranks that took part (1 without a collective)."""
+        t = self.torch
+        one = t.ones(1, dtype=t.float64, device=self.device)
+        kind = C.c_int()
+        self._check(self.lib.vilma_comm_info(self.ctx, C.byref(kind), None, None))
+        if kind.value == 2:                 # the callback only knows slices of the result vector
+            keep = self.results[:1].clone()
+            self.results[:1] = 1.0
+            self._check(self.lib.vilma_comm_allreduce(self.ctx, self._stream_handle,
+                                                      self._p['results'], 1, 0))
+            got = float(self.results[0].item())
+            self.results[:1] = keep
+            return int(round(got))
+        self._check(self.lib.vilma_comm_allreduce(self.ctx, self._stream_handle,
+                                                  C.c_void_p(one.data_ptr()), 1, 0))
+        self.torch.cuda.current_stream().synchronize()
+        return int(round(float(one.item())))
 
     def set_state(self, vi_mu, hyper, tau=None):
         """Make (vi_mu [M,P,N] or None = keep the device's, hyper_delta, error_scaling) the
