@@ -298,9 +298,9 @@ def main():
         engine.snapshot_mean()
         state = {'L': np.ones(5), 'elbo': driver._objective, 'running': None}
 
-    # an event pair costs ~10 us of stream time: every 2nd product on one GPU (~1 % of a C3 sweep),
-    # every 8th on a shard
-    prof_every = args.prof_every or (2 if (world == 1 and args.emulate_shard <= 1) else 8)
+    # an event pair costs ~10 us of stream time: every 3rd product on one GPU (<1 % of a C3 sweep;
+    # an odd stride, so one- and two-right-hand-side launches are both sampled), every 9th on a shard
+    prof_every = args.prof_every or (3 if (world == 1 and args.emulate_shard <= 1) else 9)
     engine.prof_enable(True, every=prof_every)
     engine.prof_read(reset=True)
     ev0, tr0, ah0 = driver.n_evaluations, driver.n_trials, driver.n_stages_ahead

@@ -300,9 +300,13 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
         if (it.n_eig_all < c->eig_merge_below)
             launch_ld_eig_fused_all(it.eig_all, it.n_eig_all, pl, pl2, c->sym_scratch, c->s_stride, s);
         else
-            for (int k = 0; k < 4; ++k)
-                launch_ld_eig_fused(it.eig[k], it.n_eig[k], eig_class_rows(k), pl, pl2,
-                                    c->sym_scratch, c->s_stride, s);
+            for (int k = 0; k < 4; ++k) {
+                if (k == 0 && c->eig_wave)
+                    launch_ld_eig_wave(it.eig[0], it.n_eig[0], pl, pl2, c->sym_scratch, c->s_stride, s);
+                else
+                    launch_ld_eig_fused(it.eig[k], it.n_eig[k], eig_class_rows(k), pl, pl2,
+                                        c->sym_scratch, c->s_stride, s);
+            }
         launch_ld_rowsum_combine(it.fcomb, it.n_fcomb, pl, pl2, c->sym_scratch, c->s_stride,
                                  c->dot_partials, c->dot_stride, s);
         for (const EigenGroup &g : it.groups) {
@@ -512,6 +516,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     }
     if (const char *ef = std::getenv("VILMA_EIG_FUSED")) c->eig_fused = ef[0] != '0';
     if (const char *mb = std::getenv("VILMA_EIG_MERGE_BELOW")) c->eig_merge_below = std::atoi(mb);
+    if (const char *ew = std::getenv("VILMA_EIG_WAVE")) c->eig_wave = ew[0] != '0';
     if (const char *se = std::getenv("VILMA_EIG_SLAB_ELEMS")) {
         const int v = std::atoi(se);
         if (v >= 1024) g_eig_slab_elems = v;

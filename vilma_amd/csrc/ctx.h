@@ -71,7 +71,9 @@ inline int pad2(int n) { return (n + 1) & ~1; }
 inline int g_eig_slab_elems = 49152;
 inline int eig_slab_cols(int n, int R) {
     const int C = eig_batch_cols(R);
-    const int want = (g_eig_slab_elems / n + C - 1) / C * C;
+    // blocks of up to 512 rows (R = 2) are taken one slab per WAVE: a quarter of the budget each
+    const int budget = R == 2 ? g_eig_slab_elems / 2 : g_eig_slab_elems;
+    const int want = (budget / n + C - 1) / C * C;
     return std::max(C, std::min(128, want));
 }
 inline int eig_n_slabs(int n, int r, int R) {
@@ -159,6 +161,9 @@ struct vilma_ctx {
     // eigen-form blocks go through the fused product (panel-major U, read once) unless
     // VILMA_EIG_FUSED=0 or the block is too tall for the LDS of a CU
     bool eig_fused = true;
+    // blocks of up to 512 rows: one wave per slab of columns, no barrier (VILMA_EIG_WAVE=0: the
+    // workgroup-wide kernel for them too)
+    bool eig_wave = true;
     // fewer fused work items than this: one launch for all block heights (VILMA_EIG_MERGE_BELOW)
     int eig_merge_below = 8192;
     double *repack_tmp = nullptr;   // row-major staging of one block's U before the panel repack

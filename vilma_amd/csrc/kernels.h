@@ -216,6 +216,9 @@ int eig_batch_cols(int R);
 // One launch takes the items of ONE class R (rows per thread).
 void launch_ld_eig_fused(const EigItem *items, int n_items, int R, const double *pool0,
                          const double *pool1, double *scratch, int64_t s_stride, hipStream_t s);
+// the class of blocks of up to 512 rows (R = 2): one WAVE per slab of columns, no barrier
+void launch_ld_eig_wave(const EigItem *items, int n_items, const double *pool0, const double *pool1,
+                        double *scratch, int64_t s_stride, hipStream_t s);
 // the items of every class in one launch (small shards: one ramp and tail instead of four)
 void launch_ld_eig_fused_all(const EigItem *items, int n_items, const double *pool0,
                              const double *pool1, double *scratch, int64_t s_stride,

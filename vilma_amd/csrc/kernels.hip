@@ -790,6 +790,136 @@ static __device__ __forceinline__ void eig_fused_body(
     }
 }
 
+// Blocks of up to 512 rows: ONE WAVE owns a slab of columns (lane l holds rows 128 i + 2 l, + 1,
+// i < 4), so the column sums need the in-wave butterfly only -- no LDS, no workgroup barrier -- and
+// the four waves of a workgroup work on four different slabs.  With the workgroup-wide kernel a
+// batch of this class is 8 columns x <= 512 rows = 32 KB between barriers, and with two
+// right-hand sides it needs two butterflies, an LDS exchange and a barrier per batch: 277 us
+// against 102 us with one right-hand side at C4 (profiles/r02q_c4_stats_kernel_stats.csv), slower
+// than two separate products.  Here a batch is 2 columns (8 loads of 1 KiB in flight per wave,
+// the next batch's issued before this one is used), its 2 NR dot products go through one
+// butterfly and come back as wave-uniform scalars (v_readlane).
+#define EIGW_ROWS 512
+#define EIGW_C 2
+template <int NR>
+static __device__ __forceinline__ void eig_wave_body(const EigItem &it, const PoolPair &pools,
+                                                     double *__restrict__ scratch, int64_t s_stride) {
+    constexpr int H = EIGW_ROWS / 128;             // 16-byte loads per column per lane
+    constexpr int C = EIGW_C;
+    const int n = it.n, ncols = it.ncols;
+    const int64_t ldc = it.ldc;
+    const int lane = threadIdx.x & 63;
+    const int row0 = 2 * lane;                     // + 128 i
+    double x[NR][2 * H], y[NR][2 * H];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double *xg = pools.p[r] + it.x_off;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const int row = row0 + 128 * i;
+            x[r][2 * i] = row < n ? xg[row] : 0.0;
+            x[r][2 * i + 1] = row + 1 < n ? xg[row + 1] : 0.0;
+            y[r][2 * i] = y[r][2 * i + 1] = 0.0;
+        }
+    }
+    const double *colp = it.a + row0;
+    v2d nxt[C][H];
+    auto issue = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const bool ok = c0 + c < ncols && row0 + 128 * i < n;
+                nxt[c][i] = ok ? LD_STREAM_LOAD(colp + (int64_t)(c0 + c) * ldc + 128 * i) : v2d{0.0, 0.0};
+            }
+    };
+    issue(0);
+    for (int c0 = 0; c0 < ncols; c0 += C) {
+        v2d cur[C][H];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int i = 0; i < H; ++i) cur[c][i] = nxt[c][i];
+        issue(c0 + C);                             // nothing is loaded past the slab's last column
+        double p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                    sacc = fma(cur[c][i].x, x[r][2 * i], sacc);
+                    sacc = fma(cur[c][i].y, x[r][2 * i + 1], sacc);
+                }
+                p[c * NR + r] = sacc;
+            }
+        int slot;
+        const double tot = sym_rowsum8(p, lane, slot);
+        // value v sits in the lanes whose bits 5..3 spell v: lane 8 * perm(v); read each back as a
+        // wave-uniform scalar
+        const int lo = __double2loint(tot), hi = __double2hiint(tot);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double sc = c0 + c < ncols ? it.scale[c0 + c] : 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int v = c * NR + r;
+                // slot = bit5*4 + bit4*2 + bit3  =>  lane with slot v and bits 2..0 = 0
+                const int src = ((v & 4) ? 32 : 0) | ((v & 2) ? 16 : 0) | ((v & 1) ? 8 : 0);
+                const double t = __hiloint2double(__builtin_amdgcn_readlane(hi, src),
+                                                  __builtin_amdgcn_readlane(lo, src)) * sc;
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                    y[r][2 * i] = fma(cur[c][i].x, t, y[r][2 * i]);
+                    y[r][2 * i + 1] = fma(cur[c][i].y, t, y[r][2 * i + 1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        double *so = scratch + r * s_stride + it.s_off;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const int row = row0 + 128 * i;
+            if (row < n) so[row] = y[r][2 * i];
+            if (row + 1 < n) so[row + 1] = y[r][2 * i + 1];
+        }
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void ld_eig_wave_kernel(
+    const EigItem *__restrict__ items, int n_items, const PoolPair pools_arg,
+    double *__restrict__ scratch, int64_t s_stride, const int *pred, const PhasePtrs *pp) {
+    PRED_EXIT(pred);
+    PoolPair pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int idx = blockIdx.x * 4 + w;            // one slab per wave
+    if (idx >= n_items) return;
+    const EigItem it = items[idx];
+    eig_wave_body<NR>(it, pools, scratch, s_stride);
+}
+
+void launch_ld_eig_wave(const EigItem *items, int n_items, const double *pool0, const double *pool1,
+                        double *scratch, int64_t s_stride, hipStream_t s) {
+    if (n_items <= 0) return;
+    PoolPair pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    const dim3 grid((n_items + 3) / 4), block(256);
+    if (pool1)
+        hipLaunchKernelGGL((ld_eig_wave_kernel<2>), grid, block, 0, s, items, n_items, pp, scratch,
+                           s_stride, g_pred, g_phase);
+    else
+        hipLaunchKernelGGL((ld_eig_wave_kernel<1>), grid, block, 0, s, items, n_items, pp, scratch,
+                           s_stride, g_pred, g_phase);
+}
+
 // One launch per block-height class present (R = rows per thread).  A single kernel switching on
 // the class at run time was measured and is slower (C4, one right-hand side: 695 us against
 // 620 us for the four launches together): it runs every class with the register budget of the
