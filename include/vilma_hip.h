@@ -401,6 +401,20 @@ typedef struct {
 int vilma_sweep(vilma_ctx *ctx, void *stream, double L[5], double *elbo, double *running_delta,
                 double line_search_rate, int flags, vilma_sweep_stats *stats);
 
+/* The three updates vilma_sweep is made of, one at a time, for hosts (and tests) that drive the
+ * reference's private steps themselves.  Each starts from the current state (vilma_set_state /
+ * the previous update) and leaves the updated state current.
+ *   vilma_update_beta: _update_beta (variational_inference.py:762-802): ONE damped natural-gradient
+ *     step with backtracking on *L0 (multiplied by line_search_rate per rejected trial);
+ *     *orig_obj / *new_obj = objective before / after (equal when the search gave up beyond L_MAX).
+ *   vilma_update_hyper_delta: _update_hyper_delta (:825-860), the closed-form M-step + re-evaluation.
+ *   vilma_update_error_scaling: _update_error_scaling (:472-486) followed by the re-evaluation
+ *     _nat_grad_step does behind it (:442-447); error_scaling through vilma_get_state. */
+int vilma_update_beta(vilma_ctx *ctx, void *stream, double *L0, double line_search_rate,
+                      double *orig_obj, double *new_obj);
+int vilma_update_hyper_delta(vilma_ctx *ctx, void *stream, double *orig_obj, double *new_obj);
+int vilma_update_error_scaling(vilma_ctx *ctx, void *stream, double *orig_obj, double *new_obj);
+
 /* Forget work queued ahead by VILMA_SWEEP_LOOKAHEAD (the caller breaks its promise): waits for
  * it, restores the state after the last sweep reported.  A no-op otherwise. */
 int vilma_sweep_drain(vilma_ctx *ctx);

@@ -13,6 +13,7 @@ Python, so the semantics are the reference's own up to summation order.
 Outputs (committed, data only):
     tests/golden/numerics_kat.npz          per-function known-answer vectors (numerics.py)
     tests/golden/ldop_kat.npz              LowRankMatrix / BlockDiagonalMatrix vectors
+    tests/golden/vischeme_kat.npz          MultiPopVI behaviours on the reference tests' own problems
     tests/golden/traj_<name>.npz           class-API trajectories driven through
                                            MultiPopVI._optimize_step (variational_inference.py:396)
     tests/golden/mixgrid_kat.npz           vi_options._make_simple outputs (RNG order pin)
@@ -310,6 +311,10 @@ def ldop_kat():
         out[tag + 'ridge'] = bd.ridge_inverse_dot(vec, reg)
         out[tag + 'ridge_scalar'] = bd.ridge_inverse_dot(vec, 0.7)
         out[tag + 'diag'] = bd.diag()
+        out[tag + 'dot_i'] = np.array([bd.dot_i(vec, i) for i in range(N)])
+        out[tag + 'sqrt_dot'] = bd.matrix_power(0.5).dot(vec)
+        out[tag + 'inv_inv_dot'] = bd.inverse.inverse.dot(vec)
+        out[tag + 'dot_matrix'] = bd.dot(np.stack([vec, 2 * vec - 1], axis=1))
         out[tag + 'rank'] = bd.get_rank()
         out[tag + 'ranks'] = np.array([m.get_rank() for m in lrs])
         out[tag + 'starts'] = bd.starts
@@ -325,6 +330,102 @@ def ldop_kat():
     out['degenerate_rank'] = lr.get_rank()
     out['degenerate_dot'] = lr.dot(np.arange(4.0))
     np.savez_compressed(os.path.join(HERE, 'ldop_kat.npz'), **out)
+
+
+def vischeme_problem(linked, num_annotations):
+    """The two little problems the reference's own behavioural tests are written on
+    (tests/test.py:1225-1293): 2 cohorts x 50 SNPs, one LD block (a fixed dense correlation
+    matrix, or the identity for the "unlinked" variant), two mixture components."""
+    if linked:
+        betas = np.arange(100).reshape(2, 50).astype(float)
+        ld = (1 + np.arange(50 * 50)).reshape(50, 50) / (50 * 50 + 1)
+        ld = ld + ld.T + 5 * np.eye(50)
+        d = np.diag(1 / np.sqrt(np.diag(ld)))
+        ld = d @ ld @ d
+    else:
+        betas = np.arange(100).reshape(50, 2).T.astype(float)
+        ld = np.eye(50)
+    std_errs = np.array([1.] * 50 + [2.] * 50).reshape(2, 50)
+    if num_annotations == 2:
+        ann = np.zeros((50, 2), dtype=int)
+        ann[0:25, 0] = 1
+        ann[25:, 1] = 1
+    else:
+        ann = np.ones((50, 1), dtype=int)
+    return dict(betas=betas, std_errs=std_errs, ld=ld, annotations=ann,
+                mixture_covs=[np.eye(2), 2 * np.eye(2)], gwas_N=np.array([100e3, 10e3]),
+                init_hg=np.array([0.1, 0.9]))
+
+
+def vischeme_kat():
+    """What the reference's MultiPopVI computes on those problems: construction-time constants,
+    _initialize, _update_error_scaling, _nat_to_not_vi_delta, _update_beta (twice: idempotence),
+    _nat_grad_step, a few sweeps and optimize() -- the behaviours tests/test.py:1297-1411,
+    1473-1514, 1582-1604, 1704-1726, 1849-1876 assert."""
+    out = {}
+    for tag, linked, A, scaled, scale_se in (('linked_a2', True, 2, False, False),
+                                             ('unlinked_a1', False, 1, False, False),
+                                             ('linked_a1_scaled', True, 1, True, False),
+                                             ('linked_a2_scale_se', True, 2, False, True),
+                                             ('linked_a2_scaled_scale_se', True, 2, True, True)):
+        pr = vischeme_problem(linked, A)
+        lr = rms.LowRankMatrix(X=pr['ld'], t=1.0)
+        vi = rvi.MultiPopVI(marginal_effects=pr['betas'], std_errs=pr['std_errs'],
+                            ld_mats=[rms.BlockDiagonalMatrix([lr]), rms.BlockDiagonalMatrix([lr])],
+                            mixture_covs=pr['mixture_covs'], annotations=pr['annotations'],
+                            checkpoint=False, checkpoint_freq=-1, output='test', scaled=scaled,
+                            scale_se=scale_se, gwas_N=pr['gwas_N'], init_hg=pr['init_hg'],
+                            num_its=20)
+        t = tag + '_'
+        for key in ('vi_sigma', 'nat_sigma', 'vi_sigma_log_det', 'vi_sigma_matches',
+                    'sigma_summary', 'adj_marginal_effects', 'chi_stat', 'ld_ranks',
+                    'inverse_betas', 'scaled_ld_diags', 'ld_diags', 'scalings', 'log_det'):
+            out[t + key] = np.array(getattr(vi, key))
+        np.random.seed(42)
+        mu, delta, hyper = vi._initialize()
+        params = (mu, delta, hyper)
+        out[t + 'init_mu'], out[t + 'init_delta'], out[t + 'init_hyper'] = mu, delta, hyper
+        out[t + 'init_elbo'] = vi.elbo(params)
+        out[t + 'init_post_mean'] = vi.real_posterior_mean(*params)
+        out[t + 'init_post_var'] = vi.real_posterior_variance(*params)
+        # _nat_to_not_vi_delta at the initial point
+        out[t + 'fixed_point_delta'] = vi._nat_to_not_vi_delta(params)[1]
+        # _update_error_scaling at the initial point, then back to tau = 1
+        vi._update_error_scaling(params)
+        out[t + 'tau_after_update'] = np.array(vi.error_scaling)
+        out[t + 'elbo_after_tau'] = vi.elbo(vi._nat_to_not_vi_delta(params))
+        vi.error_scaling = np.ones(2)
+        vi._set_vi_sigma()
+        # _update_beta twice from the fixed point of the initial state
+        fp = vi._nat_to_not_vi_delta(params)
+        p1, L1, o1, n1 = vi._update_beta(*fp, None, [1., 1., 1.], 0, 1.25)
+        p2, L2, o2, n2 = vi._update_beta(*p1, None, [1., 1., 1.], 0, 1.25)
+        out[t + 'ub1_mu'], out[t + 'ub1_delta'] = p1[0], p1[1]
+        out[t + 'ub1_objs'] = np.array([o1, n1]); out[t + 'ub1_L'] = np.array(L1)
+        out[t + 'ub2_mu'], out[t + 'ub2_delta'] = p2[0], p2[1]
+        out[t + 'ub2_objs'] = np.array([o2, n2]); out[t + 'ub2_L'] = np.array(L2)
+        # _update_hyper_delta from there
+        p3, L3, o3, n3 = vi._update_hyper_delta(*p1, None, [1., 1., 1.], 1, 1.25)
+        out[t + 'uh_hyper'], out[t + 'uh_delta'] = p3[2], p3[1]
+        out[t + 'uh_objs'] = np.array([o3, n3])
+        # _nat_grad_step from the fixed point, from L = 1 and from close to L_MAX
+        vi.error_scaling = np.ones(2)
+        vi._set_vi_sigma()
+        vi.nat_grad_vi_delta = rn.fast_vi_delta_grad(hyper, vi.log_det, vi.annotations)
+        q, Lq, dq = vi._nat_grad_step(fp, [1., 1., 1.], 2., None)
+        out[t + 'ngs_mu'], out[t + 'ngs_hyper'] = q[0], q[2]
+        out[t + 'ngs_L'], out[t + 'ngs_delta_elbo'] = np.array(Lq), dq
+        out[t + 'ngs_tau'] = np.array(vi.error_scaling)
+        # optimize() from the same seed
+        vi.error_scaling = np.ones(2)
+        vi._set_vi_sigma()
+        np.random.seed(42)
+        final = vi.optimize()
+        out[t + 'opt_elbo'] = vi.elbo(final)
+        out[t + 'opt_post_mean'] = vi.real_posterior_mean(*final)
+        out[t + 'opt_tau'] = np.array(vi.error_scaling)
+        out[t + 'opt_hyper'] = final[2]
+    np.savez_compressed(os.path.join(HERE, 'vischeme_kat.npz'), **out)
 
 
 def mixgrid_kat():
@@ -469,6 +570,10 @@ def main():
 
     if want('kat'):
         numerics_kat(); ldop_kat(); mixgrid_kat(); loader_kat()
+    if want('kat') or want('vischeme'):
+        vischeme_kat()
+    if want('ldop'):
+        ldop_kat()
     if want('kat') or want('sim'):
         sim_kat()
     if want('p1_dense'):

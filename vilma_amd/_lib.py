@@ -131,6 +131,9 @@ def load():
         'vilma_posterior': (C.c_int, [vp, vp, vp]),
         'vilma_sweep': (C.c_int, [vp, vp, vp, vp, vp, C.c_double, C.c_int, vp]),
         'vilma_sweep_drain': (C.c_int, [vp]),
+        'vilma_update_beta': (C.c_int, [vp, vp, vp, C.c_double, vp, vp]),
+        'vilma_update_hyper_delta': (C.c_int, [vp, vp, vp, vp]),
+        'vilma_update_error_scaling': (C.c_int, [vp, vp, vp, vp]),
         'vilma_prof_enable': (C.c_int, [vp, C.c_int]),
         'vilma_prof_read': (C.c_int, [vp, _c_double_p, _c_i64_p, C.c_int]),
         # include/vilma_numerics.h -- the Function API (vilma_amd/numerics.py)

@@ -954,6 +954,56 @@ int vilma_posterior(vilma_ctx *c, double *mean, double *var) {
     return 0;
 }
 
+int vilma_update_beta(vilma_ctx *c, void *stream, double *L0, double rate, double *orig_obj,
+                      double *new_obj) {
+    if (!c) return 1;
+    SW(c);
+    if (!s->have_state) return fail(c, "no state: call vilma_set_state or vilma_initialize");
+    if (!L0 || !(rate > 1.0)) return fail(c, "vilma_update_beta: L0 and a line_search_rate > 1 are required");
+    if (vilma_sweep_drain(c)) return 1;
+    s->stats = nullptr;
+    s->flags = 0;
+    s->lsr = rate;
+    double L[5] = {*L0, 1.0, 1.0, 1.0, 1.0};
+    const double orig = s->objective;
+    double nw;
+    if (update_beta(c, s, (hipStream_t)stream, L, orig, &nw)) return 1;
+    *L0 = L[0];
+    if (orig_obj) *orig_obj = orig;
+    if (new_obj) *new_obj = nw;
+    return 0;
+}
+
+int vilma_update_hyper_delta(vilma_ctx *c, void *stream, double *orig_obj, double *new_obj) {
+    if (!c) return 1;
+    SW(c);
+    if (!s->have_state) return fail(c, "no state: call vilma_set_state or vilma_initialize");
+    if (vilma_sweep_drain(c)) return 1;
+    s->stats = nullptr;
+    s->flags = 0;
+    const double orig = s->objective;
+    double nw;
+    if (update_hyper(c, s, (hipStream_t)stream, false, &nw)) return 1;
+    if (orig_obj) *orig_obj = orig;
+    if (new_obj) *new_obj = nw;
+    return 0;
+}
+
+int vilma_update_error_scaling(vilma_ctx *c, void *stream, double *orig_obj, double *new_obj) {
+    if (!c) return 1;
+    SW(c);
+    if (!s->have_state) return fail(c, "no state: call vilma_set_state or vilma_initialize");
+    if (vilma_sweep_drain(c)) return 1;
+    s->stats = nullptr;
+    s->flags = 0;
+    const double orig = s->objective;
+    double nw;
+    if (update_error_scaling(c, s, (hipStream_t)stream, &nw)) return 1;
+    if (orig_obj) *orig_obj = orig;
+    if (new_obj) *new_obj = nw;
+    return 0;
+}
+
 int vilma_sweep_drain(vilma_ctx *c) {
     if (!c) return 1;
     SweepState *s = c->sw;

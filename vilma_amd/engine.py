@@ -516,6 +516,25 @@ class HipEngine:
     def drain(self):
         self._check(self.lib.vilma_sweep_drain(self.ctx))
 
+    def update_beta(self, L0, line_search_rate):
+        """_update_beta from the current state; returns (L0 after backtracking, orig, new)."""
+        L, o, n = C.c_double(float(L0)), C.c_double(), C.c_double()
+        self._check(self.lib.vilma_update_beta(self.ctx, self._stream_handle, C.byref(L),
+                                               float(line_search_rate), C.byref(o), C.byref(n)))
+        return L.value, o.value, n.value
+
+    def update_hyper_delta(self):
+        o, n = C.c_double(), C.c_double()
+        self._check(self.lib.vilma_update_hyper_delta(self.ctx, self._stream_handle, C.byref(o),
+                                                      C.byref(n)))
+        return o.value, n.value
+
+    def update_error_scaling(self):
+        o, n = C.c_double(), C.c_double()
+        self._check(self.lib.vilma_update_error_scaling(self.ctx, self._stream_handle,
+                                                        C.byref(o), C.byref(n)))
+        return o.value, n.value
+
     # ------------------------------------------------------------------ measurement
     def prof_enable(self, on=True, every=1):
         """Bracket every `every`-th LD launch with HIP events (each pair costs a few microseconds

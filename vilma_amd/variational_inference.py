@@ -778,3 +778,78 @@ class MultiPopVI(SweepDriver):
         self._upload(params)
         self._require_fixed_point('_set_state')
 
+    # ------------------------------------------------------------------ the reference's private steps
+    # Same names and argument order as the reference's methods, so code (and tests) written against
+    # them keep working; each is one call into the library on the state `params` describes.
+    def _posterior_mean(self, vi_mu, vi_delta, hyper_delta=None):
+        """variational_inference.py:753-755 (without scalings)."""
+        return self._moments((vi_mu, vi_delta, hyper_delta if hyper_delta is not None
+                              else self._hyper))[0]
+
+    def _posterior_marginal_variance(self, post_mean, vi_mu, vi_delta, hyper_delta=None):
+        """variational_inference.py:757-760 (without scalings)."""
+        return self._moments((vi_mu, vi_delta, hyper_delta if hyper_delta is not None
+                              else self._hyper))[1]
+
+    def _nat_to_not_vi_delta(self, params):
+        """variational_inference.py:632-641: params with vi_delta replaced by the fixed point of
+        (vi_mu, hyper_delta, error_scaling)."""
+        vi_mu, _, hyper = params[0], params[1], params[2]
+        self.start_from(self._local_part(np.asarray(vi_mu)), hyper)
+        p = self._params()
+        return (p[0], p[1], p[2])
+
+    def _continue_from(self, params, what):
+        self._upload(params)
+        self._require_fixed_point(what)
+
+    def _update_beta(self, vi_mu, vi_delta, hyper_delta, orig_obj, L, idx, lsr):
+        """variational_inference.py:762-802."""
+        self._continue_from((vi_mu, vi_delta, hyper_delta), '_update_beta')
+        if self._hyper is None:
+            raise RuntimeError('nat_grad_vi_delta must always be set prior to running '
+                               '_update_beta')
+        try:
+            L[idx], orig, new = self.engine.update_beta(L[idx], lsr)
+        except RuntimeError as exc:
+            if 'Encountered a numerical error.' in str(exc):
+                raise RuntimeError('Encountered a numerical error.') from exc
+            raise
+        self._objective = new
+        self._version += 1
+        p = self._params()
+        return (p[0], p[1], p[2]), L, (orig if orig_obj is None else orig_obj), new
+
+    def _update_hyper_delta(self, vi_mu, vi_delta, hyper_delta, orig_obj, L, idx, lsr):
+        """variational_inference.py:825-860."""
+        self._continue_from((vi_mu, vi_delta, hyper_delta), '_update_hyper_delta')
+        orig, new = self.engine.update_hyper_delta()
+        self._objective = new
+        self._hyper_stale = True
+        self._nat_table = None
+        self._version += 1
+        p = self._params()
+        return (p[0], p[1], p[2]), L, (orig if orig_obj is None else orig_obj), new
+
+    def _update_error_scaling(self, params):
+        """variational_inference.py:472-486 (the sigma-dependent constants follow tau inside the
+        kernels, so _set_vi_sigma is implied)."""
+        self._continue_from(params, '_update_error_scaling')
+        _, new = self.engine.update_error_scaling()
+        self.error_scaling = self.engine.get_tau()
+        self._objective = new
+        self._version += 1
+
+    def _set_vi_sigma(self):
+        """variational_inference.py:712-733: vi_sigma & co. are functions of error_scaling here
+        (properties); make the device follow a tau assigned from outside."""
+        self.engine.set_tau(self.error_scaling)
+        self._version += 1
+
+    def _nat_grad_step(self, params, L, line_search_rate, running_elbo_delta=None):
+        """variational_inference.py:419-450: (params, L, change of the ELBO)."""
+        L = np.ascontiguousarray(list(L) + [1.] * (5 - len(L)), dtype=np.float64)
+        new_params, L, elbo, _ = self._optimize_step(params, L, 0.0, line_search_rate,
+                                                     running_elbo_delta)
+        return (new_params[0], new_params[1], new_params[2]), L, elbo
+
