@@ -185,6 +185,47 @@ def test_c4_eigen_form_operator_and_fit():
     eng.close()
 
 
+def test_c4f_factor_model_recipe_at_full_size():
+    """SURVEY.md 8(d)'s own recipe for configs[3] at FULL size: per block and cohort
+    R = D^-1/2 (F F^T / m + 0.05 I) D^-1/2, m = ceil(n / 4), eigendecomposed and cut by the loader's
+    --ldthresh 0.8 rule -- ranks are data-derived (about n / 4), per cohort.  `auto` storage: the
+    operator against U (s * (U^T x)) on a sample of blocks, symmetry, linearity, zero rows at the
+    LD-missing SNPs, and the fit invariants over three sweeps."""
+    import torch
+    sh, eng, drv = _setup('C4f', form='auto')
+    assert sh.kind == 'lowrank' and sh.spectrum == 'factor'
+    assert sh.N_global > 1_000_000 and len(sh.sizes_all) == 1700
+    frac = sum(float(r.sum()) for r in sh.ranks_by_cohort) / (sh.P * float(sh.sizes.sum()))
+    assert 0.2 < frac < 0.35                                            # kept rank ~ n / 4
+    rng = np.random.default_rng(10)
+    x, y = rng.normal(size=(sh.P, sh.N)), rng.normal(size=(sh.P, sh.N))
+    rx, ry = eng.ld_matvec(x), eng.ld_matvec(y)
+    order = np.argsort(sh.sizes)
+    sample = sorted(set(range(0, len(sh.blocks), 50)) | set(order[:3].tolist()) | set(order[-3:].tolist()))
+    for p in range(sh.P):
+        for i in sample:
+            U, sv = sh._eig[p][i]
+            lo = sh.snp_start[i]
+            xb = torch.as_tensor(x[p, lo:lo + U.shape[0]], device=U.device)
+            want = (U @ (sv * (U.T @ xb))).cpu().numpy()
+            np.testing.assert_allclose(rx[p, lo:lo + U.shape[0]], want, rtol=1e-10, atol=1e-10)
+    assert np.all(rx[:, sh.missing] == 0.0)
+    rz = eng.ld_matvec(2.5 * x - 0.75 * y)
+    np.testing.assert_allclose(rz, 2.5 * rx - 0.75 * ry, rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose((x * ry).sum(axis=1), (y * rx).sum(axis=1), rtol=1e-10)
+    drv.initialize_from(sh.fake_mu)
+    state, elbo_prev = None, drv._objective
+    assert np.isfinite(elbo_prev)
+    for it in range(3):
+        state, stats = drv.sweep(state, lookahead=it < 2)
+        assert state['elbo'] >= elbo_prev - 25 * (1e-6 * abs(elbo_prev) + 1e-6)
+        assert np.all(state['L'] >= 1.0) and np.all(np.isfinite(stats))
+        elbo_prev = state['elbo']
+    obj = _fresh_objective(drv)
+    assert abs(obj - drv._objective) <= 1e-12 * abs(obj)
+    eng.close()
+
+
 def test_c5_operator_and_fit_invariants():
     """BASELINE.json configs[4] on ONE GPU: P=4 (Cholesky branch of the per-SNP pass), 34 000
     block-cohorts, ~100 GB resident.  Same size-independent properties as C3."""
