@@ -104,6 +104,20 @@ def test_many_components_three_cohorts():
     _compare(_problem(rng, 3, [[30, 40], [70], [20, 20, 30]], N=80, M=9), sweeps=3)
 
 
+def test_five_to_eight_cohorts():
+    """More than four cohorts: the reference takes any P through numpy's inv / slogdet
+    (numerics.py:238-290, variational_inference.py:599-630); the per-SNP kernels are instantiated
+    up to P = 8 (unrolled Cholesky).  P = 5 with different block partitions per cohort, annotations
+    and --learn-scaling; P = 8 at the width limit; sweep by sweep against the oracle."""
+    rng = np.random.default_rng(55)
+    sizes5 = [[40, 30, 25], [60, 35], [95], [20, 20, 20, 20], [50, 45]]
+    _compare(_problem(rng, 5, sizes5, N=110, M=7), sweeps=3)
+    _compare(_problem(rng, 5, sizes5, N=110, M=6, A=2, ldthresh=0.8), sweeps=3, scale_se=True)
+    sizes8 = [[30, 30], [60], [25, 35], [45], [20, 20, 20], [61], [33, 27], [50]]
+    _compare(_problem(rng, 8, sizes8, N=70, M=5), sweeps=3)
+    _compare(_problem(rng, 6, sizes8[:6], N=70, M=130), sweeps=2)      # many components, no stash
+
+
 def test_big_blocks_and_thresholding():
     rng = np.random.default_rng(5)
     _compare(_problem(rng, 1, [[700, 130, 129]], N=1000, M=5), sweeps=3)

@@ -145,7 +145,7 @@ def test_fast_inner_product_comp_rejects_per_snp_precisions():
                                    rng.random((100, 3)))
 
 
-@pytest.mark.parametrize('P', [1, 2, 3, 4])
+@pytest.mark.parametrize('P', [1, 2, 3, 4, 5, 8])
 def test_matrix_invert_and_log_det_against_lapack(P):
     # the recipes of tests/test.py:1107-1203: every leading shape the reference test uses
     rng = np.random.default_rng(P)

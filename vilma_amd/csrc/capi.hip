@@ -467,7 +467,7 @@ const char *vilma_last_error(const vilma_ctx *ctx) {
 int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     if (!out) return fail(nullptr, "out is NULL");
     *out = nullptr;
-    if (P < 1 || P > 4) return fail(nullptr, "P must be in 1..4 (cohorts)");
+    if (P < 1 || P > VILMA_MAX_P) return fail(nullptr, "P must be in 1..8 (cohorts)");
     if (N < 1 || N >= ((int64_t)1 << 30)) return fail(nullptr, "N out of range");
     if (M < 2) return fail(nullptr, "M must be >= 2 (mixture components)");
     if (A < 1) return fail(nullptr, "A must be >= 1 (annotations)");

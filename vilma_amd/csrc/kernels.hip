@@ -1173,7 +1173,7 @@ size_t snp_pass_lds_bytes(int M, int P, int ns, bool stash) {
 // is not enough to hide the pass's latencies: profiles/r02s_ab_snp_pass_occupancy.txt); beyond
 // that the sums come from delta_kernel as before.
 bool snp_pass_can_stash(int M, int P, int ns) {
-    return SNP_SPLIT == 4 && snp_pass_lds_bytes(M, P, ns, true) <= (size_t)78 * 1024;
+    return SNP_SPLIT == 4 && P <= 4 && snp_pass_lds_bytes(M, P, ns, true) <= (size_t)78 * 1024;
 }
 
 // sum over the 64 lanes of 8 values at once (halving butterfly, DPP / permlane moves only): the
@@ -1187,7 +1187,7 @@ static __device__ __forceinline__ double tile_sum8(const double (&p)[8], int lan
 // profiles/r03c_ab_snp_pass.txt); with the Cholesky of three or four cohorts that budget spills
 // dozens, so those keep two.
 #ifndef SNP_MIN_WAVES
-#define SNP_MIN_WAVES(P) ((P) <= 2 ? 3 : 2)
+#define SNP_MIN_WAVES(P) ((P) <= 2 ? 3 : (P) <= 4 ? 2 : 1)
 #endif
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
 // store of the wave to be acknowledged (vmcnt(0)): with the pass's vi_mu stores in flight that is
@@ -1580,18 +1580,20 @@ template <int P, bool BLEND, bool ONE_ANNOT, int NS>
 static void launch_snp_pass_s(const SnpKernelArgs &a, bool stash, hipStream_t s) {
     const dim3 grid(SNP_SPLIT == 4 ? snp_tile_grid(a.N) : snp_pass_grid(a.N)), block(SNP_THREADS);
     const size_t lds = snp_pass_lds_bytes(a.M, P, NS, stash);
-    if (stash) {
-        auto kern = snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true>;
-        static bool raised = false;             // more than 64 KB of dynamic LDS needs the attribute
-        if (!raised) {
-            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      96 * 1024);
-            raised = true;
+    if constexpr (P <= 4) {
+        if (stash) {
+            auto kern = snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true>;
+            static bool raised = false;         // more than 64 KB of dynamic LDS needs the attribute
+            if (!raised) {
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          96 * 1024);
+                raised = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+            return;
         }
-        hipLaunchKernelGGL(kern, grid, block, lds, s, a);
-    } else {
-        hipLaunchKernelGGL((snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, false>), grid, block, lds, s, a);
     }
+    hipLaunchKernelGGL((snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, false>), grid, block, lds, s, a);
 }
 
 template <int P>
@@ -1609,6 +1611,18 @@ static void launch_snp_pass_p(const SnpKernelArgs &a, bool blend, int ns, bool s
     }
 }
 
+template <int P>
+static void launch_snp_pass_big(const SnpKernelArgs &a, bool blend, hipStream_t s) {
+    const bool one = a.A == 1;
+    if (blend) {
+        if (one) launch_snp_pass_s<P, true, true, 1>(a, false, s);
+        else launch_snp_pass_s<P, true, false, 1>(a, false, s);
+    } else {
+        if (one) launch_snp_pass_s<P, false, true, 1>(a, false, s);
+        else launch_snp_pass_s<P, false, false, 1>(a, false, s);
+    }
+}
+
 // ns = 1: one candidate (or a plain evaluation); ns = 2: a beta trial at a.step and a.step2.
 // With a.sum_partials != nullptr (and snp_pass_can_stash) the per-tile responsibility sums of every
 // candidate are written there: [candidate][tile][A*M].
@@ -1622,6 +1636,13 @@ void launch_snp_pass(const SnpKernelArgs &args, bool blend, int ns, hipStream_t 
         case 2: launch_snp_pass_p<2>(a, blend, ns, stash, s); break;
         case 3: launch_snp_pass_p<3>(a, blend, ns, stash, s); break;
         case 4: launch_snp_pass_p<4>(a, blend, ns, stash, s); break;
+        // five to eight cohorts: the same kernel with the P x P Cholesky unrolled (it spills; the
+        // reference's own general branch, numerics.py:238-290, is numpy's inv / slogdet per matrix);
+        // one candidate per trial, sums from delta_kernel
+        case 5: launch_snp_pass_big<5>(a, blend, s); break;
+        case 6: launch_snp_pass_big<6>(a, blend, s); break;
+        case 7: launch_snp_pass_big<7>(a, blend, s); break;
+        case 8: launch_snp_pass_big<8>(a, blend, s); break;
         default: break;   // rejected in vilma_create
     }
 }
@@ -1826,6 +1847,10 @@ static void launch_delta_any(const DeltaArgs &args, hipStream_t s) {
         case 2: launch_delta_p<2, WRITE>(a, s); break;
         case 3: launch_delta_p<3, WRITE>(a, s); break;
         case 4: launch_delta_p<4, WRITE>(a, s); break;
+        case 5: launch_delta_p<5, WRITE>(a, s); break;
+        case 6: launch_delta_p<6, WRITE>(a, s); break;
+        case 7: launch_delta_p<7, WRITE>(a, s); break;
+        case 8: launch_delta_p<8, WRITE>(a, s); break;
         default: break;
     }
 }
@@ -1989,6 +2014,10 @@ void launch_init_state(const InitArgs &a, double *sums_out, hipStream_t s) {
         case 2: launch_init_p<2>(a, s); break;
         case 3: launch_init_p<3>(a, s); break;
         case 4: launch_init_p<4>(a, s); break;
+        case 5: launch_init_p<5>(a, s); break;
+        case 6: launch_init_p<6>(a, s); break;
+        case 7: launch_init_p<7>(a, s); break;
+        case 8: launch_init_p<8>(a, s); break;
         default: break;
     }
     const int ncols = a.A * a.M;
@@ -2132,6 +2161,10 @@ void launch_snp_given_delta(const SnpKernelArgs &a, const double *delta_km, cons
         case 2: launch_given_p<2>(a, delta_km, lse_cur, maxdev_partials, s); break;
         case 3: launch_given_p<3>(a, delta_km, lse_cur, maxdev_partials, s); break;
         case 4: launch_given_p<4>(a, delta_km, lse_cur, maxdev_partials, s); break;
+        case 5: launch_given_p<5>(a, delta_km, lse_cur, maxdev_partials, s); break;
+        case 6: launch_given_p<6>(a, delta_km, lse_cur, maxdev_partials, s); break;
+        case 7: launch_given_p<7>(a, delta_km, lse_cur, maxdev_partials, s); break;
+        case 8: launch_given_p<8>(a, delta_km, lse_cur, maxdev_partials, s); break;
         default: break;
     }
     hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, s, maxdev_partials,

@@ -568,7 +568,11 @@ int launch_inverse(int P, const double *m, const MatLayout &l, double *out) {
         case 2: hipLaunchKernelGGL((mat_inverse_kernel<2, CLOSED>), grid, block, 0, 0, m, l, out); break;
         case 3: hipLaunchKernelGGL((mat_inverse_kernel<3, false>), grid, block, 0, 0, m, l, out); break;
         case 4: hipLaunchKernelGGL((mat_inverse_kernel<4, false>), grid, block, 0, 0, m, l, out); break;
-        default: return fail("matrix inverse: P must be 1..4");
+        case 5: hipLaunchKernelGGL((mat_inverse_kernel<5, false>), grid, block, 0, 0, m, l, out); break;
+        case 6: hipLaunchKernelGGL((mat_inverse_kernel<6, false>), grid, block, 0, 0, m, l, out); break;
+        case 7: hipLaunchKernelGGL((mat_inverse_kernel<7, false>), grid, block, 0, 0, m, l, out); break;
+        case 8: hipLaunchKernelGGL((mat_inverse_kernel<8, false>), grid, block, 0, 0, m, l, out); break;
+        default: return fail("matrix inverse: P must be 1..8");
     }
     return 0;
 }
@@ -580,7 +584,11 @@ int launch_log_det(int P, const double *m, const MatLayout &l, double *out) {
         case 2: hipLaunchKernelGGL((mat_log_det_kernel<2, CLOSED>), grid, block, 0, 0, m, l, out); break;
         case 3: hipLaunchKernelGGL((mat_log_det_kernel<3, false>), grid, block, 0, 0, m, l, out); break;
         case 4: hipLaunchKernelGGL((mat_log_det_kernel<4, false>), grid, block, 0, 0, m, l, out); break;
-        default: return fail("matrix log-determinant: P must be 1..4");
+        case 5: hipLaunchKernelGGL((mat_log_det_kernel<5, false>), grid, block, 0, 0, m, l, out); break;
+        case 6: hipLaunchKernelGGL((mat_log_det_kernel<6, false>), grid, block, 0, 0, m, l, out); break;
+        case 7: hipLaunchKernelGGL((mat_log_det_kernel<7, false>), grid, block, 0, 0, m, l, out); break;
+        case 8: hipLaunchKernelGGL((mat_log_det_kernel<8, false>), grid, block, 0, 0, m, l, out); break;
+        default: return fail("matrix log-determinant: P must be 1..8");
     }
     return 0;
 }

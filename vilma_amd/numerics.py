@@ -237,9 +237,9 @@ def fast_invert_nat_vi_delta(new_mu, nat_mu, const_part, nat_vi_delta):
 
 
 def _check_p(P, what):
-    if P > 4:
-        raise NotImplementedError('%s: matrices larger than 4 x 4 are not supported by the HIP '
-                                  'kernels (the fit is limited to 4 cohorts)' % what)
+    if P > 8:
+        raise NotImplementedError('%s: matrices larger than 8 x 8 are not supported by the HIP '
+                                  'kernels (the fit is limited to 8 cohorts)' % what)
 
 
 def _stack_of_matrices(matrix, what):
