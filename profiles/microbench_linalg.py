@@ -42,7 +42,13 @@ def main():
             out['cholesky_ms'] = 1e3 * timed(lambda: torch.linalg.cholesky_ex(A)) / B
             L = torch.linalg.cholesky_ex(A)[0]
             out['trsm_inv_ms'] = 1e3 * timed(lambda: torch.linalg.solve_triangular(L, eye, upper=False)) / B
-            out['chol_solve_1rhs_ms'] = 1e3 * timed(lambda: torch.cholesky_solve(eye[:, :, :1], L)) / B
+            # torch.cholesky_solve with a batch faults on this stack for matrices beyond 512 rows
+            # (hipErrorLaunchFailure at n = 588, batch 8 -- with a strided AND with a contiguous
+            # right-hand side; batch 1 and n = 200 pass: profiles/r03k_diag_cholesky_solve.txt).
+            # Nothing in the product calls it; here it is timed only where it is known to work.
+            if B == 1 or n <= 512:
+                rhs = eye[:, :, :1].contiguous()
+                out['chol_solve_1rhs_ms'] = 1e3 * timed(lambda: torch.cholesky_solve(rhs, L)) / B
             out['eigh_ms'] = 1e3 * timed(lambda: torch.linalg.eigh(A), reps=2) / B
             w, Q = torch.linalg.eigh(A)
             out['recon_gemm_ms'] = 1e3 * timed(lambda: (Q * w[:, None, :]) @ Q.transpose(1, 2)) / B
