@@ -78,6 +78,15 @@ def test_device_loader_matches_host_formulas(form, gpu_eigh, monkeypatch):
             want = old.ridge_inverse_dot(rmle, reg)
             got = ld_device.ridge_start(eng, rmle[None], reg[None], diag[None])[0]
             np.testing.assert_allclose(got, want, rtol=1e-8, atol=tol * np.abs(want).max())
+        # an iteration budget too small for 1e-13: the iterate is accepted (with a warning) once its
+        # TRUE residual is below 1e-6 -- it only seeds a starting point -- and raises RidgeStalled,
+        # which MultiPopVI answers with the reference's per-block solve, when not even that is reached
+        reg = 30.0 * rng.uniform(0.5, 2.0, size=N)
+        want = old.ridge_inverse_dot(rmle, reg)
+        got = ld_device.ridge_start(eng, rmle[None], reg[None], diag[None], max_iter=8)[0]
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * np.abs(want).max())
+        with pytest.raises(ld_device.RidgeStalled):
+            ld_device.ridge_start(eng, rmle[None], 1e-7 * reg[None], diag[None], max_iter=8)
         eng.close()
 
 

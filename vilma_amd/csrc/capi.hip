@@ -712,6 +712,10 @@ int vilma_ld_add_dense(vilma_ctx *c, int cohort, int n, const double *R) {
                               (size_t)(n - j0), hipMemcpyDefault));
         dst += sym_panel_elems(n, J);
     }
+    // the copies above run on the NULL stream and a device-to-device hipMemcpy may return before it
+    // has finished: the caller is free to release (or a caching allocator to reuse) R the moment
+    // this returns, so wait here
+    HIPCHK(c, hipStreamSynchronize(nullptr));
     BlockRec b{0, n, n, co.store_used, 0, co.next_start, 0};
     co.blocks.push_back(b);
     co.store_used += need;
@@ -753,6 +757,7 @@ int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U
                               (size_t)r * sizeof(double), (size_t)n, hipMemcpyDefault));
     }
     HIPCHK(c, hipMemcpy(dS, s, (size_t)r * sizeof(double), hipMemcpyDefault));
+    HIPCHK(c, hipStreamSynchronize(nullptr));      // as in vilma_ld_add_dense: U and s may be released now
     BlockRec b{1, n, r, co.store_used, co.store_used + (int64_t)pad2(n) * pad_ld(r), co.next_start,
                (int32_t)co.t_used, W};
     co.blocks.push_back(b);

@@ -398,11 +398,22 @@ def stream_cohort(engine, cohort, ld, form, z_ld, workers=None, window=None):
             'gpu_eigh_s': t_gpu}
 
 
+class RidgeStalled(RuntimeError):
+    """Conjugate gradients did not get the ridge start below the residual the caller can use."""
+
+
+RIDGE_ACCEPT = 1e-6     # true relative residual good enough for a starting point that is then
+                        # jittered by 1e-3 se (variational_inference.py:643-657)
+
+
 def ridge_start(engine, b, reg, diag, rtol=1e-13, max_iter=20000):
     """x = (R_p + diag(reg_p))^-1 b_p for every cohort p at once (b, reg, diag: [P, N] in SNP
     order; reg > 0) by Jacobi-preconditioned conjugate gradients on the resident LD store --
     the per-block ridge solve of reference matrix_structures.py:349-387, without factorising
-    anything.  Raises if the residual does not reach `rtol`."""
+    anything.  The result only seeds _initialize, so an iterate whose TRUE residual is below
+    RIDGE_ACCEPT is accepted with a warning when the recurrence stalls above `rtol` (a small
+    regulariser on strongly correlated blocks makes 1e-13 tight in fp64); beyond that it raises
+    RidgeStalled and the caller falls back to the reference's per-block solve on the host."""
     torch = engine.torch
     dev = engine.device
     f64 = dict(dtype=torch.float64, device=dev)
@@ -439,13 +450,16 @@ def ridge_start(engine, b, reg, diag, rtol=1e-13, max_iter=20000):
         worst = float((torch.linalg.vector_norm(r, dim=1) / safe).max().item())
         if worst <= rtol:
             break
-    else:
-        raise RuntimeError('ridge start: conjugate gradients stalled at relative residual '
-                           '%.3e after %d iterations' % (worst, it))
+    stalled = not worst <= rtol
     # the recurrence residual can drift from the true one: verify against the operator itself
     engine.ld_matvec_device(x, Ap)
     Ap += reg * x
     true_res = float((torch.linalg.vector_norm(b - Ap, dim=1) / safe).max().item())
-    if not true_res <= 1e-9:
-        raise RuntimeError('ridge start: residual %.3e after %d iterations' % (true_res, it))
+    if stalled or not true_res <= 1e-9:
+        if not true_res <= RIDGE_ACCEPT:
+            raise RidgeStalled('ridge start: relative residual %.3e (recurrence %.3e) after %d '
+                               'iterations of conjugate gradients' % (true_res, worst, it))
+        logging.warning('ridge start: conjugate gradients stopped at relative residual %.3e after '
+                        '%d iterations (wanted %.0e); accepted -- it only seeds the jittered '
+                        'starting point', true_res, it, rtol)
     return x.cpu().numpy()

@@ -623,7 +623,15 @@ class MultiPopVI(SweepDriver):
             chi_loc[p], rank_loc[p] = out['chi'], out['rank']
         adj_loc = rmle / se                                   # (R R^+ z) / se  (:243)
         reg = se ** 2 / prior[:, None]
-        ridge = ld_device.ridge_start(self.engine, rmle, reg, diag_loc)   # rhs = adj * se
+        try:
+            ridge = ld_device.ridge_start(self.engine, rmle, reg, diag_loc)   # rhs = adj * se
+        except ld_device.RidgeStalled as exc:
+            # the reference's own per-block solve (matrix_structures.py:349-387) always returns a
+            # starting point: fall back to it on the host (re-decomposing blocks that were dropped)
+            logging.warning('%s; falling back to the per-block ridge solve on the host', exc)
+            ridge = np.zeros((P, n_loc))
+            for p, (sub, perm, n_ld) in enumerate(local_lds):
+                ridge[p] = sub.ridge_inverse_dot(rmle[p], reg[p])
         return diag_loc, adj_loc, ridge * se, chi_loc, rank_loc
 
     def _load_on_host(self, local_lds, z_loc, prior, form):
