@@ -46,8 +46,9 @@ def parse():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--ld-form', default='auto', choices=['auto', 'dense', 'eig'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frac', type=float, default=0.5,
-                    help='fraction of the workload\'s LD blocks in the CPU-baseline sample')
+    ap.add_argument('--cpu-frac', type=float, default=None,
+                    help='fraction of the workload\'s LD blocks in the CPU-baseline sample '
+                         '(default: 0.5; 0.04 for C5, whose sweep is ~25x C3\'s on the CPU)')
     ap.add_argument('--cpu-sweeps', type=int, default=5)
     ap.add_argument('--prof-every', type=int, default=0,
                     help='bracket every k-th LD product with HIP events (roofline.avg_launch_ms); '
@@ -441,8 +442,8 @@ def main():
             'algorithmic_bytes_per_launch': r['ld_algorithmic_bytes']}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, args.cpu_frac,
-                                               args.cpu_sweeps)
+            frac = args.cpu_frac if args.cpu_frac is not None else (0.04 if args.workload == 'C5' else 0.5)
+            out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, frac, args.cpu_sweeps)
         except Exception as exc:      # the GPU number stands on its own
             out['cpu_baseline'] = {'value': None, 'unit': 'sweeps/s', 'cores': 0,
                                    'kind': 'port', 'sample': 'failed: %r' % (exc,)}

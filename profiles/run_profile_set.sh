@@ -25,7 +25,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     d=/tmp/rp_$(echo $ctr | tr A-Z a-z | cut -d_ -f1)
     # counters only for the library's kernels: the synthetic setup issues ~100 k torch dispatches
     # that a counter pass would serialise one by one
-    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "ld_sym|ld_eig|ld_colsum|ld_rowsum|snp_pass|delta_kernel" --output-format csv -d $d -- \
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "ld_sym|ld_eig|ld_colsum|ld_rowsum|snp_pass|delta_kernel|finalize|sweep_decide|tile_sums" --output-format csv -d $d -- \
         python3 "$ROOT/bench.py" --workload $WL --ld-form $FORM --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
     python3 "$ROOT/profiles/summarize_rocprof.py" $d "$OUT/${PFX}_$(echo $ctr | tr A-Z a-z | cut -d_ -f1)" || exit 1
     rm -rf $d

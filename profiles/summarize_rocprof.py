@@ -14,9 +14,10 @@ import sys
 
 import pandas as pd
 
-OURS = ("ld_sym_combine_kernel", "ld_sym_kernel", "ld_eig_fused_kernel", "ld_rowsum_combine_kernel",
+OURS = ("ld_sym_combine_kernel", "ld_sym_kernel", "ld_eig_fused_kernel", "ld_eig_wave_kernel",
+        "ld_rowsum_combine_kernel", "sweep_decide_kernel", "tile_sums_kernel",
         "ld_rowsum_kernel", "ld_colsum_kernel", 'snp_pass_kernel', 'delta_kernel', 'reduce_cols_kernel',
-        'finalize_kernel', 'mean_diff', 'gather_x_kernel', 'scatter_y_kernel', 'decide_kernel', 'mstep_kernel',
+        'finalize_kernel', 'mean_diff', 'gather_x_kernel', 'scatter_y_kernel', 'mstep_kernel',
         'init_state_kernel', 'snp_given_delta_kernel')
 
 
