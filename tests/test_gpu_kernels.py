@@ -228,7 +228,7 @@ def test_errors_are_loud():
     from vilma_amd import _lib
     from vilma_amd.engine import HipEngine
     with pytest.raises(_lib.VilmaHipError):
-        HipEngine(5, 10, 3, 1)              # P > 4 unsupported
+        HipEngine(9, 10, 3, 1)              # more than 8 cohorts: unsupported
     eng = HipEngine(1, 10, 3, 1)
     with pytest.raises(_lib.VilmaHipError):
         eng.eval()                          # LD not loaded

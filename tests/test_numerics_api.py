@@ -59,7 +59,7 @@ def test_shape_mismatches_raise_value_error():
         nm.fast_invert_nat_vi_delta(np.zeros((3, 2, 10)), np.zeros((3, 2, 10)),
                                     np.zeros((10, 3)), np.zeros((10, 3)))
     with pytest.raises(NotImplementedError):
-        nm.matrix_invert(np.zeros((2, 5, 5)))
+        nm.matrix_invert(np.zeros((2, 9, 9)))            # beyond 8 x 8: not instantiated
     with pytest.raises(ValueError):
         nm._matrix_invert_4d_numba(np.zeros((2, 2, 3, 3)))
 
