@@ -241,58 +241,6 @@ int vilma_snapshot_mean(vilma_ctx *ctx, void *stream);
  * (pinned staging + stream synchronise): the one blocking point of a decision. */
 int vilma_fetch(vilma_ctx *ctx, void *stream, const double *src_dev, double *dst_host, int64_t n);
 
-/* ---- decisions on the device, work queued ahead of them ----------------------------------- */
-
-/* Is the NEXT sweep a standard one?  Evaluated on the device, at the end of the sweep being
- * closed, from the (all-reduced) sums of the state after its M-step (totals_dev), of the next
- * sweep's first beta trial (ttotals_dev) and of the convergence statistic (dsum_dev), with the
- * host's own arithmetic (SweepDriver._objective_from, _update_beta, _nat_grad_step,
- * _optimize_step: same operations and order, no fused multiply-add), so host and device always
- * agree.  Flag out_slot (0/1) = 1 iff
- *   - the trial is accepted: new >= orig - rel_tol |orig| - abs_tol (variational_inference.py:
- *     777-787), and
- *   - the inner beta loop ends after it: loop_ends_anyway (L == 1 or L > L_MAX, known to the
- *     host) or |new - orig| <= 0.1 running', running' = the running ELBO change updated with the
- *     sweep being closed (:406-409, 432-435): change = delta_beta + (orig - obj_before_mstep);
- *     running' = 0.5 (running_is_none ? change : running) + 0.5 max(change, 0), and
- *   - not (check_convergence and dsum_dev[0] == 0): optimize() stops when no posterior mean moved.
- * chi = chi_stat [P]; half_rank_log_tau[p] = 0.5 ld_ranks[p] log tau_p (computed by the host).
- * With from_state != 0, delta_beta / obj_before_mstep / running are not taken from the
- * arguments but from what the previous vilma_decide left on the device (a stage queued ahead of
- * the host: the host does not know them yet).
- * With results_dev != NULL the kernel also snapshots results_dev[0..n_results) and both flags,
- * in stream order, for vilma_fetch_begin(..., src_dev = NULL, n_results, buffer = out_slot): the
- * device->host copy then runs on a context-owned copy stream while `stream` goes straight on
- * with the next stage (which overwrites the result vector). */
-int vilma_decide(vilma_ctx *ctx, void *stream, const double *totals_dev, const double *ttotals_dev,
-                 const double *dsum_dev, const double *chi, const double *half_rank_log_tau,
-                 double rel_tol, double abs_tol, int check_convergence, int from_state,
-                 int running_is_none, int loop_ends_anyway, double delta_beta,
-                 double obj_before_mstep, double running, int out_slot,
-                 const double *results_dev, int64_t n_results);
-
-/* Every kernel launched on this context by the calling thread while slot >= 0 first reads flag
- * `slot` and exits if it is 0: the host can queue the M-step, re-evaluation and next trial of a
- * sweep BEFORE it knows the line-search decision; mis-speculated work touches nothing.
- * slot = -1 restores unconditional launches.  (vilma_decide under a predicate whose flag is 0
- * writes 0 to its own slot.) */
-int vilma_set_predicate(vilma_ctx *ctx, int slot);
-
-/* Host-side buffer indices (which vi_mu / moment buffers are current) move at queue time
- * (vilma_accept); save them before queuing predicated work and restore them if its flag was 0. */
-int vilma_spec_save(vilma_ctx *ctx);
-int vilma_spec_restore(vilma_ctx *ctx);
-
-/* vilma_fetch in two halves, so the host can queue more work between them: begin copies n
- * doubles (+ both decision flags) into pinned landing buffer 0/1 behind everything queued on
- * `stream` and records an event; end waits for that event only.  src_dev == NULL: copy the
- * snapshot the last vilma_decide(out_slot = buffer) took, on the copy stream. */
-int vilma_fetch_begin(vilma_ctx *ctx, void *stream, const double *src_dev, int64_t n, int buffer);
-int vilma_fetch_end(vilma_ctx *ctx, int buffer, double *dst_host, int64_t n, int *flags2);
-
-/* Synchronous read of a flag slot and of {orig, new} of the last vilma_decide (tests). */
-int vilma_read_decision(vilma_ctx *ctx, int slot, int *flag, double *obj2);
-
 /* ---- the sweep behind ONE call (vilma_sweep / vilma_elbo / vilma_posterior /
  *      vilma_set_state / vilma_get_state, communicator owned by the context) -------------------
  *

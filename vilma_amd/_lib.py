@@ -107,15 +107,6 @@ def load():
         'vilma_mean_diff': (C.c_int, [vp, vp, vp, vp]),
         'vilma_snapshot_mean': (C.c_int, [vp, vp]),
         'vilma_fetch': (C.c_int, [vp, vp, vp, vp, C.c_int64]),
-        'vilma_decide': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int,
-                                   C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
-                                   C.c_int, vp, C.c_int64]),
-        'vilma_set_predicate': (C.c_int, [vp, C.c_int]),
-        'vilma_spec_save': (C.c_int, [vp]),
-        'vilma_spec_restore': (C.c_int, [vp]),
-        'vilma_fetch_begin': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
-        'vilma_fetch_end': (C.c_int, [vp, C.c_int, vp, C.c_int64, vp]),
-        'vilma_read_decision': (C.c_int, [vp, C.c_int, vp, vp]),
         'vilma_results_size': (C.c_int64, [vp]),
         'vilma_results_dev': (vp, [vp]),
         'vilma_set_fit_constants': (C.c_int, [vp, vp, vp, C.c_int]),

@@ -525,20 +525,6 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         const int v = std::atoi(cr);
         if (v >= 128) c->chunk_rows = (v + 31) / 32 * 32;
     }
-    {
-        const int ones[2] = {1, 1};
-        if (dev_alloc(c, &c->flags, 2) || dev_alloc(c, &c->decide_obj, 2) ||
-            dev_alloc(c, &c->decide_state, 3) ||
-            hipMemcpy(c->flags, ones, sizeof(ones), hipMemcpyHostToDevice) != hipSuccess ||
-            hipEventCreateWithFlags(&c->landed[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->landed[1], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_decided[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_decided[1], hipEventDisableTiming) != hipSuccess) {
-            g_create_error = "cannot create the decision flags";
-            vilma_destroy(c);
-            return 1;
-        }
-    }
     // VILMA_OVERLAP=0 keeps everything on the caller's stream (A/B measurements)
     const char *ov = std::getenv("VILMA_OVERLAP");
     c->overlap = !(ov && ov[0] == '0');
@@ -550,11 +536,6 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     // responsibility kernels get their waves ahead of the long LD stream.
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
-        g_create_error = "cannot create the copy stream";
-        vilma_destroy(c);
-        return 1;
-    }
     if (c->overlap &&
         (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
          hipEventCreateWithFlags(&c->ev_snp, hipEventDisableTiming) != hipSuccess ||
@@ -577,14 +558,6 @@ void vilma_destroy(vilma_ctx *c) {
     dev_free(c->repack_tmp);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    for (int b = 0; b < 2; ++b) {
-        if (c->landing[b]) (void)hipHostFree(c->landing[b]);
-        if (c->landed[b]) (void)hipEventDestroy(c->landed[b]);
-        if (c->ev_decided[b]) (void)hipEventDestroy(c->ev_decided[b]);
-        dev_free(c->snap[b]);
-    }
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    dev_free(c->flags); dev_free(c->decide_obj); dev_free(c->decide_state);
     if (c->ev_snp) (void)hipEventDestroy(c->ev_snp);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -1029,134 +1002,6 @@ int vilma_fetch(vilma_ctx *c, void *stream, const double *src_dev, double *dst_h
     HIPCHK(c, hipMemcpyAsync(c->pinned, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     std::memcpy(dst_host, c->pinned, (size_t)n * sizeof(double));
-    return 0;
-}
-
-int vilma_set_predicate(vilma_ctx *c, int slot) {
-    if (!c) return 1;
-    if (slot < -1 || slot > 1) return fail(c, "predicate slot must be -1, 0 or 1");
-    c->pred_slot = slot;
-    set_launch_predicate(slot < 0 ? nullptr : c->flags + slot);
-    return 0;
-}
-
-int vilma_decide(vilma_ctx *c, void *stream, const double *totals_dev, const double *ttotals_dev,
-                 const double *dsum_dev, const double *chi, const double *half_rank_log_tau,
-                 double rel_tol, double abs_tol, int check_convergence, int from_state,
-                 int running_is_none, int loop_ends_anyway, double delta_beta,
-                 double obj_before_mstep, double running, int out_slot,
-                 const double *results_dev, int64_t n_results) {
-    if (!c) return 1;
-    if (out_slot < 0 || out_slot > 1) return fail(c, "flag slot must be 0 or 1");
-    if (out_slot == c->pred_slot) return fail(c, "a stage cannot overwrite the flag it runs under");
-    double *snap = nullptr;
-    if (results_dev != nullptr) {
-        if (n_results <= 0) return fail(c, "nothing to snapshot");
-        if (n_results + 2 > c->snap_elems[out_slot]) {
-            // ordered behind anything that may still read the old buffer
-            HIPCHK(c, hipDeviceSynchronize());
-            dev_free(c->snap[out_slot]);
-            c->snap[out_slot] = nullptr;
-            c->snap_elems[out_slot] = 0;
-            if (dev_alloc(c, &c->snap[out_slot], n_results + 2)) return 1;
-            c->snap_elems[out_slot] = n_results + 2;
-        }
-        snap = c->snap[out_slot];
-        c->snap_n[out_slot] = n_results;
-    }
-    launch_decide(c->P, check_convergence, totals_dev, ttotals_dev, dsum_dev, chi, c->tau,
-                  half_rank_log_tau, rel_tol, abs_tol, from_state, running_is_none,
-                  loop_ends_anyway, delta_beta, obj_before_mstep, running, c->decide_state,
-                  c->flags + out_slot, c->decide_obj, results_dev, (int)n_results, snap, c->flags,
-                  (hipStream_t)stream);
-    HIPCHK(c, hipGetLastError());
-    return 0;
-}
-
-int vilma_read_decision(vilma_ctx *c, int slot, int *flag, double *obj2) {
-    if (!c) return 1;
-    if (slot < 0 || slot > 1) return fail(c, "flag slot must be 0 or 1");
-    HIPCHK(c, hipDeviceSynchronize());
-    if (flag) HIPCHK(c, hipMemcpy(flag, c->flags + slot, sizeof(int), hipMemcpyDeviceToHost));
-    if (obj2) HIPCHK(c, hipMemcpy(obj2, c->decide_obj, 2 * sizeof(double), hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int vilma_fetch_begin(vilma_ctx *c, void *stream, const double *src_dev, int64_t n, int buffer) {
-    if (!c) return 1;
-    if (buffer < 0 || buffer > 1) return fail(c, "landing buffer must be 0 or 1");
-    if (n <= 0) return fail(c, "nothing to fetch");
-    // the two decision flags ride behind the doubles
-    const int64_t need = n + 2;
-    if (need > c->landing_elems[buffer]) {
-        if (c->landing[buffer]) (void)hipHostFree(c->landing[buffer]);
-        c->landing[buffer] = nullptr;
-        c->landing_elems[buffer] = 0;
-        HIPCHK(c, hipHostMalloc((void **)&c->landing[buffer], (size_t)need * sizeof(double),
-                                hipHostMallocDefault));
-        c->landing_elems[buffer] = need;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    if (src_dev == nullptr) {
-        // the snapshot vilma_decide(out_slot = buffer) took in stream order: copy it out on the
-        // copy stream, so `stream` goes straight on with the next stage
-        if (c->snap[buffer] == nullptr || c->snap_n[buffer] != n)
-            return fail(c, "no snapshot of that size was taken for this buffer");
-        HIPCHK(c, hipEventRecord(c->ev_decided[buffer], s));
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_decided[buffer], 0));
-        HIPCHK(c, hipMemcpyAsync(c->landing[buffer], c->snap[buffer], (size_t)need * sizeof(double),
-                                 hipMemcpyDeviceToHost, c->copy_stream));
-        HIPCHK(c, hipEventRecord(c->landed[buffer], c->copy_stream));
-        c->landing_flags_as_doubles[buffer] = true;
-        return 0;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->landing[buffer], src_dev, (size_t)n * sizeof(double),
-                             hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->landing[buffer] + n, c->flags, 2 * sizeof(int),
-                             hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipEventRecord(c->landed[buffer], s));
-    c->landing_flags_as_doubles[buffer] = false;
-    return 0;
-}
-
-int vilma_fetch_end(vilma_ctx *c, int buffer, double *dst_host, int64_t n, int *flags2) {
-    if (!c) return 1;
-    if (buffer < 0 || buffer > 1 || n + 2 > c->landing_elems[buffer])
-        return fail(c, "no copy in flight for this landing buffer");
-    HIPCHK(c, hipEventSynchronize(c->landed[buffer]));
-    std::memcpy(dst_host, c->landing[buffer], (size_t)n * sizeof(double));
-    if (flags2) {
-        if (c->landing_flags_as_doubles[buffer]) {
-            flags2[0] = (int)c->landing[buffer][n];
-            flags2[1] = (int)c->landing[buffer][n + 1];
-        } else {
-            std::memcpy(flags2, c->landing[buffer] + n, 2 * sizeof(int));
-        }
-    }
-    return 0;
-}
-
-int vilma_spec_save(vilma_ctx *c) {
-    if (!c) return 1;
-    c->saved = {{c->mu_cur, c->mu_ta, c->mu_tb}, {c->mom_cur, c->mom_ta, c->mom_tb},
-                c->have_moments, c->snp_marked, c->have_b};
-    c->prof_mark = c->pending.size();
-    return 0;
-}
-
-int vilma_spec_restore(vilma_ctx *c) {
-    if (!c) return 1;
-    c->mu_cur = c->saved.mu[0]; c->mu_ta = c->saved.mu[1]; c->mu_tb = c->saved.mu[2];
-    c->mom_cur = c->saved.mom[0]; c->mom_ta = c->saved.mom[1]; c->mom_tb = c->saved.mom[2];
-    c->have_moments = c->saved.have_moments; c->snp_marked = c->saved.snp_marked;
-    c->have_b = c->saved.have_b;
-    // the launches of a stage that did not run were bracketed like any other: drop them, or the
-    // average LD-product time would include empty kernels
-    while (c->pending.size() > c->prof_mark) {
-        c->event_pool.push_back(c->pending.back().e0);
-        c->event_pool.push_back(c->pending.back().e1);
-        c->pending.pop_back();
-    }
     return 0;
 }
 

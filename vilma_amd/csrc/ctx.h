@@ -176,27 +176,6 @@ struct vilma_ctx {
     hipEvent_t ev_snp = nullptr, ev_side = nullptr;
     bool overlap = true, snp_marked = false;
 
-    // Decisions taken on the device (vilma_decide) and work queued ahead of them: two flag slots
-    // (stage s is predicated on one while it writes the other), two pinned landing buffers for
-    // asynchronous result copies, and a snapshot of the host-side buffer indices to undo a stage
-    // whose flag turned out 0.
-    int *flags = nullptr;           // device [2]
-    double *decide_obj = nullptr;   // device [2]: {orig, new} objective of the last decision
-    double *decide_state = nullptr; // device [3]: what one decision hands to the next (kernels.hip)
-    int pred_slot = -1;             // -1: launches are unconditional
-    double *landing[2] = {nullptr, nullptr};
-    int64_t landing_elems[2] = {0, 0};
-    hipEvent_t landed[2] = {nullptr, nullptr};
-    // snapshots of the result vector taken by the decide kernel (+ the two flags), copied out on
-    // copy_stream so the caller's stream never waits for a device->host copy
-    double *snap[2] = {nullptr, nullptr};
-    int64_t snap_elems[2] = {0, 0}, snap_n[2] = {0, 0};
-    bool landing_flags_as_doubles[2] = {false, false};
-    hipEvent_t ev_decided[2] = {nullptr, nullptr};
-    hipStream_t copy_stream = nullptr;
-    size_t prof_mark = 0;           // pending profiling brackets at the last vilma_spec_save
-    struct Saved { int mu[3], mom[3]; bool have_moments, snp_marked, have_b; } saved{{0, 1, 2}, {0, 1, 2}, false, false, false};
-
     int prof = 0;                   // 0 off, k >= 1: bracket every k-th LD launch
     int64_t prof_tick = 0;
     bool prof_now = false;

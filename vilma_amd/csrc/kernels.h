@@ -175,15 +175,8 @@ struct SnpKernelArgs {
 };
 
 // launch attribute of the calling thread: kernels launched while it is set exit at once when
-// *flag == 0 (work queued ahead of a device-side decision); nullptr = unconditional
+// *flag == 0 (sweeps queued ahead of the decision that may turn them dead); nullptr = unconditional
 void set_launch_predicate(const int *flag);
-void launch_decide(int P, int check_convergence, const double *totals, const double *ttotals,
-                   const double *dsum, const double *chi, const double *tau,
-                   const double *half_rank_log_tau, double rel_tol, double abs_tol,
-                   int from_state, int running_is_none, int loop_ends_anyway, double delta_beta,
-                   double obj_before_mstep, double running, double *state, int *out_flag,
-                   double *out_obj, const double *results, int n_results, double *snap,
-                   const int *flags, hipStream_t s);
 
 // ns = 2: a beta trial at the two step sizes a.step / a.step2, second candidate into the *2 outputs
 void launch_snp_pass(const SnpKernelArgs &a, bool blend, int ns, hipStream_t s);

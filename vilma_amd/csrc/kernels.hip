@@ -2500,119 +2500,6 @@ void launch_mstep(const double *sums, const double *counts, const double *log_de
 }
 
 // --------------------------------------------------------------------------------------------
-// The line-search decision on the device (variational_inference.py:777-787): accept the beta
-// trial iff  new >= orig - 1e-6 |orig| - 1e-6,  both objectives assembled from the (all-reduced)
-// sums exactly as the host does (SweepDriver._objective_from: same operations, same order, no
-// fused multiply-add), so host and device can never disagree.  Optionally the previous sweep's
-// convergence statistic vetoes (optimize() stops when no posterior mean moved: nothing queued
-// behind that point may run).  Work queued behind this kernel is predicated on out_flag.
-// --------------------------------------------------------------------------------------------
-struct DecideArgs {
-    int32_t P, check_convergence, from_state, running_is_none, loop_ends_anyway;
-    const double *totals;        // [3P+2] of the state after the M-step of the sweep being closed
-    const double *ttotals;       // [3P+2] of the next sweep's first beta trial
-    const double *dsum;          // [3]; dsum[0] = number of posterior means that moved
-    double chi[VILMA_MAX_P], tau[VILMA_MAX_P], half_rank_log_tau[VILMA_MAX_P];
-    double rel_tol, abs_tol;
-    double delta_beta;           // host: objective gained by the beta stage of the sweep being closed
-    double obj_before_mstep;     // host: objective the M-step of that sweep started from
-    double running;              // host: running_elbo_delta at the start of that sweep
-    double *state;               // device [3] = {objective after the M-step, objective of the
-                                 //               accepted trial, running_elbo_delta}
-    const int *pred;             // the stage this decision belongs to may itself be mis-speculated
-    const double *results;       // result vector to snapshot for the host (with both flags behind
-    int32_t n_results;           // it), or snap == nullptr
-    double *snap;
-    const int *flags;            // [2]
-    int *out_flag;
-    double *out_obj;             // [2] = {orig, new} (for tests / host cross-check), may be null
-};
-
-static __device__ double objective_from(const DecideArgs &a, const double *t) {
-#pragma clang fp contract(off)
-    const int P = a.P;
-    double lik = 0.0;
-    for (int p = 0; p < P; ++p) {
-        const double inner = ((-0.5 * (t[P + p] + t[2 * P + p]) + t[p]) - 0.5 * a.chi[p]) / a.tau[p];
-        lik = lik + (inner - a.half_rank_log_tau[p]);
-    }
-    return lik - (t[3 * P] + t[3 * P + 1]);
-}
-
-// flag = 1 iff the next sweep is a "standard" one as far as the device can tell: its first beta
-// trial is accepted AND the inner beta loop ends after it (variational_inference.py:432-435:
-// |new - orig| <= 0.1 running_elbo_delta, with the running value updated from the sweep being
-// closed exactly as _optimize_step does, :406-409) AND optimize() does not stop on convergence.
-__global__ __launch_bounds__(256) void decide_kernel(const DecideArgs a) {
-#pragma clang fp contract(off)
-    if (threadIdx.x == 0) {
-        if (a.pred != nullptr && *a.pred == 0) {
-            *a.out_flag = 0;
-        } else {
-            const double orig = objective_from(a, a.totals);
-            const double fresh = objective_from(a, a.ttotals);
-            double delta_beta = a.delta_beta, before = a.obj_before_mstep, running = a.running;
-            int running_is_none = a.running_is_none;
-            if (a.from_state) {
-                delta_beta = a.state[1] - a.state[0];
-                before = a.state[1];
-                running = a.state[2];
-                running_is_none = 0;
-            }
-            const double change = delta_beta + (orig - before);
-            double r = running_is_none ? change : running;
-            r = r * 0.5;
-            r = r + 0.5 * (change > 0.0 ? change : 0.0);
-            const double conv_tol = 0.1 * r;
-            const bool accept = fresh >= (orig - a.rel_tol * fabs(orig)) - a.abs_tol;
-            const bool ends = a.loop_ends_anyway || fabs(fresh - orig) <= conv_tol;
-            int ok = (accept && ends) ? 1 : 0;
-            if (a.check_convergence && a.dsum[0] == 0.0) ok = 0;
-            *a.out_flag = ok;
-            if (ok) { a.state[0] = orig; a.state[1] = fresh; a.state[2] = r; }
-            if (a.out_obj) { a.out_obj[0] = orig; a.out_obj[1] = fresh; }
-        }
-    }
-    // Snapshot of the result vector + both flags for the host, taken HERE, in stream order, so
-    // the device->host copy can run on its own stream while the next stage already overwrites the
-    // result vector.  (A dead stage still reports its flags; the rest of its snapshot is stale.)
-    if (a.snap == nullptr) return;
-    __syncthreads();
-    const bool dead = a.pred != nullptr && *a.pred == 0;
-    if (!dead)
-        for (int t = threadIdx.x; t < a.n_results; t += blockDim.x) a.snap[t] = a.results[t];
-    if (threadIdx.x == 0) {
-        a.snap[a.n_results] = (double)a.flags[0];
-        a.snap[a.n_results + 1] = (double)a.flags[1];
-    }
-}
-
-void launch_decide(int P, int check_convergence, const double *totals, const double *ttotals,
-                   const double *dsum, const double *chi, const double *tau,
-                   const double *half_rank_log_tau, double rel_tol, double abs_tol,
-                   int from_state, int running_is_none, int loop_ends_anyway, double delta_beta,
-                   double obj_before_mstep, double running, double *state, int *out_flag,
-                   double *out_obj, const double *results, int n_results, double *snap,
-                   const int *flags, hipStream_t s) {
-    DecideArgs a;
-    a.P = P; a.check_convergence = check_convergence;
-    a.from_state = from_state; a.running_is_none = running_is_none;
-    a.loop_ends_anyway = loop_ends_anyway;
-    a.totals = totals; a.ttotals = ttotals; a.dsum = dsum;
-    for (int p = 0; p < VILMA_MAX_P; ++p) {
-        a.chi[p] = p < P ? chi[p] : 0.0;
-        a.tau[p] = p < P ? tau[p] : 1.0;
-        a.half_rank_log_tau[p] = p < P ? half_rank_log_tau[p] : 0.0;
-    }
-    a.rel_tol = rel_tol; a.abs_tol = abs_tol;
-    a.delta_beta = delta_beta; a.obj_before_mstep = obj_before_mstep; a.running = running;
-    a.state = state;
-    a.pred = g_pred; a.out_flag = out_flag; a.out_obj = out_obj;
-    a.results = results; a.n_results = n_results; a.snap = snap; a.flags = flags;
-    hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(256), 0, s, a);
-}
-
-// --------------------------------------------------------------------------------------------
 // The decision of a device-resident sweep (sweep.hip).  One workgroup, run behind a queued beta
 // trial (candidates A at L = L_try and B at L_try * rate) and the all-reduce of its sums:
 //   - the line search of _update_beta (variational_inference.py:777-800) on the two candidates:

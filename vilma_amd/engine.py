@@ -307,53 +307,6 @@ class HipEngine:
                                          self._host_ptr, self.layout.size))
         return self._host.copy()
 
-    # ------------------------------------------------------------------ decisions on the device
-    def decide(self, chi, half_rank_log_tau, rel_tol, abs_tol, check_convergence, out_slot,
-               from_state=False, running=None, loop_ends_anyway=True, delta_beta=0.0,
-               obj_before_mstep=0.0, snapshot=False):
-        """Queue vilma_decide on (totals, trial totals, convergence statistic) of the result
-        vector; the outcome lands in flag slot `out_slot`.  The defaults reduce it to the plain
-        accept test of the trial.  snapshot=True: the kernel also copies the result vector and
-        both flags aside, for fetch_begin(out_slot, snapshot=True)."""
-        chi, hrl = _f64(chi), _f64(half_rank_log_tau)
-        self._check(self.lib.vilma_decide(
-            self.ctx, self._stream_handle, self._p['totals'], self._p['ttotals'], self._p['dsum'],
-            _ptr(chi), _ptr(hrl), float(rel_tol), float(abs_tol), 1 if check_convergence else 0,
-            1 if from_state else 0, 1 if running is None else 0, 1 if loop_ends_anyway else 0,
-            float(delta_beta), float(obj_before_mstep), 0.0 if running is None else float(running),
-            int(out_slot), self._p['results'] if snapshot else None,
-            self.layout.size if snapshot else 0))
-
-    def set_predicate(self, slot):
-        """slot 0/1: everything queued from now on runs only if that flag is 1; None: always."""
-        self._check(self.lib.vilma_set_predicate(self.ctx, -1 if slot is None else int(slot)))
-
-    def spec_save(self):
-        self._check(self.lib.vilma_spec_save(self.ctx))
-
-    def spec_restore(self):
-        self._check(self.lib.vilma_spec_restore(self.ctx))
-
-    def fetch_begin(self, buffer, snapshot=False):
-        """Start copying the result vector (+ flags) to the host; snapshot=True copies what
-        decide(..., out_slot=buffer, snapshot=True) set aside, on the library's copy stream."""
-        self._check(self.lib.vilma_fetch_begin(self.ctx, self._stream_handle,
-                                               None if snapshot else self._p['results'],
-                                               self.layout.size, int(buffer)))
-
-    def fetch_end(self, buffer):
-        """(host copy of the result vector, [flag0, flag1]) of a fetch_begin."""
-        flags = (C.c_int * 2)()
-        self._check(self.lib.vilma_fetch_end(self.ctx, int(buffer), self._host_ptr,
-                                             self.layout.size, flags))
-        return self._host.copy(), (flags[0], flags[1])
-
-    def read_decision(self, slot):
-        flag = C.c_int()
-        obj = (C.c_double * 2)()
-        self._check(self.lib.vilma_read_decision(self.ctx, int(slot), C.byref(flag), obj))
-        return flag.value, (obj[0], obj[1])
-
     def delta_sums(self, which=_lib.STATE_CURRENT):
         self._check(self.lib.vilma_delta_sums(self.ctx, self._stream_handle, self._p['sums'],
                                               which))
