@@ -40,7 +40,8 @@ HBM_ACHIEVABLE_GBS = 6300.0   # measured copy ceiling on MI355X (same guide, HBM
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50,
+                    help='timed sweeps (SURVEY.md 8d quotes the metric over a run of 50)')
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='C3')
     ap.add_argument('--seed', type=int, default=0)

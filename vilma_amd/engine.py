@@ -349,15 +349,18 @@ class HipEngine:
         if comm.backend == 'nccl' and not comm.force_callback:
             # every rank must end up with the same kind of collective: agree on the outcome
             err = None
-            try:
-                ident = C.create_string_buffer(128)
-                if comm.rank == 0 and self.lib.vilma_comm_unique_id(ident):
-                    raise _lib.VilmaHipError('ncclGetUniqueId failed (is librccl.so loadable?)')
-                raw = comm.broadcast_bytes(ident.raw)
-                self._check(self.lib.vilma_comm_init_rccl(self.ctx, comm.world, comm.rank,
-                                                          C.create_string_buffer(raw, 128)))
-            except _lib.VilmaHipError as exc:
-                err = str(exc)
+            ident = C.create_string_buffer(128)
+            have_id = comm.rank != 0 or self.lib.vilma_comm_unique_id(ident) == 0
+            # rank 0 always broadcasts (an empty id = "could not make one"), so nobody waits forever
+            raw = comm.broadcast_bytes(ident.raw if have_id else b'')
+            if len(raw) != 128:
+                err = 'ncclGetUniqueId failed on rank 0 (is librccl.so loadable?)'
+            else:
+                try:
+                    self._check(self.lib.vilma_comm_init_rccl(self.ctx, comm.world, comm.rank,
+                                                              C.create_string_buffer(raw, 128)))
+                except _lib.VilmaHipError as exc:
+                    err = str(exc)
             failed = comm.allreduce_np(np.array([0.0 if err is None else 1.0]))[0]
             if failed == 0:
                 self.collective = 'rccl (communicator owned by the context)'
