@@ -18,6 +18,8 @@ def main():
     ap.add_argument('--M', type=int, default=40)
     ap.add_argument('--A', type=int, default=1)
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--step', type=float, default=1e-3,
+                    help='trial step: small keeps the candidate near the reference state (no tile is redone)')
     args = ap.parse_args()
     import torch
     from vilma_amd.engine import HipEngine
@@ -47,8 +49,8 @@ def main():
         eng.synchronize()
         return (time.perf_counter() - t0) / args.iters * 1e3
     t_eval = timed(lambda: eng.eval())
-    t_trial = timed(lambda: eng.trial(0.5))
-    t_trial2 = timed(lambda: eng.trial2(0.5, 0.25))
+    t_trial = timed(lambda: eng.trial(args.step))
+    t_trial2 = timed(lambda: eng.trial2(args.step, 0.5 * args.step))
     have = eng.trial_sums_available()
     t_tile = timed(lambda: eng.trial_sums(both=have == 2)) if have else float('nan')
     t_sums = timed(lambda: eng.delta_sums())

@@ -1241,6 +1241,24 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     const bool live = i < N;
     const int ii = live ? i : N - 1;
 
+    // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
+    // buffered (see below).  A plain evaluation requests its first batch before anything else, so
+    // the per-SNP constants and the divisions that follow do not add a trip to HBM in front of it
+    // (C3: 0.207 -> 0.198 ms).  A trial does not: the same move costs it 0.02 ms
+    // (gpurun_out/ab23.txt of round 3; it is bound by its stores, not by latency).
+    auto fetch_mu = [&](double (&dst)[KB][P], int k0) {
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
+#pragma unroll
+            for (int p = 0; p < P; ++p) dst[kk][p] = MU_LOAD(&q.mu_in[((int64_t)kc * P + p) * N64 + ii]);
+        }
+    };
+    double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
+    constexpr bool FETCH_FIRST = !BLEND;
+    if (FETCH_FIRST) fetch_mu(bufA, kbeg);
+    const double s0 = q.lse_ref != nullptr ? q.lse_ref[ii] : 0.0;
+
     double d[P], se[P], adj[P], sld[P], g[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -1261,6 +1279,15 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         }
     }
     const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
+    auto fetch_lh = [&](double (&lhv)[KB], int k0) {
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) lhv[kk] = ONE_ANNOT ? 0.0 : lh[min(k0 + kk, M - 1)];
+    };
+    auto fetch = [&](double (&dst)[KB][P], double (&lhv)[KB], int k0) {
+        fetch_mu(dst, k0);
+        fetch_lh(lhv, k0);
+    };
+    if (FETCH_FIRST) fetch_lh(lhA, kbeg);
     double step[NS];
     double *mu_out[NS];
     step[0] = q.step;
@@ -1274,27 +1301,14 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     constexpr bool TAB_AHEAD = P <= 2;
 
     double shift[NS], Z[NS], Skl[NS], Sip[NS], amax[NS], Sm[NS][P], S2[NS][P];
-    {
-        const double s0 = q.lse_ref != nullptr ? q.lse_ref[ii] : 0.0;
 #pragma unroll
-        for (int c = 0; c < NS; ++c) shift[c] = s0;
-    }
+    for (int c = 0; c < NS; ++c) shift[c] = s0;
 
-    // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
-    // buffered: the loads of batch b+1 are issued BEFORE batch b is folded in and its new vi_mu
-    // stored.  On gfx9 loads and stores retire through one in-order counter (vmcnt), so a wave that
+    // Double buffering: the loads of batch b+1 are issued BEFORE batch b is folded in and its new
+    // vi_mu stored.  On gfx9 loads and stores retire through one in-order counter (vmcnt), so a wave that
     // stores and then loads waits for its own stores to reach HBM before it sees the loaded data;
     // with the next loads ahead of the stores it only ever waits for loads.  With several
     // annotations the log-weight row differs per lane: those (vector) loads travel with the batch.
-    auto fetch = [&](double (&dst)[KB][P], double (&lhv)[KB], int k0) {
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-            const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
-#pragma unroll
-            for (int p = 0; p < P; ++p) dst[kk][p] = MU_LOAD(&q.mu_in[((int64_t)kc * P + p) * N64 + ii]);
-            lhv[kk] = ONE_ANNOT ? 0.0 : lh[kc];
-        }
-    };
     auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0) {
         double prt[TAB_AHEAD ? KB : 1][P][P], lht[TAB_AHEAD ? KB : 1];
         if (TAB_AHEAD) {
@@ -1347,7 +1361,9 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                         t = 0.0;
 #pragma unroll
                         for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+#ifndef SNP_DIAG_NOSTORE                 // (diagnostic builds of profiles/microbench_snp.py only)
                         if (live) MU_STORE(&mu_out[c][((int64_t)k * P + p) * N64 + i], t);
+#endif
                     }
                     mun[p] = t;
                     quad += t * nat[p];
@@ -1384,8 +1400,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
 #pragma unroll
             for (int p = 0; p < P; ++p) { Sm[c][p] = 0.0; S2[c][p] = 0.0; }
         }
-        double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
-        fetch(bufA, lhA, kbeg);
+        if (!FETCH_FIRST || attempt > 0) fetch(bufA, lhA, kbeg);
         for (int k0 = kbeg; k0 < kend; k0 += 2 * KB) {
             fetch(bufB, lhB, k0 + KB);         // past the end the clamped loads re-read component M-1
             fold(bufA, lhA, k0);
