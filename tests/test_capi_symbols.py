@@ -53,3 +53,19 @@ def test_library_binds_to_the_hip_runtime_torch_ships():
             % root)
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, check=True)
     assert out.stdout.strip().splitlines()[-1] == '1', out.stdout + out.stderr
+
+
+def test_headers_are_c99_and_the_c_host_example_links(tmp_path):
+    """include/*.h are what a cgo / JNI / FFI stub binds: plain C99, no HIP or C++ types; and
+    examples/host_fit.c (a whole fit from C) compiles and links against the library with gcc."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 'h.c'
+    src.write_text('#include "vilma_hip.h"\n#include "vilma_numerics.h"\nint main(void) { return 0; }\n')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror',
+                           '-I' + os.path.join(root, 'include'), '-fsyntax-only', str(src)])
+    lib_dir = os.path.join(root, 'vilma_amd')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-O2',
+                           '-I' + os.path.join(root, 'include'),
+                           os.path.join(root, 'examples', 'host_fit.c'), '-o', str(tmp_path / 'host_fit'),
+                           '-L' + lib_dir, '-l:libvilma_hip.so', '-Wl,-rpath,' + lib_dir, '-lm'])
