@@ -1362,7 +1362,10 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
 #pragma unroll
                         for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
 #ifndef SNP_DIAG_NOSTORE                 // (diagnostic builds of profiles/microbench_snp.py only)
-                        if (live) MU_STORE(&mu_out[c][((int64_t)k * P + p) * N64 + i], t);
+                        // no `if (live)`: a lane past the end works on a copy of SNP N-1 and stores
+                        // the value that SNP's own lane stores, to the same place -- cheaper than
+                        // four exec-mask branches per component (C3 trial pass 0.48 -> 0.44 ms)
+                        MU_STORE(&mu_out[c][((int64_t)k * P + p) * N64 + ii], t);
 #endif
                     }
                     mun[p] = t;
