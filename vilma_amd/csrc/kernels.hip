@@ -715,17 +715,26 @@ static __device__ __forceinline__ void eig_fused_body(
             y[r][2 * i] = y[r][2 * i + 1] = 0.0;
         }
     }
-    const double *colp = it.a + row0;
+    // Loads are UNCONDITIONAL, at addresses clamped into the slab (a row pair past the block's end
+    // re-reads the column's last pair, a column past the slab's end its last column): what they
+    // return there is finite and meets x = 0 (rows) or a zero eigenvalue factor (columns), and y of
+    // a row past the end is never stored.  Guarded loads (`ok ? load : 0`) put every load in a
+    // basic block of its own; the compiler then cannot count what is in flight and waits for
+    // vmcnt(0) -- for the NEXT batch too -- before it touches this one.
+    int roff[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) roff[i] = min(row0 + 512 * i, (int)ldc - 2);
+    // eigenvalue factors: wave-uniform, written at load time only -> scalar loads.  As vector loads
+    // they share vmcnt with the stream, and waiting for one of them is waiting for the next batch.
+    const const_tab scale_tab = as_table(it.scale);
     v2d nxt[C][H];
     auto issue = [&](int c0) {
 #pragma unroll
-        for (int c = 0; c < C; ++c)
+        for (int c = 0; c < C; ++c) {
+            const double *cp = it.a + (int64_t)min(c0 + c, ncols - 1) * ldc;
 #pragma unroll
-            for (int i = 0; i < H; ++i) {
-                const bool ok = c0 + c < ncols && row0 + 512 * i < n;
-                nxt[c][i] = ok ? LD_STREAM_LOAD(colp + (int64_t)(c0 + c) * ldc + 512 * i)
-                               : v2d{0.0, 0.0};
-            }
+            for (int i = 0; i < H; ++i) nxt[c][i] = LD_STREAM_LOAD(cp + roff[i]);
+        }
     };
     issue(0);
     int buf = 0;
@@ -763,7 +772,7 @@ static __device__ __forceinline__ void eig_fused_body(
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double sc = c0 + c < ncols ? it.scale[c0 + c] : 0.0;
+            const double sc = c0 + c < ncols ? scale_tab[c0 + c] : 0.0;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 double t = red[buf][0][c * NR + r];
@@ -822,16 +831,18 @@ static __device__ __forceinline__ void eig_wave_body(const EigItem &it, const Po
             y[r][2 * i] = y[r][2 * i + 1] = 0.0;
         }
     }
-    const double *colp = it.a + row0;
+    int roff[H];                                   // unconditional, clamped loads: see eig_fused_body
+#pragma unroll
+    for (int i = 0; i < H; ++i) roff[i] = min(row0 + 128 * i, (int)ldc - 2);
+    const const_tab scale_tab = as_table(it.scale);     // scalar loads: see eig_fused_body
     v2d nxt[C][H];
     auto issue = [&](int c0) {
 #pragma unroll
-        for (int c = 0; c < C; ++c)
+        for (int c = 0; c < C; ++c) {
+            const double *cp = it.a + (int64_t)min(c0 + c, ncols - 1) * ldc;
 #pragma unroll
-            for (int i = 0; i < H; ++i) {
-                const bool ok = c0 + c < ncols && row0 + 128 * i < n;
-                nxt[c][i] = ok ? LD_STREAM_LOAD(colp + (int64_t)(c0 + c) * ldc + 128 * i) : v2d{0.0, 0.0};
-            }
+            for (int i = 0; i < H; ++i) nxt[c][i] = LD_STREAM_LOAD(cp + roff[i]);
+        }
     };
     issue(0);
     for (int c0 = 0; c0 < ncols; c0 += C) {
@@ -863,7 +874,7 @@ static __device__ __forceinline__ void eig_wave_body(const EigItem &it, const Po
         const int lo = __double2loint(tot), hi = __double2hiint(tot);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double sc = c0 + c < ncols ? it.scale[c0 + c] : 0.0;
+            const double sc = c0 + c < ncols ? scale_tab[c0 + c] : 0.0;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int v = c * NR + r;
