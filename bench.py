@@ -323,6 +323,12 @@ def main():
     elapsed_local = elapsed
     prof = engine.prof_read(reset=True)
     engine.prof_enable(False)
+    # the yardstick for this process: a bare read of the very same LD store (where an allocation
+    # lands in HBM moves a box's streaming rate by several percent from process to process)
+    try:
+        store_ms, store_bytes = engine.stream_store(5)
+    except Exception:
+        store_ms, store_bytes = None, 0
     # the dominant kernel = the LD-streaming kernel with the most accumulated time; ld_sym_kernel
     # launches with one and with two right-hand sides (a two-step beta trial: one pass over the
     # store, two products) are bracketed separately and pooled for the roofline: the algorithmic
@@ -405,6 +411,16 @@ def main():
             'frac_of_achievable': achieved / HBM_ACHIEVABLE_GBS,
             'achievable_GBps': HBM_ACHIEVABLE_GBS,
             'traffic': traffic, 'traffic_source': traffic_source,
+            # a read-only streaming kernel over the same store, same process, after the timed
+            # region (vilma_prof_stream_store): what these bytes stream at with no arithmetic
+            'store_stream': ({'ms': store_ms, 'bytes': store_bytes,
+                              'GBps': store_bytes / (store_ms * 1e-3) / 1e9} if store_ms else None),
+            'kernel_GBps_on_bytes_moved': ((traffic or alg_launch) / (avg_ms * 1e-3) / 1e9
+                                           if launches else None),
+            'bytes_moved_basis': 'PMC traffic' if traffic else 'algorithmic bytes (no PMC figure for this build)',
+            'frac_of_store_stream': (((traffic or alg_launch) / (avg_ms * 1e-3))
+                                     / (store_bytes / (store_ms * 1e-3))
+                                     if launches and store_ms else None),
             'algorithmic_bytes_per_launch': alg_launch,
             'basis': 'symmetric dense block: lower triangle once, 8 n(n+1)/2 B; eigen-form '
                      'block: U once, 8 n r B; summed over this rank\'s blocks and cohorts',

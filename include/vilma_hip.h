@@ -385,6 +385,16 @@ int vilma_sweep_drain(vilma_ctx *ctx);
 int vilma_prof_enable(vilma_ctx *ctx, int enable);
 int vilma_prof_read(vilma_ctx *ctx, double *ms_total, int64_t *launches, int reset);
 
+/* The yardstick for the LD kernels on THIS placement of the store: `passes` bare reads of every
+ * cohort's LD store (a read-only streaming kernel, nothing computed), timed with HIP events on
+ * `stream`; *ms_per_pass = average time of one pass over all stores, *bytes_per_pass = the bytes
+ * it read (the stored bytes, rounded down to 32 KB per cohort).  Where an allocation lands in HBM
+ * moves the streaming rate of a box by several percent from process to process
+ * (profiles/r03r_placement_probe.txt); this is what the same bytes stream at with no arithmetic
+ * at all.  Measurement only: nothing in a fit calls it. */
+int vilma_prof_stream_store(vilma_ctx *ctx, void *stream, int passes, double *ms_per_pass,
+                            int64_t *bytes_per_pass);
+
 #ifdef __cplusplus
 }
 #endif

@@ -333,6 +333,11 @@ def test_ld_matvec_block_sizes(sizes):
     _close((x * ry).sum(axis=1), (y * got).sum(axis=1), rtol=1e-10)
     alg, stored = eng.ld_bytes()
     assert alg == 8 * sum(n * n + n * max(1, n // 3) for n in sizes)
+    # the measurement yardstick (vilma_prof_stream_store): a bare read of the stores, whole
+    # 32 KB steps of each cohort's store, and the product still gives the same answer afterwards
+    ms, nbytes = eng.stream_store(2)
+    assert 0 <= nbytes <= stored and nbytes % 32768 == 0 and ms >= 0 and (ms > 0 or nbytes == 0)
+    assert np.array_equal(eng.ld_matvec(x), got)
     eng.close()
 
 

@@ -456,6 +456,24 @@ void vilma_detail::prof_truncate(vilma_ctx *c, size_t mark) {
     }
 }
 
+// A bare read of the LD store: what this placement of the store in HBM streams at, with nothing
+// else in the way (16 B per lane, non-temporal, 8 loads in flight per thread, 32 KB per workgroup
+// step).  The yardstick vilma_prof_stream_store reports beside the LD kernels' own times.
+typedef double probe_v2d __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void store_stream_kernel(const probe_v2d *__restrict__ p,
+                                                           int64_t n_chunks, double *sink) {
+    double acc = 0.0;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const probe_v2d *q = p + ch * 2048 + threadIdx.x;
+        probe_v2d t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(q + u * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u].x + t[u].y;
+    }
+    if (acc == 1.2345e300) sink[0] = acc;      // never true for LD data: keeps the loads alive
+}
+
 extern "C" {
 
 const char *vilma_version(void) { return "vilma_hip 0.1 (gfx950)"; }
@@ -1021,6 +1039,40 @@ int vilma_prof_read(vilma_ctx *c, double *ms_total, int64_t *launches, int reset
         if (launches) launches[k] = c->prof_launches[k];
         if (reset) { c->prof_ms[k] = 0.0; c->prof_launches[k] = 0; }
     }
+    return 0;
+}
+
+int vilma_prof_stream_store(vilma_ctx *c, void *stream, int passes, double *ms_per_pass,
+                            int64_t *bytes_per_pass) {
+    if (!c) return 1;
+    if (passes < 1) return fail(c, "passes must be positive");
+    if (vilma_sweep_drain(c)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    int64_t bytes = 0;
+    double total = 0.0;
+    for (int it = 0; it <= passes; ++it) {          // the first pass warms up and is not counted
+        bytes = 0;
+        HIPCHK(c, hipEventRecord(e0, st));
+        for (const CohortLd &co : c->ld) {
+            const int64_t chunks = co.store_used / 4096;        // whole 32 KB steps
+            if (!co.store || chunks == 0) continue;
+            hipLaunchKernelGGL(store_stream_kernel, dim3((unsigned)std::min<int64_t>(chunks, 4096)),
+                               dim3(256), 0, st, (const probe_v2d *)co.store, chunks, c->diff_partials);
+            bytes += chunks * 32768;
+        }
+        HIPCHK(c, hipEventRecord(e1, st));
+        HIPCHK(c, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0) total += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ms_per_pass) *ms_per_pass = total / passes;
+    if (bytes_per_pass) *bytes_per_pass = bytes;
     return 0;
 }
 

@@ -506,3 +506,11 @@ class HipEngine:
         n = (C.c_int64 * len(self.PROF_KINDS))()
         self._check(self.lib.vilma_prof_read(self.ctx, ms, n, 1 if reset else 0))
         return {k: (ms[i], n[i]) for i, k in enumerate(self.PROF_KINDS)}
+
+    def stream_store(self, passes=5):
+        """(milliseconds, bytes) of one bare read of the LD store as it sits in HBM: the yardstick
+        for the LD kernels in this process (include/vilma_hip.h: vilma_prof_stream_store)."""
+        ms, nbytes = C.c_double(), C.c_int64()
+        self._check(self.lib.vilma_prof_stream_store(self.ctx, self._stream(), int(passes),
+                                                     C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
