@@ -40,6 +40,12 @@ def test_bench_json_contract_one_gpu():
     assert r['launches'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert 0 < r['frac'] <= 1 and 'traffic_source' in r and 'basis' in r
     assert r['algorithmic_bytes_per_launch'] < r['survey_8d_bytes_per_launch']
+    # the in-run yardstick: a bare read of the same LD store (None when the store is below one
+    # 32 KB step per cohort, as on `tiny`), and the kernel's rate against it when there is one
+    assert 'store_stream' in r and 'frac_of_store_stream' in r and 'bytes_moved_basis' in r
+    if r['store_stream'] is not None:
+        assert r['store_stream']['bytes'] % 32768 == 0 and r['store_stream']['GBps'] > 0
+        assert 0 < r['frac_of_store_stream'] < 2
     c = d['cpu_baseline']
     for key in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert key in c, key
