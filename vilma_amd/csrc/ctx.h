@@ -66,15 +66,22 @@ inline int eig_class(int R) { return R == 2 ? 0 : R == 4 ? 1 : R == 8 ? 2 : 3; }
 inline int eig_class_rows(int k) { return k == 0 ? 2 : k == 1 ? 4 : k == 2 ? 8 : 12; }
 inline int pad2(int n) { return (n + 1) & ~1; }
 // columns of U one workgroup of the fused product takes (a whole number of batches): about
-// g_eig_slab_elems elements (default 48 k = 384 KB) of U per workgroup, at most 128 columns
-// (VILMA_EIG_SLAB_ELEMS, read when a context is created, keeps the sweep reproducible)
-inline int g_eig_slab_elems = 49152;
+// g_eig_slab_elems elements (default 96 k = 768 KB) of U per workgroup, at most EIG_SLAB_MAX_COLS
+// columns (VILMA_EIG_SLAB_ELEMS, read when a context is created, keeps the sweep reproducible).
+// Every slab re-reads the block's x and writes (and the combine re-reads) a partial y of the
+// block's height: 3 / columns of the slab's own bytes.  48 k -> 96 k elements: C4 product
+// 0.66 - 0.69 -> 0.59 - 0.63 ms, an 8-way shard of it 0.088 -> 0.083 ms
+// (gpurun_out/slab_sweep4.txt of round 3; round 2 had settled on 48 k with guarded loads).
+#ifndef EIG_SLAB_MAX_COLS
+#define EIG_SLAB_MAX_COLS 128
+#endif
+inline int g_eig_slab_elems = 98304;
 inline int eig_slab_cols(int n, int R) {
     const int C = eig_batch_cols(R);
     // blocks of up to 512 rows (R = 2) are taken one slab per WAVE: a quarter of the budget each
     const int budget = R == 2 ? g_eig_slab_elems / 2 : g_eig_slab_elems;
     const int want = (budget / n + C - 1) / C * C;
-    return std::max(C, std::min(128, want));
+    return std::max(C, std::min(EIG_SLAB_MAX_COLS, want));
 }
 inline int eig_n_slabs(int n, int r, int R) {
     const int cols = eig_slab_cols(n, R);
