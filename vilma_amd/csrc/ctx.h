@@ -71,7 +71,9 @@ inline int pad2(int n) { return (n + 1) & ~1; }
 // Every slab re-reads the block's x and writes (and the combine re-reads) a partial y of the
 // block's height: 3 / columns of the slab's own bytes.  48 k -> 96 k elements: C4 product
 // 0.66 - 0.69 -> 0.59 - 0.63 ms, an 8-way shard of it 0.088 -> 0.083 ms
-// (gpurun_out/slab_sweep4.txt of round 3; round 2 had settled on 48 k with guarded loads).
+// (profiles/r03u_eigen_slab_size.txt; round 2 had settled on 48 k with guarded loads).  At C4
+// the gain needs the single launch for all block heights, which 96 k brings along (about 6 000
+// work items, below eig_merge_below): with one launch per class 96 k and 48 k measure the same.
 #ifndef EIG_SLAB_MAX_COLS
 #define EIG_SLAB_MAX_COLS 128
 #endif
