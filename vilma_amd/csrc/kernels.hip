@@ -1161,8 +1161,12 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 #define SNP_SPLIT 4                 // waves sharing a tile's components (1: experiment, no stash)
 #endif
 #define SNP_TILE (SNP_THREADS / SNP_SPLIT)
+// components per vi_mu batch (P <= 2; more cohorts always take 2).  2 against 4, final round-3
+// kernels, same box: evaluation pass 0.200 -> 0.182 ms, two-step trial 0.482 -> 0.475 ms
+// (gpurun_out/ab33.txt): the smaller batch leaves registers for the scheduler, and with the
+// branch-free stores nothing needs a deeper batch to hide.
 #ifndef KU
-#define KU 4
+#define KU 2
 #endif
 
 int snp_pass_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
