@@ -350,11 +350,14 @@ class HipEngine:
             # every rank must end up with the same kind of collective: agree on the outcome
             err = None
             ident = C.create_string_buffer(128)
-            have_id = comm.rank != 0 or self.lib.vilma_comm_unique_id(ident) == 0
+            # every rank makes an id (only rank 0's is used): a rank that cannot even load RCCL must
+            # be known BEFORE the others enter ncclCommInitRank, which would wait for it forever
+            have_id = self.lib.vilma_comm_unique_id(ident) == 0
+            cannot = comm.allreduce_np(np.array([0.0 if have_id else 1.0]))[0]
             # rank 0 always broadcasts (an empty id = "could not make one"), so nobody waits forever
-            raw = comm.broadcast_bytes(ident.raw if have_id else b'')
+            raw = comm.broadcast_bytes(ident.raw if (have_id and cannot == 0) else b'')
             if len(raw) != 128:
-                err = 'ncclGetUniqueId failed on rank 0 (is librccl.so loadable?)'
+                err = 'RCCL is not loadable on %d rank(s) (librccl.so?)' % int(cannot)
             else:
                 try:
                     self._check(self.lib.vilma_comm_init_rccl(self.ctx, comm.world, comm.rank,
