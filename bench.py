@@ -58,6 +58,8 @@ def parse():
     ap.add_argument('--emulate-shard', type=int, default=0,
                     help='diagnostic: time rank 0 of a K-way sharding alone on one GPU '
                          '(no collectives; NOT a valid bench line)')
+    ap.add_argument('--emulate-rank', type=int, default=0,
+                    help='with --emulate-shard K: which rank\'s shard to time (default 0)')
     return ap.parse_args()
 
 
@@ -256,7 +258,8 @@ def main():
     cfg = dict(WORKLOADS[args.workload])
     t_setup = time.perf_counter()
     if args.emulate_shard > 1:
-        shard = SyntheticShard(seed=args.seed, rank=0, world=args.emulate_shard, **cfg).build(device)
+        shard = SyntheticShard(seed=args.seed, rank=args.emulate_rank % args.emulate_shard,
+                               world=args.emulate_shard, **cfg).build(device)
     else:
         shard = SyntheticShard(seed=args.seed, rank=rank, world=world, **cfg).build(device)
     P, M = shard.P, shard.M
