@@ -154,3 +154,21 @@ def test_bench_gpus_without_a_launcher_starts_one():
                          cwd=ROOT, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'),
                          capture_output=True, text=True)
     assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)
+
+
+def test_shard_emulation_is_labelled_a_diagnostic_and_takes_any_rank():
+    """`--emulate-shard K --emulate-rank r` times one rank's shard alone (profiles/r03w_all_ranks.txt):
+    never a bench line (the metric says so), and the ranks' shards partition the LD bytes."""
+    got = []
+    for r in (0, 1):
+        out = subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '3',
+                              '--warmup', '1', '--no-cpu-baseline', '--emulate-shard', '2',
+                              '--emulate-rank', str(r)],
+                             cwd=ROOT, capture_output=True, text=True, check=True)
+        d = _last_json(out.stdout)
+        assert d['metric'].startswith('DIAGNOSTIC') and d['n_gpus'] == 1 and d['value'] > 0
+        got.append(d['roofline']['algorithmic_bytes_per_launch'])
+    whole = subprocess.run([sys.executable, 'bench.py', '--workload', 'tiny', '--steps', '3',
+                            '--warmup', '1', '--no-cpu-baseline'],
+                           cwd=ROOT, capture_output=True, text=True, check=True)
+    assert abs(sum(got) - _last_json(whole.stdout)['roofline']['algorithmic_bytes_per_launch']) < 1.0
