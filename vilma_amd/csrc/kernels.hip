@@ -404,9 +404,12 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
                            acc0[r], acc1[r], lane, rs_diag[r]);
     }
     // (2) the rows below it.  One right-hand side: plain loop, 8 x 1 KiB loads in flight per wave,
-    // latency hidden by occupancy (software pipelining measured the same, 1.20 ms @C3).  Two:
-    // the arithmetic per group doubles and fewer waves fit (104 VGPRs), so the next group's
-    // loads are issued before the current group is folded in (double-buffered, unrolled by two).
+    // latency hidden by occupancy.  Two: the loop is unrolled by two with the next group's loads
+    // written ahead of the current group's arithmetic -- but they sit in a wave-uniform `if`, so the
+    // compiler cannot count them and waits for vmcnt(0) before the arithmetic: in effect the plain
+    // loop (SYM_PIPELINE=0 measures the same).  A TRUE double buffer (unconditional, clamped
+    // prefetch: 16 KiB in flight per wave) was measured in round 3 and is 2 % SLOWER, for one and
+    // for two right-hand sides (gpurun_out/ab36.txt): this kernel does not want more in flight.
     if (SYM_PIPELINE && NR == 2) {
         v2d vb[CS_ROWS];
         if (g < nfull) {
