@@ -55,6 +55,11 @@ def main():
     wall = (time.perf_counter() - t0) / args.iters
     prof = eng.prof_read()
     alg, stored = eng.ld_bytes()
+    try:
+        sms, sbytes = eng.stream_store(5)
+        print('bare read of the same store: %.3f ms = %.0f GB/s' % (sms, sbytes / sms / 1e6))
+    except Exception as exc:
+        print('bare read unavailable:', exc)
     print('form=%s  algorithmic %.3f GB  stored %.3f GB  wall/product %.3f ms'
           % (args.form, alg / 1e9, stored / 1e9, wall * 1e3))
     for k, (ms, n) in prof.items():
