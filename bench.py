@@ -49,8 +49,14 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frac', type=float, default=None,
                     help='fraction of the workload\'s LD blocks in the CPU-baseline sample '
-                         '(default: 0.5; 0.04 for C5, whose sweep is ~25x C3\'s on the CPU)')
-    ap.add_argument('--cpu-sweeps', type=int, default=5)
+                         '(default: 0.25; 0.02 for C5, whose sweep is ~25x C3\'s on the CPU)')
+    ap.add_argument('--cpu-sweeps', type=int, default=8,
+                    help='sweeps of the CPU baseline (fewer if --cpu-budget runs out first)')
+    ap.add_argument('--cpu-budget', type=float, default=150.0,
+                    help='seconds the whole CPU-baseline leg may take (sample setup included): '
+                         'the timed loop stops after the sweep during which the budget runs out '
+                         '(at least 2 sweeps) and the in-run GPU-vs-CPU comparison of the sample '
+                         'is skipped when less than a fifth of it is left')
     ap.add_argument('--prof-every', type=int, default=0,
                     help='bracket every k-th LD product with HIP events (roofline.avg_launch_ms); '
                          'default: every product on 1 GPU, every 8th on a sharded run, where the '
@@ -63,7 +69,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(workload, seed, block_frac, n_sweeps):
+def cpu_baseline(workload, seed, block_frac, n_sweeps, budget_s=150.0):
     """The oracle (oracle/vi.py: the reference's operation schedule -- two GEMVs per LD block in
     a serial block loop with threaded BLAS, 5-8 products per sweep, one pass per numerics
     function) on the first `block_frac` of the blocks of the same synthetic problem, on this
@@ -75,6 +81,7 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps):
     from oracle.vi import MultiPopVIOracle
     from oracle import native
     from threadpoolctl import threadpool_limits
+    t_leg = time.perf_counter()
     cfg = dict(WORKLOADS[workload])
     if cfg.get('kind', 'ar1') != 'ar1':
         # the eigen-form synthetic workloads build their factors on the GPU; the baseline is
@@ -139,10 +146,16 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps):
             params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)   # warm-up sweep
             cpu_elbos.append(elbo)
             ld_seconds[0] = 0.0
+            setup_s = time.perf_counter() - t_leg
             t0 = time.perf_counter()
-            for _ in range(n_sweeps):
+            asked, n_sweeps = n_sweeps, 0
+            for _ in range(asked):
                 params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
                 cpu_elbos.append(elbo)
+                n_sweeps += 1
+                # bounded by time, not by count: a slow host must not cost the bench line
+                if n_sweeps >= 2 and time.perf_counter() - t_leg > 0.8 * budget_s:
+                    break
             dt = time.perf_counter() - t0
     finally:
         native.disable()
@@ -150,6 +163,10 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps):
     frac = sh.N / full.N_global
     parity = None
     try:
+        if time.perf_counter() - t_leg > 0.8 * budget_s:
+            raise TimeoutError('skipped: the CPU leg had used %.0f s of its %.0f s budget; the '
+                               'same comparison is asserted by tests/test_gpu_fullsize.py'
+                               % (time.perf_counter() - t_leg, budget_s))
         # "ELBO vs CPU": the same sample through the product class API on the GPU, same seed
         from vilma_amd.matrix_structures import LowRankMatrix, BlockDiagonalMatrix
         from vilma_amd.variational_inference import MultiPopVI
@@ -182,6 +199,8 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps):
     return {
         'value': (n_sweeps / dt) * frac, 'unit': 'sweeps/s', 'cores': int(threads),
         'cores_os_cpu_count': os.cpu_count(), 'cores_how': core_note, 'sweeps_timed': int(n_sweeps),
+        'sweeps_asked': int(asked), 'budget_seconds': budget_s, 'setup_seconds': setup_s,
+        'leg_seconds': time.perf_counter() - t_leg,
         'kind': 'port', 'parity_vs_cpu': parity,
         'ld_product_share_of_cpu_time': t_ld / dt,
         'sample_fraction_of_snps': frac,
@@ -234,12 +253,23 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    # rehearsal knobs (tests only): several ranks on one GPU over gloo
+    # rehearsal knobs (tests only): several ranks on one GPU over gloo; or -- VILMA_BENCH_ENGINE=
+    # "module:Class" -- the whole launch line without any GPU on a CPU test engine with HipEngine's
+    # interface (tests/oracle_engine.py), to rehearse N ranks' protocol and the fields of the JSON
+    # line on the CPU.  Such a line says REHEARSAL in `metric` and measures nothing.
+    engine_spec = os.environ.get('VILMA_BENCH_ENGINE')
+    rehearsal = bool(engine_spec)
     if os.environ.get('VILMA_BENCH_SAME_DEVICE') == '1':
         local_rank = 0
-    backend = os.environ.get('VILMA_BENCH_BACKEND', 'nccl')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    backend = os.environ.get('VILMA_BENCH_BACKEND', 'gloo' if rehearsal else 'nccl')
+    device = None
+    if not rehearsal:
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+
+    def sync():
+        if not rehearsal:
+            torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -267,19 +297,27 @@ def main():
     chi, ranks, inv_se2 = g[:P], g[P:2 * P], g[2 * P:]
     shard.finish_init(inv_se2)
 
-    engine = HipEngine(P, shard.N, M, 1)
+    if rehearsal:
+        import importlib
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        mod, cls = engine_spec.split(':')
+        engine = getattr(importlib.import_module(mod), cls)(P, shard.N, M, 1)
+    else:
+        engine = HipEngine(P, shard.N, M, 1)
     engine.set_snp_data(shard.adj, shard.se, shard.sld, shard.scalings, shard.annot)
     prec = np.linalg.inv(shard.covs)
     log_det = np.linalg.slogdet(shard.covs)[1]
     engine.set_mixture(prec, log_det)
     for p in range(P):
-        if shard.kind == 'lowrank':
+        if rehearsal:
+            engine.load_ld(p, list(shard.ld_blocks_numpy(p)), shard.perm, shard.n_ld)
+        elif shard.kind == 'lowrank':
             engine.load_ld(p, shard.ld_blocks_torch(p, device, args.ld_form), shard.perm,
                            shard.n_ld, specs=shard.block_specs(args.ld_form, p))
         else:
             engine.load_ld(p, shard.ld_blocks_torch(p, device), shard.perm, shard.n_ld,
                            specs=shard.block_specs())
-    torch.cuda.synchronize()
+    sync()
 
     driver = SweepDriver()
     driver._setup_driver(engine, comm, P, M, 1, chi, ranks, [shard.N_global], log_det,
@@ -313,13 +351,13 @@ def main():
     sk0 = driver.n_stages_skipped
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     elbos = []
     for k in range(args.steps):
         state, _ = driver.sweep(state, lookahead=k + 1 < args.steps)
         elbos.append(state['elbo'])
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -379,7 +417,8 @@ def main():
             traffic = None
 
     out = {
-        'metric': ('DIAGNOSTIC shard emulation' if args.emulate_shard > 1 else
+        'metric': ('REHEARSAL on a CPU test engine (%s): not a measurement' % engine_spec if rehearsal else
+                   'DIAGNOSTIC shard emulation' if args.emulate_shard > 1 else
                    'full VI sweeps/sec (1M SNPs, 2 cohorts)' if args.workload == 'C3'
                    else 'full VI sweeps/sec'),
         'value': args.steps / elapsed, 'unit': 'sweeps/s', 'n_gpus': world,
@@ -388,11 +427,12 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': '%s: %d cohorts, %d SNPs (%d in %d %s LD blocks + %d LD-missing), '
-                        'M=%d mixture components, fp64 LD %.2f GB algorithmic (%s), A=1, no '
+                        'M=%d mixture components%s, fp64 LD %.2f GB algorithmic (%s), A=1, no '
                         '--learn-scaling' % (args.workload, P, shard.N_global, shard.n_ld_global,
                                              len(shard.sizes_all),
                                              'AR(1)' if shard.kind == 'ar1' else ('factor-model, --ldthresh 0.8 (kept rank %.3f n)' % (sum(float(r.sum()) for r in shard.ranks_by_cohort) / (P * max(1.0, float(shard.sizes.sum())))) if shard.spectrum == 'factor' else 'eigen-form (rank %.2f n)' % shard.rank_frac),
                                              shard.N_global - shard.n_ld_global, M,
+                                             (' (the grid `vilma fit` builds by default: _make_simple at -K %d)' % cfg['K']) if cfg.get('mixture') == 'make_simple' else '',
                                              (1e-9 * shard.ld_bytes if world == 1 and args.emulate_shard <= 1 else 8e-9 * P * float((shard.sizes_all.astype(np.float64) * shard.ranks_all).sum())),
                                              '8 n^2 as full matrices; the symmetric kernel needs the lower triangle, half of it' if shard.kind == 'ar1' else '8 n r, U counted once'),
             'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
@@ -460,10 +500,11 @@ def main():
             'unit': 'GB/s', 'frac': r['achieved_GBps'] / HBM_PEAK_GBS,
             'avg_launch_ms': r['avg_launch_ms'], 'launches': r['launches'],
             'algorithmic_bytes_per_launch': r['ld_algorithmic_bytes']}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not rehearsal:
         try:
-            frac = args.cpu_frac if args.cpu_frac is not None else (0.04 if args.workload == 'C5' else 0.5)
-            out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, frac, args.cpu_sweeps)
+            frac = args.cpu_frac if args.cpu_frac is not None else (0.02 if args.workload == 'C5' else 0.25)
+            out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, frac, args.cpu_sweeps,
+                                               args.cpu_budget)
         except Exception as exc:      # the GPU number stands on its own
             out['cpu_baseline'] = {'value': None, 'unit': 'sweeps/s', 'cores': 0,
                                    'kind': 'port', 'sample': 'failed: %r' % (exc,)}

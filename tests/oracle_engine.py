@@ -236,6 +236,26 @@ class OracleEngine:
     def close(self):
         pass
 
+    # ---- measurement hooks of HipEngine: nothing to measure here (bench.py's CPU rehearsal of
+    # the multi-rank launch line, VILMA_BENCH_ENGINE, still walks through them)
+    PROF_KINDS = ('ld_sym_kernel', 'ld_eig_fused_kernel', 'ld_sym_kernel_two_rhs',
+                  'snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2')
+
+    def prof_enable(self, on=True, every=1):
+        pass
+
+    def prof_read(self, reset=True):
+        return {k: (0.0, 0) for k in self.PROF_KINDS}
+
+    def stream_store(self, passes=5):
+        raise RuntimeError('no LD store on a device')
+
+    def comm_check(self):
+        """The number of ranks an all-reduce of a one per rank reaches."""
+        if getattr(self, 'comm', None) is None or not self.comm.active:
+            return 1
+        return int(round(float(self.comm.allreduce_np(np.array([1.0]))[0])))
+
     # ---- the sweep behind one call: the engine-level interface of HipEngine (vilma_sweep & co.),
     # with the reference's line search (variational_inference.py:396-450, 762-802, 825-860)
     # restated in Python on the oracle-backed evaluations above.  TEST ONLY: the product's sweep

@@ -69,3 +69,24 @@ def test_headers_are_c99_and_the_c_host_example_links(tmp_path):
                            '-I' + os.path.join(root, 'include'),
                            os.path.join(root, 'examples', 'host_fit.c'), '-o', str(tmp_path / 'host_fit'),
                            '-L' + lib_dir, '-l:libvilma_hip.so', '-Wl,-rpath,' + lib_dir, '-lm'])
+
+
+def test_a_rank_without_rccl_gets_an_error_code_not_a_crash():
+    """vilma_comm_unique_id on a host where librccl cannot be loaded (VILMA_RCCL_LIB points at
+    nothing) returns 1 with a message -- the outcome HipEngine.bind_comm's agreement protocol
+    relies on -- instead of building a std::string from a null dlerror()."""
+    import subprocess
+    import sys
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r); from vilma_amd import _lib; "
+            "lib = _lib.load(); buf = C.create_string_buffer(128); "
+            "print(lib.vilma_comm_unique_id(buf), lib.vilma_last_error(None).decode())" % ROOT)
+    env = dict(os.environ, VILMA_RCCL_LIB='/nonexistent/librccl.so')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+                         check=True)
+    rc, msg = out.stdout.strip().splitlines()[-1].split(' ', 1)
+    assert rc == '1' and 'cannot load librccl.so' in msg and '/nonexistent/librccl.so' in msg
+    # twice in one process: the failure is not cached as a half-initialised binding
+    code2 = code.replace("print(", "lib.vilma_comm_unique_id(buf); print(")
+    out = subprocess.run([sys.executable, '-c', code2], env=env, capture_output=True, text=True,
+                         check=True)
+    assert out.stdout.strip().splitlines()[-1].startswith('1 ')

@@ -326,3 +326,104 @@ def test_shard_plan_is_closed_and_balanced():
                 mats, perm, n_ld = local_ld(ld[p], s['snps'], s['blocks'][p], N)
                 assert sorted(perm.tolist()) == list(range(len(s['snps'])))
                 assert n_ld == sum(m.shape[0] for m in mats)
+
+
+def _agree_main(rank, world, port, bad_rank, mode, q):
+    if rank == bad_rank and mode == 'noload':
+        os.environ['VILMA_RCCL_LIB'] = '/nonexistent/librccl.so'      # before the library loads
+    import ctypes as C
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
+                            world_size=world)
+    try:
+        from vilma_amd import _lib
+        from vilma_amd.sharding import Comm, agree_on_rccl
+        lib = _lib.load()
+        comm = Comm()
+        calls = []
+
+        def make_id():          # the library's own entry point, as HipEngine.bind_comm calls it
+            ident = C.create_string_buffer(128)
+            return ident.raw if lib.vilma_comm_unique_id(ident) == 0 else None
+
+        def init_rccl(raw):     # ncclCommInitRank needs a GPU: stand-in that fails where asked
+            calls.append(len(raw))
+            if mode == 'initfail' and rank == bad_rank:
+                raise RuntimeError('ncclCommInitRank: simulated failure')
+
+        ok, err, failed = agree_on_rccl(comm, make_id, init_rccl)
+        # every rank then runs its sweeps through the callback collective: the sharded fit is the
+        # reference trajectory whatever the agreement said
+        g = golden('traj_p2_scale_se.npz')
+        vi, _ = product_vi_from_traj(g, engine_factory=OracleEngine)
+        assert vi.comm.world == world
+        check_trajectory(vi, g)
+        q.put((rank, 'ok', (ok, err, failed, len(calls))))
+    except BaseException:     # noqa: BLE001 - report to the parent
+        import traceback
+        q.put((rank, 'fail', traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['noload', 'initfail'])
+def test_rccl_setup_failure_on_one_of_four_ranks_switches_every_rank(mode):
+    """One rank of four cannot load librccl (the library's real failure path, VILMA_RCCL_LIB) or
+    fails in ncclCommInitRank: every rank learns it, nobody is left inside ncclCommInitRank, all
+    four fall back to the callback collective together and the fit is unchanged."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + (0 if mode == 'noload' else 1)
+    procs = [ctx.Process(target=_agree_main, args=(r, 4, port, 2, mode, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in results:
+        assert status == 'ok', 'rank %d failed:\n%s' % (rank, info)
+    for rank, _, (ok, err, failed, n_calls) in results:
+        assert ok is False and err
+        if mode == 'noload':
+            # known before anybody calls ncclCommInitRank
+            assert n_calls == 0 and 'not loadable on 1 rank' in err
+        else:
+            assert n_calls == 1 and failed == 1
+            assert ('simulated failure' in err) == (rank == 2)
+
+
+def test_bench_line_of_four_ranks_carries_the_fields_a_scale_record_is_judged_on():
+    """The driver's multi-GPU launch line, rehearsed on the CPU (bench.py's VILMA_BENCH_ENGINE
+    seam: the oracle-backed test engine over gloo, no GPU, `metric` says REHEARSAL): whatever N,
+    the ONE JSON line carries rccl_ranks == N, the collective, per-rank times and shard sizes and
+    the slowest rank's roofline."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for n in (2, 4):
+        env = dict(os.environ, VILMA_BENCH_ENGINE='oracle_engine:OracleEngine')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+               str(n), '--master-addr', '127.0.0.1', '--master-port',
+               str(34100 + os.getpid() % 800 + n), 'bench.py', '--gpus', str(n), '--steps', '2',
+               '--warmup', '1', '--workload', 'tiny']
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, out.stdout
+        d = json.loads(lines[0])
+        assert d['metric'].startswith('REHEARSAL') and d['n_gpus'] == n and d['steps'] == 2
+        assert d['rccl_ranks'] == n and d['collective']
+        pr = d['per_rank']
+        for key in ('ms_per_step', 'ld_algorithmic_bytes', 'snps', 'avg_launch_ms', 'launches',
+                    'achieved_GBps'):
+            assert len(pr[key]) == n, key
+        assert sum(pr['snps']) == 6316 and min(pr['snps']) > 0
+        assert d['ms_per_step_min_rank'] <= d['ms_per_step_max_rank']
+        slow = d['roofline_slowest_rank']
+        for key in ('rank', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms',
+                    'launches', 'algorithmic_bytes_per_launch'):
+            assert key in slow, key
+        assert 0 <= slow['rank'] < n and slow['peak'] == 8000.0
+        assert 'cpu_baseline' not in d and d['scaling'] == 'strong'

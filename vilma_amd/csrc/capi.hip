@@ -132,7 +132,10 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
     }
 }
 
-void sort_items(HostItems &H) {
+// order of the symmetric product's work items (vilma_ctx::ld_order): 0 = longest first (default);
+// 1 = the order the panels lie in the store; 2 = store order dealt out so that the workgroups one
+// XCD receives under round-robin dispatch (b, b + 8, ...) walk ONE contiguous eighth of the list
+void sort_items(HostItems &H, int order) {
     // longest first: workgroup run time ~ rows streamed (within each eigen group for its lists)
     for (const EigenGroup &g : H.groups) {
         std::stable_sort(H.a.begin() + g.a0, H.a.begin() + g.a0 + g.na,
@@ -145,9 +148,20 @@ void sort_items(HostItems &H) {
             return (int64_t)x.rows * x.w > (int64_t)y.rows * y.w;
         });
     }
-    std::stable_sort(H.sym.begin(), H.sym.end(), [](const SymItem &x, const SymItem &y) {
-        return (int64_t)x.rows * x.ld > (int64_t)y.rows * y.ld;
-    });
+    if (order == 0) {
+        std::stable_sort(H.sym.begin(), H.sym.end(), [](const SymItem &x, const SymItem &y) {
+            return (int64_t)x.rows * x.ld > (int64_t)y.rows * y.ld;
+        });
+    } else if (order == 2 && H.sym.size() > 8) {
+        const size_t n = H.sym.size(), per = (n + 7) / 8;
+        std::vector<SymItem> out;
+        out.reserve(n);
+        for (size_t q = 0; q < 8 * per; ++q) {
+            const size_t src = (q % 8) * per + q / 8;
+            if (src < n) out.push_back(H.sym[src]);
+        }
+        H.sym.swap(out);
+    }
     for (auto &v : H.eig)
         std::stable_sort(v.begin(), v.end(), [](const EigItem &x, const EigItem &y) {
             return (int64_t)x.n * x.ncols > (int64_t)y.n * y.ncols;
@@ -165,7 +179,7 @@ int upload_vec(vilma_ctx *c, const std::vector<T> &v, T **dev, int *count) {
 }
 
 int upload_items(vilma_ctx *c, HostItems &H, ItemSet &out) {
-    sort_items(H);
+    sort_items(H, c->ld_order);
     out.groups = H.groups;
     std::vector<EigItem> eig_all;
     for (int k = 0; k < 4; ++k) {
@@ -180,6 +194,30 @@ int upload_items(vilma_ctx *c, HostItems &H, ItemSet &out) {
     return upload_vec(c, H.sym, &out.sym, &out.n_sym) || upload_vec(c, H.comb, &out.comb, &out.n_comb) ||
            upload_vec(c, H.a, &out.a, &out.n_a) || upload_vec(c, H.row, &out.row, &out.n_row) ||
            upload_vec(c, H.rcomb, &out.rcomb, &out.n_rcomb);
+}
+
+// the device-resident work lists of every cohort's product (and of all cohorts together)
+int build_item_lists(vilma_ctx *c, std::vector<int32_t> &dstart, int32_t &slot, int32_t &t_base,
+                     int32_t &s_base) {
+    HostItems all;
+    dstart.assign(c->P + 1, 0);
+    slot = 0; t_base = 0; s_base = 0;
+    free_items(c->all);
+    for (auto &it : c->solo) free_items(it);
+    c->solo.clear();
+    c->solo.resize(c->P);
+    for (int p = 0; p < c->P; ++p) {
+        dstart[p] = slot;
+        HostItems one;
+        int32_t s0 = slot;
+        make_items(c, p, c->ld[p], t_base, s_base, s0, one);
+        make_items(c, p, c->ld[p], t_base, s_base, slot, all);     // same items, same slots
+        if (upload_items(c, one, c->solo[p])) return 1;
+        t_base += c->ld[p].t_used;
+        s_base += c->ld[p].s_used;
+    }
+    dstart[c->P] = slot;
+    return upload_items(c, all, c->all);
 }
 
 int ensure_ready(vilma_ctx *c) {
@@ -205,22 +243,9 @@ int ensure_ready(vilma_ctx *c) {
                            std::to_string(s_total) + " doubles) must stay below 2^31; shard the "
                            "SNPs over more GPUs");
     }
-    HostItems all;
-    std::vector<int32_t> dstart(c->P + 1, 0);
+    std::vector<int32_t> dstart;
     int32_t slot = 0, t_base = 0, s_base = 0;
-    c->solo.resize(c->P);
-    for (int p = 0; p < c->P; ++p) {
-        dstart[p] = slot;
-        HostItems one;
-        int32_t s0 = slot;
-        make_items(c, p, c->ld[p], t_base, s_base, s0, one);
-        make_items(c, p, c->ld[p], t_base, s_base, slot, all);     // same items, same slots
-        if (upload_items(c, one, c->solo[p])) return 1;
-        t_base += c->ld[p].t_used;
-        s_base += c->ld[p].s_used;
-    }
-    dstart[c->P] = slot;
-    if (upload_items(c, all, c->all)) return 1;
+    if (build_item_lists(c, dstart, slot, t_base, s_base)) return 1;
     const int64_t pool_elems = 2 * (int64_t)c->P * c->N + t_base + 2;
     c->pool_elems = pool_elems;
     for (int s = 0; s < 3; ++s)
@@ -474,6 +499,29 @@ __global__ __launch_bounds__(256) void store_stream_kernel(const probe_v2d *__re
     if (acc == 1.2345e300) sink[0] = acc;      // never true for LD data: keeps the loads alive
 }
 
+// The same bare read with the store cut into chunks of `steps` x 32 KB, each read front to back by
+// one workgroup; chunk c of the grid-stride loop is chunk (c * mult) mod n_chunks of the store
+// (mult = 1: store order; an odd multiplier coprime to n_chunks: scattered).  What an access
+// pattern alone costs: the LD kernels' workgroups each stream their own panel chunk (up to 512 KB)
+// from wherever it lies, some two thousand of them at a time.
+__global__ __launch_bounds__(256) void store_pattern_kernel(const probe_v2d *__restrict__ p,
+                                                            int64_t n_chunks, int steps,
+                                                            int64_t mult, double *sink) {
+    double acc = 0.0;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const int64_t src = mult == 1 ? ch : (int64_t)(((unsigned __int128)ch * (uint64_t)mult) % (uint64_t)n_chunks);
+        const probe_v2d *q = p + src * steps * 2048 + threadIdx.x;
+        for (int st = 0; st < steps; ++st, q += 2048) {
+            probe_v2d t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(q + u * 256);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u].x + t[u].y;
+        }
+    }
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+
 extern "C" {
 
 const char *vilma_version(void) { return "vilma_hip 0.1 (gfx950)"; }
@@ -538,6 +586,10 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     if (const char *se = std::getenv("VILMA_EIG_SLAB_ELEMS")) {
         const int v = std::atoi(se);
         if (v >= 1024) g_eig_slab_elems = v;
+    }
+    if (const char *lo = std::getenv("VILMA_LD_ORDER")) {
+        const int v = std::atoi(lo);
+        if (v >= 0 && v <= 2) c->ld_order = v;
     }
     if (const char *cr = std::getenv("VILMA_LD_CHUNK_ROWS")) {
         const int v = std::atoi(cr);
@@ -1073,6 +1125,70 @@ int vilma_prof_stream_store(vilma_ctx *c, void *stream, int passes, double *ms_p
     (void)hipEventDestroy(e1);
     if (ms_per_pass) *ms_per_pass = total / passes;
     if (bytes_per_pass) *bytes_per_pass = bytes;
+    return 0;
+}
+
+int vilma_prof_stream_pattern(vilma_ctx *c, void *stream, int passes, int chunk_kb, int scattered,
+                              int grid, double *ms_per_pass, int64_t *bytes_per_pass) {
+    if (!c) return 1;
+    if (passes < 1 || chunk_kb < 32 || chunk_kb % 32 || grid < 1)
+        return fail(c, "vilma_prof_stream_pattern: passes >= 1, chunk_kb a multiple of 32, grid >= 1");
+    if (vilma_sweep_drain(c)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    const int steps = chunk_kb / 32;
+    int64_t bytes = 0;
+    double total = 0.0;
+    for (int it = 0; it <= passes; ++it) {          // the first pass warms up and is not counted
+        bytes = 0;
+        HIPCHK(c, hipEventRecord(e0, st));
+        for (const CohortLd &co : c->ld) {
+            const int64_t chunks = co.store_used / (4096 * (int64_t)steps);
+            if (!co.store || chunks == 0) continue;
+            int64_t mult = 1;
+            if (scattered) {            // an odd multiplier near chunks * 0.618, coprime to chunks
+                mult = ((int64_t)(0.6180339887 * (double)chunks)) | 1;
+                auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+                while (gcd(mult, chunks) != 1) mult += 2;
+            }
+            hipLaunchKernelGGL(store_pattern_kernel, dim3((unsigned)std::min<int64_t>(chunks, grid)),
+                               dim3(256), 0, st, (const probe_v2d *)co.store, chunks, steps, mult,
+                               c->diff_partials);
+            bytes += chunks * steps * 32768;
+        }
+        HIPCHK(c, hipEventRecord(e1, st));
+        HIPCHK(c, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0) total += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ms_per_pass) *ms_per_pass = total / passes;
+    if (bytes_per_pass) *bytes_per_pass = bytes;
+    return 0;
+}
+
+int vilma_prof_ld_order(vilma_ctx *c, int order) {
+    if (!c) return 1;
+    if (order < 0 || order > 2) return fail(c, "vilma_prof_ld_order: order must be 0, 1 or 2");
+    if (vilma_sweep_drain(c)) return 1;
+    HIPCHK(c, hipDeviceSynchronize());
+    c->ld_order = order;
+    if (!c->ready) return 0;
+    // the same items in another order: offsets, scratch and partial slots do not move
+    std::vector<int32_t> dstart;
+    int32_t slot = 0, t_base = 0, s_base = 0;
+    return build_item_lists(c, dstart, slot, t_base, s_base);
+}
+
+int vilma_prof_ld_trace(vilma_ctx *c, double *buf_dev, int64_t capacity_rows) {
+    if (!c) return 1;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (set_ld_trace(buf_dev, capacity_rows))
+        return fail(c, "this build of the library has no LD trace (compile with -DLD_TRACE=1)");
     return 0;
 }
 

@@ -160,6 +160,9 @@ struct vilma_ctx {
     bool ready = false;
     // rows per work item of the symmetric product (multiple of 32); VILMA_LD_CHUNK_ROWS overrides
     int chunk_rows = 512;
+    // order of the symmetric product's work items (capi.hip: sort_items); VILMA_LD_ORDER /
+    // vilma_prof_ld_order override
+    int ld_order = 0;
     // U bytes per eigen-form group.  Default: ONE group (first pass over every block, then the
     // second).  Running both passes group by group so that the second finds U in the 256 MB
     // Infinity Cache was measured and LOSES: 1.16 ms per product ungrouped, 1.50 / 1.76 / 2.32 ms

@@ -224,6 +224,9 @@ void launch_repack_columns(const double *src, int n, int r, int64_t ldc, double 
 // sits s_stride doubles, its y.z partials dot_stride slots behind the first one's
 void launch_ld_sym(const SymItem *items, int n_items, const double *pool0, const double *pool1,
                    double *scratch, int64_t s_stride, hipStream_t s);
+// per-workgroup trace of ld_sym_kernel (builds with -DLD_TRACE=1 only; else returns 1): row b of
+// buf = {s_memrealtime at start, at end (100 MHz ticks), XCC id, bytes of the chunk}
+int set_ld_trace(double *buf_dev, int64_t capacity_rows);
 void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0, double *pool1,
                            const double *scratch, int64_t s_stride, double *dot_partials,
                            int dot_stride, hipStream_t s);

@@ -354,6 +354,23 @@ static __device__ __forceinline__ void sym_group_diag(const v2d (&v)[CS_ROWS],
 #ifndef SYM_PIPELINE
 #define SYM_PIPELINE 1
 #endif
+// -DLD_TRACE=1 (profiles/ld_levels_probe.py builds that variant next to the library): every
+// workgroup of ld_sym_kernel leaves {start, end, XCC id, bytes} in a trace buffer
+#ifndef LD_TRACE
+#define LD_TRACE 0
+#endif
+#if LD_TRACE
+__device__ double *g_ld_trace = nullptr;
+__device__ long long g_ld_trace_cap = 0;
+int set_ld_trace(double *buf_dev, int64_t capacity_rows) {
+    long long cap = capacity_rows;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ld_trace), &buf_dev, sizeof(buf_dev)) != hipSuccess) return 2;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ld_trace_cap), &cap, sizeof(cap)) != hipSuccess) return 2;
+    return 0;
+}
+#else
+int set_ld_trace(double *, int64_t) { return 1; }
+#endif
 template <int NR>
 __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     const SymItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
@@ -361,6 +378,9 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     __shared__ double red[NR][CS_WAVES][128];
     __shared__ double rs_diag[NR][128];
     PRED_EXIT(pred);
+#if LD_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     PoolPair pools = pools_arg;
     if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const SymItem it = items[blockIdx.x];
@@ -475,6 +495,15 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
             scratch[r * s_stride + it.c_off + threadIdx.x] = has_diag ? s + rs_diag[r][threadIdx.x] : s;
         }
     }
+#if LD_TRACE
+    if (threadIdx.x == 0 && g_ld_trace != nullptr && (long long)blockIdx.x < g_ld_trace_cap) {
+        double *row = g_ld_trace + 4 * (long long)blockIdx.x;
+        row[0] = (double)trace_t0;
+        row[1] = (double)__builtin_amdgcn_s_memrealtime();
+        row[2] = (double)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xf);    // HW_REG_XCC_ID[3:0]
+        row[3] = 8.0 * (double)it.rows * (double)it.ld;
+    }
+#endif
 }
 
 // y[j] for 256 columns of one block per workgroup: the row sums S[J][j] of the slabs to the left

@@ -44,29 +44,40 @@ Rccl &rccl() {
 bool rccl_load() {
     Rccl &r = rccl();
     if (r.handle) return true;
-    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1",
-                           "/opt/rocm/lib/librccl.so"};
+    const char *defaults[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1",
+                              "/opt/rocm/lib/librccl.so"};
+    // VILMA_RCCL_LIB names the one library to bind instead (a site's own build; tests point it
+    // at a file that does not exist to walk the "no RCCL on this rank" path)
+    const char *only = std::getenv("VILMA_RCCL_LIB");
+    std::vector<const char *> names;
+    if (only && only[0]) names.push_back(only);
+    else names.assign(defaults, defaults + 4);
     // the copy already mapped into the process first (two RCCL runtimes in one process would each
     // keep their own device state)
+    void *h = nullptr;
     for (const char *n : names)
-        if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-    if (!r.handle)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!h)
         for (const char *n : names)
-            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!r.handle) {
-        r.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found");
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+        const char *e = dlerror();          // one call: it returns the message and clears it
+        r.error = std::string("cannot load librccl.so: ") + (e ? e : "not found");
         return false;
     }
-    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
-    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
-    r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
-    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
-    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) {
         r.error = "librccl.so lacks the ncclCommInitRank / ncclAllReduce entry points";
-        r.handle = nullptr;
+        r.GetUniqueId = nullptr; r.CommInitRank = nullptr; r.AllReduce = nullptr;
+        r.CommDestroy = nullptr; r.GetErrorString = nullptr;
+        (void)dlclose(h);
         return false;
     }
+    r.handle = h;
     return true;
 }
 
@@ -825,10 +836,11 @@ int vilma_set_fit_constants(vilma_ctx *c, const double *chi, const double *ranks
 }
 
 int vilma_comm_unique_id(char id[128]) {
-    if (!rccl_load()) return 1;
+    // no context to carry the message: vilma_last_error(NULL) reports it
+    if (!rccl_load()) return fail(nullptr, rccl().error);
     Id128 u;
     std::memset(&u, 0, sizeof(u));
-    if (rccl().GetUniqueId(&u) != 0) return 1;
+    if (rccl().GetUniqueId(&u) != 0) return fail(nullptr, "ncclGetUniqueId failed");
     std::memcpy(id, u.bytes, 128);
     return 0;
 }

@@ -348,30 +348,24 @@ class HipEngine:
             return
         if comm.backend == 'nccl' and not comm.force_callback:
             # every rank must end up with the same kind of collective: agree on the outcome
-            err = None
-            ident = C.create_string_buffer(128)
-            # every rank makes an id (only rank 0's is used): a rank that cannot even load RCCL must
-            # be known BEFORE the others enter ncclCommInitRank, which would wait for it forever
-            have_id = self.lib.vilma_comm_unique_id(ident) == 0
-            cannot = comm.allreduce_np(np.array([0.0 if have_id else 1.0]))[0]
-            # rank 0 always broadcasts (an empty id = "could not make one"), so nobody waits forever
-            raw = comm.broadcast_bytes(ident.raw if (have_id and cannot == 0) else b'')
-            if len(raw) != 128:
-                err = 'RCCL is not loadable on %d rank(s) (librccl.so?)' % int(cannot)
-            else:
-                try:
-                    self._check(self.lib.vilma_comm_init_rccl(self.ctx, comm.world, comm.rank,
-                                                              C.create_string_buffer(raw, 128)))
-                except _lib.VilmaHipError as exc:
-                    err = str(exc)
-            failed = comm.allreduce_np(np.array([0.0 if err is None else 1.0]))[0]
-            if failed == 0:
+            from .sharding import agree_on_rccl
+
+            def make_id():
+                ident = C.create_string_buffer(128)
+                return ident.raw if self.lib.vilma_comm_unique_id(ident) == 0 else None
+
+            def init_rccl(raw):
+                self._check(self.lib.vilma_comm_init_rccl(self.ctx, comm.world, comm.rank,
+                                                          C.create_string_buffer(raw, 128)))
+
+            ok, err, failed = agree_on_rccl(comm, make_id, init_rccl)
+            if ok:
                 self.collective = 'rccl (communicator owned by the context)'
                 return
             import logging
             logging.warning('the context could not set up its own RCCL communicator on %d rank(s) '
                             '(%s); the sweep\'s all-reduces go through torch.distributed instead',
-                            int(failed), err or 'another rank failed')
+                            failed, err)
         base, results = int(self._results_ptr), self.results
 
         def allreduce(_user, _stream, buf, n, op):
@@ -517,3 +511,25 @@ class HipEngine:
         self._check(self.lib.vilma_prof_stream_store(self.ctx, self._stream(), int(passes),
                                                      C.byref(ms), C.byref(nbytes)))
         return ms.value, nbytes.value
+
+    def stream_pattern(self, chunk_kb, scattered, grid=4096, passes=5):
+        """(milliseconds, bytes) of a bare read of the LD store in chunks of `chunk_kb`, one
+        workgroup per chunk, in store order or scattered (vilma_prof_stream_pattern)."""
+        ms, nbytes = C.c_double(), C.c_int64()
+        self._check(self.lib.vilma_prof_stream_pattern(self.ctx, self._stream(), int(passes),
+                                                       int(chunk_kb), 1 if scattered else 0,
+                                                       int(grid), C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
+
+    def ld_order(self, order):
+        """Order of ld_sym_kernel's work items (vilma_prof_ld_order); results do not change."""
+        self._check(self.lib.vilma_prof_ld_order(self.ctx, int(order)))
+
+    def ld_trace(self, buf):
+        """Per-workgroup trace of ld_sym_kernel into the torch tensor buf [rows, 4] (None = off);
+        only in builds with -DLD_TRACE=1 (vilma_prof_ld_trace)."""
+        if buf is None:
+            self._check(self.lib.vilma_prof_ld_trace(self.ctx, None, 0))
+        else:
+            self._check(self.lib.vilma_prof_ld_trace(self.ctx, C.c_void_p(buf.data_ptr()),
+                                                     int(buf.shape[0])))

@@ -37,6 +37,35 @@ def init_distributed_from_env():
     return True
 
 
+def agree_on_rccl(comm, make_id, init_rccl):
+    """Set up one RCCL communicator per context on every rank, or on none: all ranks leave with
+    the same answer, and no rank is ever left waiting inside ncclCommInitRank for a rank that
+    cannot take part.
+
+    make_id() -> the 128 bytes of ncclGetUniqueId, or None when this rank cannot even load RCCL;
+    init_rccl(id_bytes) -> None, raising on failure (ncclCommInitRank on this rank's context).
+    Returns (ok, reason, n_failed): ok on every rank or on none."""
+    ident = make_id()
+    have_id = ident is not None and len(ident) == 128
+    # every rank makes an id (only rank 0's is used): a rank that cannot load RCCL must be known
+    # BEFORE the others enter ncclCommInitRank, which would wait for it forever
+    cannot = int(round(float(comm.allreduce_np(np.array([0.0 if have_id else 1.0]))[0])))
+    # rank 0 always broadcasts (an empty id = "not everybody can"), so nobody waits forever
+    raw = comm.broadcast_bytes(bytes(ident) if (have_id and cannot == 0) else b'')
+    err = None
+    if len(raw) != 128:
+        err = 'RCCL is not loadable on %d rank(s) (librccl.so?)' % max(cannot, 1)
+    else:
+        try:
+            init_rccl(raw)
+        except Exception as exc:        # noqa: BLE001 - reported to every rank below
+            err = str(exc)
+    failed = int(round(float(comm.allreduce_np(np.array([0.0 if err is None else 1.0]))[0])))
+    if failed == 0:
+        return True, None, 0
+    return False, err or 'another rank failed', failed
+
+
 class Comm:
     """Thin wrapper over torch.distributed; a no-op for a single process."""
 

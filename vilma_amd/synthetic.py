@@ -39,6 +39,13 @@ WORKLOADS = {
                 kind='lowrank', spectrum='factor', rank_frac=0.25),
     'tiny4f': dict(P=2, n_ld=6_000, B=12, M=12, fixed=None, missing_frac=0.05,
                    kind='lowrank', spectrum='factor', rank_frac=0.25),
+    # C3K12: C3's SNPs and LD under the mixture `vilma fit` builds BY DEFAULT for two cohorts: the
+    # grid of _make_simple at -K 12 (reference vi_options.py:17-20, 284-337) = 582 components
+    # (SURVEY.md section 0.4).  The per-SNP passes then move 14.5x C3's bytes and dominate the sweep.
+    'C3K12': dict(P=2, n_ld=1_000_000, B=1700, M=582, fixed=None, missing_frac=0.05,
+                  mixture='make_simple', K=12),
+    'tinyK12': dict(P=2, n_ld=6_000, B=12, M=582, fixed=None, missing_frac=0.05,
+                    mixture='make_simple', K=12),
 }
 FACTOR_LD_THRESH = 0.8
 
@@ -83,6 +90,21 @@ def mixture_covs(P, M):
         r = 0.0 if P == 1 else (0.0, 0.5, 0.9)[k % 3]
         covs.append(var[k] * ((1 - r) * np.eye(P) + r * np.ones((P, P))))
     return np.array(covs)
+
+
+def make_simple_covs(P, K, seed):
+    """The reference's default mixture grid (vi_options._make_simple, reference vi_options.py:
+    284-337) for squared effects between 1e-7 and 2e-3 in every cohort -- the range its data-driven
+    heuristic (:196-226) lands in for sumstats of this recipe.  The grid draws from numpy's global
+    legacy RNG; the caller's stream is put back afterwards."""
+    from .vi_options import _make_simple
+    state = np.random.get_state()
+    try:
+        np.random.seed(100003 + seed)
+        covs = _make_simple(P, K, np.full(P, 1e-7), np.full(P, 2e-3))
+    finally:
+        np.random.set_state(state)
+    return np.array(covs, dtype=np.float64)
 
 
 def shard_ranges(sizes, miss, world, per_snp_cost):
@@ -132,7 +154,7 @@ class SyntheticShard:
 
     def __init__(self, P, n_ld, B, M, fixed=None, missing_frac=0.0, seed=0, rank=0, world=1,
                  gwas_N=1e5, init_hg=0.1, block_range=None, kind='ar1', rank_frac=0.28,
-                 spectrum='geom'):
+                 spectrum='geom', mixture='geom', K=None):
         self.P, self.M, self.A, self.seed = P, M, 1, seed
         self.kind, self.rank_frac, self.spectrum = kind, rank_frac, spectrum
         self.gwas_N = np.full(P, gwas_N, dtype=np.float64)
@@ -162,7 +184,11 @@ class SyntheticShard:
         self.missing = (np.concatenate(miss_pos).astype(np.int64) if miss_pos
                         else np.zeros(0, dtype=np.int64))
         self.perm = np.concatenate([self.ld_snps, self.missing])
-        self.covs = mixture_covs(P, M)
+        if mixture == 'make_simple':
+            self.covs = make_simple_covs(P, K, seed)
+            assert len(self.covs) == M, (len(self.covs), M)
+        else:
+            self.covs = mixture_covs(P, M)
         if kind == 'ar1':
             self.ranks_all = self.sizes_all.astype(np.int64)
         elif spectrum == 'factor':
