@@ -65,11 +65,13 @@ def make_problem(seed, P, sizes, M, ldthresh, kind, frac_missing, A, shuffle):
         ld_members = np.sort(rng.choice(N, size=n_ld, replace=False))
     missing = np.setdiff1d(np.arange(N), ld_members)
     blocks = []     # blocks[p][b] = dense symmetric matrix handed to LowRankMatrix(X, t)
+    rhos = np.zeros((P, len(sizes)))
     for p in range(P):
         this = []
-        for n in sizes:
+        for b, n in enumerate(sizes):
             if kind == 'ar1':
-                this.append(ar1(n, rng.uniform(0.5, 0.95)))
+                rhos[p, b] = rng.uniform(0.5, 0.95)
+                this.append(ar1(n, rhos[p, b]))
             else:
                 this.append(factor_ld(rng, n))
         blocks.append(this)
@@ -109,7 +111,8 @@ def make_problem(seed, P, sizes, M, ldthresh, kind, frac_missing, A, shuffle):
     annotations[np.arange(N), rng.integers(0, A, size=N)] = 1
     return dict(P=P, N=N, M=M, A=A, sizes=np.asarray(sizes, dtype=np.int64), perm=perm,
                 missing=missing.astype(np.int64), blocks=blocks, ldthresh=ldthresh,
-                betahat=betahat, se=se, covs=np.array(covs), annotations=annotations)
+                betahat=betahat, se=se, covs=np.array(covs), annotations=annotations,
+                kind=kind, rhos=rhos)
 
 
 def build_reference_vi(prob, scaled, scale_se, num_its, gwas_N, init_hg):
@@ -138,7 +141,9 @@ class ObjectiveLog(logging.Handler):
 
 
 def trajectory(name, prob, n_sweeps, scaled=False, scale_se=False, seed=42,
-               gwas_N=None, init_hg=None, full_optimize_its=None):
+               gwas_N=None, init_hg=None, full_optimize_its=None, compact=False):
+    """compact=True (mid-size problems): AR(1) LD is stored as its rho per (cohort, block) --
+    tests rebuild R_ij = rho^|i-j| -- and the [M,P,P,N] / initial arrays are left out."""
     P = prob['P']
     gwas_N = [1e5] * P if gwas_N is None else gwas_N
     init_hg = [0.1] * P if init_hg is None else init_hg
@@ -207,9 +212,18 @@ def trajectory(name, prob, n_sweeps, scaled=False, scale_se=False, seed=42,
         final_vi_mu=params[0], final_vi_delta=params[1], final_hyper_delta=params[2],
         final_post_var=vi.real_posterior_variance(*params), final_vi_sigma=vi.vi_sigma,
     )
+    if compact:
+        assert prob['kind'] == 'ar1'
+        out['ld_rho'] = prob['rhos']
+        for key in ('init_vi_mu', 'init_vi_delta', 'init_nat_grad_vi_delta', 'final_vi_sigma',
+                    'final_vi_delta'):
+            out.pop(key)
+        out['post_mean'] = out['post_mean'][[0, len(elbos) // 2, len(elbos) - 1]]
+        out['post_mean_sweeps'] = np.array([0, len(elbos) // 2, len(elbos) - 1])
     for p in range(P):
-        for b, X in enumerate(prob['blocks'][p]):
-            out['ld_%d_%d' % (p, b)] = X
+        if not compact:
+            for b, X in enumerate(prob['blocks'][p]):
+                out['ld_%d_%d' % (p, b)] = X
         for b, m in enumerate(ld_mats[p].matrices):
             out['rank_%d_%d' % (p, b)] = m.s.shape[0]
 
@@ -613,6 +627,14 @@ def main():
         prob = make_problem(8, P=2, sizes=[330, 140], M=10, ldthresh=0.8,
                             kind='factor', frac_missing=0.02, A=1, shuffle=True)
         trajectory('p2_bigblock_lr', prob, n_sweeps=8)
+    if want('p2_mid'):
+        # mid-size (5 000 LD SNPs + 3 % missing, 2 cohorts): long enough a run to hold sweeps with
+        # several beta updates, rejected first steps and a both-candidates-rejected trial; LD stored
+        # as AR(1) parameters (compact)
+        prob = make_problem(9, P=2, sizes=[600, 450, 520, 380, 700, 350, 500, 480, 420, 600],
+                            M=20, ldthresh=1.0, kind='ar1', frac_missing=0.03, A=1, shuffle=True)
+        trajectory('p2_mid', prob, n_sweeps=16, gwas_N=[2e5, 2e5], init_hg=[0.5, 0.5],
+                   compact=True)
 
 
 if __name__ == '__main__':

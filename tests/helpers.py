@@ -13,9 +13,19 @@ def golden(name):
 
 
 def traj_blocks(g):
-    """Dense per-cohort block matrices stored in a trajectory golden."""
+    """Dense per-cohort block matrices stored in a trajectory golden (a compact golden stores
+    AR(1) LD as its parameter: R_ij = rho^|i-j|)."""
     P = int(g['P'])
     nb = len(g['sizes'])
+    if 'ld_rho' in g.files:
+        out = []
+        for p in range(P):
+            this = []
+            for b, n in enumerate(g['sizes']):
+                idx = np.arange(int(n))
+                this.append(float(g['ld_rho'][p, b]) ** np.abs(idx[:, None] - idx[None, :]))
+            out.append(this)
+        return out
     return [[g['ld_%d_%d' % (p, b)] for b in range(nb)] for p in range(P)]
 
 
@@ -141,3 +151,41 @@ def check_trajectory(vi, g, rtol_elbo=1e-9, rtol_mean=1e-7):
                                rtol=1e-7)
     np.testing.assert_allclose(vi.vi_sigma, g['final_vi_sigma'], rtol=1e-9)
     return params
+
+
+def check_compact_trajectory(vi, g, lookahead=False, rtol_elbo=1e-9, rtol_mean=1e-7):
+    """check_trajectory for a compact (mid-size) golden: ELBO, L, running change and hyper_delta
+    per sweep, posterior means at the recorded sweeps, final vi_mu and variance.  lookahead=True
+    drives the sweeps through SweepDriver.sweep with the promise of a next call, i.e. through the
+    device-resident path (sweeps queued ahead, decided on the device)."""
+    for key in ('ld_diags', 'adj_marginal_effects', 'chi_stat', 'ld_ranks', 'inverse_betas'):
+        np.testing.assert_allclose(getattr(vi, key), g[key], rtol=1e-8, atol=1e-12, err_msg=key)
+    np.random.seed(int(g['seed']))
+    params = vi._initialize()
+    elbo = vi.elbo(params)
+    assert abs(elbo - float(g['init_elbo'])) < rtol_elbo * abs(elbo)
+    np.testing.assert_allclose(params[2], g['init_hyper_delta'], rtol=1e-10)
+    n_sweeps = len(g['elbo'])
+    marks = {int(s): i for i, s in enumerate(g['post_mean_sweeps'])}
+    state, L, red = None, np.ones(5), None
+    counts = []
+    for it in range(n_sweeps):
+        e0, t0 = vi.n_evaluations, vi.n_trials
+        if lookahead:
+            state, _ = vi.sweep(state, lookahead=it + 1 < n_sweeps)
+            L, elbo, red = state['L'], state['elbo'], state['running']
+            params = vi._params()
+        else:
+            params, L, elbo, red = vi._optimize_step(params, L=L, curr_elbo=elbo,
+                                                     line_search_rate=2., running_elbo_delta=red)
+        counts.append((vi.n_evaluations - e0, vi.n_trials - t0))
+        assert abs(elbo - g['elbo'][it]) < rtol_elbo * abs(elbo), (it, elbo, g['elbo'][it])
+        assert np.array_equal(L, g['L'][it]), (it, L, g['L'][it])
+        assert abs(red - g['running_elbo_delta'][it]) <= 1e-7 * abs(red) + 1e-9, (it, red)
+        if it in marks:
+            np.testing.assert_allclose(vi.real_posterior_mean(params), g['post_mean'][marks[it]],
+                                       rtol=rtol_mean, atol=1e-12)
+            np.testing.assert_allclose(params[2], g['hyper_delta'][it], rtol=1e-6, atol=1e-300)
+    np.testing.assert_allclose(params[0], g['final_vi_mu'], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(vi.real_posterior_variance(params), g['final_post_var'], rtol=1e-7)
+    return counts

@@ -23,6 +23,23 @@ def test_fit_trajectory(name):
     check_trajectory(vi, g)
 
 
+@pytest.mark.parametrize('lookahead', [False, True])
+def test_mid_size_trajectory_with_inner_loops(lookahead):
+    """5 000 LD SNPs x 2 cohorts, 16 sweeps recorded from the reference, among them sweeps with
+    several beta updates, rejected first steps and a trial whose two candidates are BOTH rejected.
+    lookahead=True: through the device-resident path (sweeps queued ahead and decided on the
+    device); lookahead=False: every decision taken by the library's host code.  Same bars either
+    way: L to the bit, ELBO 1e-9, posterior means 1e-7."""
+    from helpers import check_compact_trajectory
+    g = golden('traj_p2_mid.npz')
+    assert int(g['objs_per_sweep'].max()) >= 9 and g['L'][0, 0] >= 4.0
+    vi, _ = product_vi_from_traj(g)
+    counts = check_compact_trajectory(vi, g, lookahead=lookahead)
+    assert max(t for _, t in counts) >= 3          # a sweep with three or more beta trials
+    if lookahead:
+        assert vi.n_stages_ahead >= 8               # most sweeps did run from the control block
+
+
 @pytest.mark.parametrize('form', ['dense', 'eig'])
 @pytest.mark.parametrize('name', ['p2_lowrank', 'p4_general', 'p2_bigblock_lr'])
 def test_fit_trajectory_forms(name, form):

@@ -11,14 +11,14 @@ from scipy.signal import lfilter
 pytestmark = pytest.mark.gpu
 
 
-def _setup(workload, seed=0, form='auto'):
+def _setup(workload, seed=0, form='auto', block_range=None):
     import torch
     from vilma_amd.synthetic import SyntheticShard, WORKLOADS
     from vilma_amd.engine import HipEngine
     from vilma_amd.sharding import Comm
     from vilma_amd.variational_inference import SweepDriver
     device = torch.device('cuda', 0)
-    sh = SyntheticShard(seed=seed, **WORKLOADS[workload]).build(device)
+    sh = SyntheticShard(seed=seed, block_range=block_range, **WORKLOADS[workload]).build(device)
     sh.finish_init(sh.inv_se2_local)
     eng = HipEngine(sh.P, sh.N, sh.M, 1)
     eng.set_snp_data(sh.adj, sh.se, sh.sld, sh.scalings, sh.annot)
@@ -250,3 +250,74 @@ def test_c5_operator_and_fit_invariants():
     obj = _fresh_objective(drv)
     assert abs(obj - drv._objective) <= 1e-12 * abs(obj)
     eng.close()
+
+
+def _sample_against_oracle(workload, block_range, n_sweeps, form='auto'):
+    """A contiguous run of a full-size workload's LD blocks (its SNPs, LD, sumstats and mixture
+    exactly as in the full problem) fitted on the GPU -- sweeps queued ahead and decided on the
+    device -- and by the oracle from the same starting point: ELBO 1e-9 per sweep, the L
+    trajectory to the bit, posterior means 1e-7 (north star: 1e-5)."""
+    import os
+    from oracle.ldop import EigenBlock, BlockDiagonalLD
+    from oracle.vi import MultiPopVIOracle
+    from oracle import native, numerics as nm
+    from vilma_amd.synthetic import ar1_numpy
+    sh, eng, drv = _setup(workload, form=form, block_range=block_range)
+    assert len(sh.blocks) == block_range[1] - block_range[0]
+    assert len(sh.blocks) >= 0.1 * len(sh.sizes_all)
+    if sh.kind == 'lowrank':
+        ld = [BlockDiagonalLD([EigenBlock(u=U.cpu().numpy(), s=sv.cpu().numpy(), t=1.0)
+                               for U, sv in sh._eig[p]], perm=sh.perm, missing=sh.missing)
+              for p in range(sh.P)]
+    else:
+        ld = [BlockDiagonalLD([EigenBlock(ar1_numpy(b.n, b.rho[p]), 1.0) for b in sh.blocks],
+                              perm=sh.perm, missing=sh.missing) for p in range(sh.P)]
+    ovi = MultiPopVIOracle(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
+                           annotations=np.ones((sh.N, 1)), mixture_covs=list(sh.covs),
+                           checkpoint=False, checkpoint_freq=-1, scaled=False, scale_se=False,
+                           gwas_N=sh.gwas_N, init_hg=sh.init_hg, num_its=n_sweeps)
+    # (the sample's constants use its own sum of 1/se^2, on both sides)
+    np.testing.assert_allclose(ovi.adj_marginal_effects, sh.adj, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ovi.chi_stat, sh.chi_local, rtol=1e-8)
+    # one starting point for both: the device's _initialize on the shard's own jittered start
+    drv.initialize_from(sh.fake_mu)
+    vi_mu0, hyper0 = eng.get_mu(), drv._hyper
+    ovi.nat_grad_vi_delta = nm.fast_vi_delta_grad(hyper0, ovi.log_det, ovi.annotations)
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    native.enable(threads=threads)          # the oracle's per-SNP passes as compiled C loops
+    try:
+        _, d0, _ = ovi._nat_to_not_vi_delta((vi_mu0, None, hyper0))
+        oparams = (vi_mu0, d0, hyper0)
+        oelbo = ovi.elbo(oparams)
+        assert abs(drv._objective - oelbo) < 1e-9 * abs(oelbo)
+        state, oL, ored = None, np.ones(5), None
+        ahead = 0
+        for it in range(n_sweeps):
+            oparams, oL, oelbo, ored = ovi._optimize_step(oparams, oL, oelbo, 2., ored)
+            a0 = drv.n_stages_ahead
+            state, _ = drv.sweep(state, lookahead=it + 1 < n_sweeps)
+            ahead += drv.n_stages_ahead - a0
+            assert abs(state['elbo'] - oelbo) < 1e-9 * abs(oelbo), (it, state['elbo'], oelbo)
+            assert np.array_equal(state['L'], oL), (it, state['L'], oL)
+            assert abs(state['running'] - ored) <= 1e-9 * abs(ored)
+        assert ahead >= n_sweeps - 2            # the sweeps did run from the device's control block
+        mean, var = eng.get_moments()
+        omean = ovi._posterior_mean(*oparams)
+        np.testing.assert_allclose(mean, omean, rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(var, ovi._posterior_marginal_variance(omean, *oparams[:2]),
+                                   rtol=1e-7, atol=1e-16)
+        np.testing.assert_allclose(drv._hyper, oparams[2], rtol=1e-8, atol=1e-300)
+    finally:
+        native.disable()
+        eng.close()
+
+
+def test_c3_block_sample_four_sweeps_against_the_oracle():
+    """170 consecutive blocks of C3's 1700 (10 %, ~100 k SNPs x 2 cohorts, M = 40), four sweeps."""
+    _sample_against_oracle('C3', (700, 870), 4)
+
+
+def test_c4f_block_sample_three_sweeps_against_the_oracle():
+    """170 consecutive blocks of C4f (SURVEY 8d's factor-model LD cut at --ldthresh 0.8; eigen-form
+    and dense blocks mixed by the `auto` rule), three sweeps."""
+    _sample_against_oracle('C4f', (700, 870), 3)

@@ -60,3 +60,34 @@ def test_optimize_convergence(name):
     np.testing.assert_allclose(vi.real_posterior_mean(*params), g['opt_post_mean'], rtol=1e-6,
                                atol=1e-12)
     np.testing.assert_allclose(vi.error_scaling, g['opt_error_scaling'], rtol=1e-8)
+
+
+def test_mid_size_trajectory_with_inner_loops():
+    """The compact mid-size golden (5 000 LD SNPs, 2 cohorts, 16 sweeps recorded from the
+    reference): sweeps with several beta updates and a trial whose first two steps are both
+    rejected -- the schedule (objective evaluations per sweep) as well as the values."""
+    g = golden('traj_p2_mid.npz')
+    assert int(g['objs_per_sweep'].max()) >= 9          # a sweep with an inner beta loop
+    assert g['L'][0, 0] >= 4.0                           # 1 and 2 rejected in the very first update
+    vi, ld = oracle_from_traj(g)
+    for p in range(int(g['P'])):
+        for b, blk in enumerate(ld[p].blocks):
+            assert blk.s.shape[0] == int(g['rank_%d_%d' % (p, b)])
+    np.random.seed(int(g['seed']))
+    params = vi._initialize()
+    elbo = vi.elbo(params)
+    assert abs(elbo - float(g['init_elbo'])) < 1e-9 * abs(elbo)
+    L, red = np.ones(5), None
+    marks = {int(s): i for i, s in enumerate(g['post_mean_sweeps'])}
+    for it in range(len(g['elbo'])):
+        o0 = vi.n_objective
+        params, L, elbo, red = vi._optimize_step(params, L=L, curr_elbo=elbo,
+                                                 line_search_rate=2., running_elbo_delta=red)
+        params = tuple(params)
+        assert abs(elbo - g['elbo'][it]) < 1e-9 * abs(elbo), (it, elbo, g['elbo'][it])
+        assert np.array_equal(L, g['L'][it]), it
+        assert vi.n_objective - o0 == int(g['objs_per_sweep'][it])
+        if it in marks:
+            np.testing.assert_allclose(vi.real_posterior_mean(*params), g['post_mean'][marks[it]],
+                                       rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(params[0], g['final_vi_mu'], rtol=1e-6, atol=1e-12)
