@@ -47,6 +47,10 @@ def parse():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--ld-form', default='auto', choices=['auto', 'dense', 'eig'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--learn-scaling', action='store_true',
+                    help='fit with --learn-scaling (scale_se: the error-scaling EM update of '
+                         '_update_error_scaling, reference variational_inference.py:441-448, 472-486, '
+                         'runs whenever a sweep gains less than EM_TOL); the config string says so')
     ap.add_argument('--cpu-frac', type=float, default=None,
                     help='fraction of the workload\'s LD blocks in the CPU-baseline sample '
                          '(default: 0.25; 0.02 for C5, whose sweep is ~25x C3\'s on the CPU)')
@@ -69,7 +73,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(workload, seed, block_frac, n_sweeps, budget_s=150.0):
+def cpu_baseline(workload, seed, block_frac, n_sweeps, budget_s=150.0, scale_se=False):
     """The oracle (oracle/vi.py: the reference's operation schedule -- two GEMVs per LD block in
     a serial block loop with threaded BLAS, 5-8 products per sweep, one pass per numerics
     function) on the first `block_frac` of the blocks of the same synthetic problem, on this
@@ -123,7 +127,7 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps, budget_s=150.0):
     annotations = np.ones((sh.N, 1))
     vi = MultiPopVIOracle(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
                           annotations=annotations, mixture_covs=list(sh.covs), checkpoint=False,
-                          checkpoint_freq=-1, scaled=False, scale_se=False, gwas_N=sh.gwas_N,
+                          checkpoint_freq=-1, scaled=False, scale_se=scale_se, gwas_N=sh.gwas_N,
                           init_hg=sh.init_hg, num_its=n_sweeps)
     cpu_elbos = []
     # the timed region is split into LD products and per-SNP passes (shares reported)
@@ -175,7 +179,7 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps, budget_s=150.0):
                for p in range(P)]
         gvi = MultiPopVI(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=gld,
                          annotations=annotations, mixture_covs=list(sh.covs), checkpoint=False,
-                         scaled=False, scale_se=False, gwas_N=sh.gwas_N, init_hg=sh.init_hg,
+                         scaled=False, scale_se=scale_se, gwas_N=sh.gwas_N, init_hg=sh.init_hg,
                          num_its=n_sweeps + 1)
         np.random.seed(42)
         gp = gvi._initialize()
@@ -321,7 +325,7 @@ def main():
 
     driver = SweepDriver()
     driver._setup_driver(engine, comm, P, M, 1, chi, ranks, [shard.N_global], log_det,
-                         scale_se=False, num_its=args.steps + args.warmup)
+                         scale_se=args.learn_scaling, num_its=args.steps + args.warmup)
     # one all-reduce through the sweep's own collective, on its stream, before anything is timed:
     # the communicator is connected and every rank is in it
     rccl_ranks = engine.comm_check()
@@ -427,14 +431,15 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': '%s: %d cohorts, %d SNPs (%d in %d %s LD blocks + %d LD-missing), '
-                        'M=%d mixture components%s, fp64 LD %.2f GB algorithmic (%s), A=1, no '
-                        '--learn-scaling' % (args.workload, P, shard.N_global, shard.n_ld_global,
+                        'M=%d mixture components%s, fp64 LD %.2f GB algorithmic (%s), A=1, %s'
+                        % (args.workload, P, shard.N_global, shard.n_ld_global,
                                              len(shard.sizes_all),
                                              'AR(1)' if shard.kind == 'ar1' else ('factor-model, --ldthresh 0.8 (kept rank %.3f n)' % (sum(float(r.sum()) for r in shard.ranks_by_cohort) / (P * max(1.0, float(shard.sizes.sum())))) if shard.spectrum == 'factor' else 'eigen-form (rank %.2f n)' % shard.rank_frac),
                                              shard.N_global - shard.n_ld_global, M,
                                              (' (the grid `vilma fit` builds by default: _make_simple at -K %d)' % cfg['K']) if cfg.get('mixture') == 'make_simple' else '',
                                              (1e-9 * shard.ld_bytes if world == 1 and args.emulate_shard <= 1 else 8e-9 * P * float((shard.sizes_all.astype(np.float64) * shard.ranks_all).sum())),
-                                             '8 n^2 as full matrices; the symmetric kernel needs the lower triangle, half of it' if shard.kind == 'ar1' else '8 n r, U counted once'),
+                                             '8 n^2 as full matrices; the symmetric kernel needs the lower triangle, half of it' if shard.kind == 'ar1' else '8 n r, U counted once',
+                                             'WITH --learn-scaling (error_scaling updated by EM)' if args.learn_scaling else 'no --learn-scaling'),
             'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
             'points_evaluated_per_sweep': n_eval / args.steps,
             # a beta trial evaluates the step the line search tries now and the one it would try
@@ -446,6 +451,7 @@ def main():
             # in a rocprofv3 --stats average as ~6 us launches, not in roofline.avg_launch_ms
             'stages_queued_ahead_then_skipped': driver.n_stages_skipped - sk0,
             'elbo_start': elbo0, 'elbo_end': elbos[-1] if elbos else elbo0,
+            'error_scaling_end': [float(t) for t in np.atleast_1d(driver.error_scaling)],
             'setup_seconds': setup_s,
         },
         'roofline': {
@@ -504,7 +510,7 @@ def main():
         try:
             frac = args.cpu_frac if args.cpu_frac is not None else (0.02 if args.workload == 'C5' else 0.25)
             out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, frac, args.cpu_sweeps,
-                                               args.cpu_budget)
+                                               args.cpu_budget, args.learn_scaling)
         except Exception as exc:      # the GPU number stands on its own
             out['cpu_baseline'] = {'value': None, 'unit': 'sweeps/s', 'cores': 0,
                                    'kind': 'port', 'sample': 'failed: %r' % (exc,)}

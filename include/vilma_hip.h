@@ -400,16 +400,22 @@ int vilma_prof_stream_store(vilma_ctx *ctx, void *stream, int passes, double *ms
  *   vilma_prof_stream_pattern: the bare read of vilma_prof_stream_store with the store cut into
  *     chunks of chunk_kb (a multiple of 32) KB, each read front to back by one workgroup of a grid
  *     of `grid` workgroups; scattered != 0 visits the chunks in a scattered order instead of store
- *     order -- what an access pattern alone costs on this placement of the store.
+ *     order -- what an access pattern alone costs on this placement of the store; writes != 0 adds
+ *     a thin stream of stores (1/128 of the bytes read, like ld_sym_kernel's partial sums) into the
+ *     product's scratch: 1 = 8 doubles per wave per 8 KiB read, 2 = the same non-temporal, 3 =
+ *     whole 128-B lines, 4 = half the bytes, 5 = 4 KiB per workgroup per 512 KB read, 6 = all of
+ *     it at the end of the workgroup's life, 7 = as 5 / 8 = as 1 but addressed by the order in
+ *     time of the chunks instead of their place in the store.
  *   vilma_prof_ld_order: the order of ld_sym_kernel's work items from now on: 0 longest chunk first
  *     (default), 1 the order the panels lie in the store, 2 store order dealt out so that each XCD's
  *     workgroups (b, b + 8, ... under round-robin dispatch) walk one contiguous eighth of it.
  *     Results are bit-identical in every order.  VILMA_LD_ORDER in the environment sets the default.
  *   vilma_prof_ld_trace: builds with -DLD_TRACE=1 only (else an error): every workgroup of
- *     ld_sym_kernel writes {start, end (100 MHz ticks), XCC id, bytes of its chunk} to row
- *     blockIdx.x of buf_dev [capacity_rows][4]; NULL switches it off. */
+ *     ld_sym_kernel writes {start, end (100 MHz ticks), XCC id, bytes of its chunk, core-clock
+ *     cycles from start to end} to row blockIdx.x of buf_dev [capacity_rows][5]; NULL switches
+ *     it off. */
 int vilma_prof_stream_pattern(vilma_ctx *ctx, void *stream, int passes, int chunk_kb,
-                              int scattered, int grid, double *ms_per_pass,
+                              int scattered, int grid, int writes, double *ms_per_pass,
                               int64_t *bytes_per_pass);
 int vilma_prof_ld_order(vilma_ctx *ctx, int order);
 int vilma_prof_ld_trace(vilma_ctx *ctx, double *buf_dev, int64_t capacity_rows);

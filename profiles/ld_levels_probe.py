@@ -7,9 +7,12 @@ process (profiles/r03r_placement_probe.txt)?  One process, one placement of a C3
   2. ld_sym_kernel with its work items longest-first (the default), in store order, and in store
      order dealt out per XCD (vilma_prof_ld_order), interleaved and repeated;
   3. with the -DLD_TRACE=1 build of the library (VILMA_HIP_LIB=vilma_amd/libvilma_hip_trace.so,
-     built by `python profiles/ld_levels_probe.py --build-trace` where hipcc is): the per-workgroup
-     trace of one launch per order -- per-XCD bytes, span and finish time, the tail of the launch,
-     the spread of per-workgroup streaming rates.
+     built by `python profiles/ld_levels_probe.py --build-variants` where hipcc is): the
+     per-workgroup trace of one launch per order -- per-XCD bytes, span and finish time, the tail
+     of the launch, the spread of per-workgroup streaming rates, the core clock the workgroups saw;
+  4. the same bare reads with the thin stream of small stores ld_sym_kernel makes beside them,
+     and (other builds made by --build-variants: VILMA_HIP_LIB=.../libvilma_hip_nostore.so,
+     ..._ntstore.so) ld_sym_kernel without its stores / with non-temporal stores.
 
     python profiles/ld_levels_probe.py [--iters 20] [--workload C3]
 """
@@ -61,8 +64,15 @@ def time_ld(eng, x, y, iters):
 
 
 def analyse_trace(rows, label):
-    """rows [n, 4]: start, end (100 MHz ticks), XCC id, bytes."""
+    """rows [n, 5]: start, end (100 MHz ticks), XCC id, bytes, core-clock cycles start to end."""
     rows = rows[rows[:, 1] > 0]
+    ticks = np.maximum(rows[:, 1] - rows[:, 0], 1.0)
+    mhz = rows[:, 4] / (ticks * 1e-2)           # cycles per microsecond
+    long = ticks >= 2000                        # workgroups that lived 20 us or more
+    if long.any():
+        q = np.percentile(mhz[long], [1, 50, 99])
+        print('  core clock seen by workgroups of 20 us or more (s_memtime / s_memrealtime): '
+              'p1 %.0f  p50 %.0f  p99 %.0f MHz' % tuple(q))
     t0 = rows[:, 0].min()
     start = (rows[:, 0] - t0) * 1e-2          # microseconds
     end = (rows[:, 1] - t0) * 1e-2
@@ -105,12 +115,21 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--workload', default='C3')
     ap.add_argument('--shard', type=int, default=1)
-    ap.add_argument('--build-trace', action='store_true',
-                    help='only build vilma_amd/libvilma_hip_trace.so (-DLD_TRACE=1) and exit')
+    ap.add_argument('--build-variants', action='store_true',
+                    help='only build the diagnostic variants of the library next to it and exit: '
+                         'libvilma_hip_trace.so (-DLD_TRACE=1), _nostore.so (-DLD_STORE_MODE=1: '
+                         'wrong results, timing only), _ntstore.so (-DLD_STORE_MODE=2), '
+                         '_ldsstage.so (-DLD_STORE_MODE=3)')
     args = ap.parse_args()
-    if args.build_trace:
+    if args.build_variants:
+        from concurrent.futures import ThreadPoolExecutor
         from vilma_amd import build
-        build.build_library(extra_flags=['-DLD_TRACE=1'], out=TRACE_LIB)
+        jobs = [(['-DLD_TRACE=1'], TRACE_LIB),
+                (['-DLD_STORE_MODE=1'], TRACE_LIB.replace('_trace', '_nostore')),
+                (['-DLD_STORE_MODE=2'], TRACE_LIB.replace('_trace', '_ntstore')),
+                (['-DLD_STORE_MODE=3'], TRACE_LIB.replace('_trace', '_ldsstage'))]
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            list(pool.map(lambda j: build.build_library(extra_flags=j[0], out=j[1], verbose=False), jobs))
         return
     import torch
     eng, x, y = build_engine(args.workload, args.shard)
@@ -127,6 +146,16 @@ def main():
         ms, nb = eng.stream_pattern(chunk_kb, scattered, grid)
         print('  chunk %5d KB  %-9s  grid %5d: %.3f ms = %.0f GB/s'
               % (chunk_kb, 'scattered' if scattered else 'in order', grid, ms, nb / ms / 1e6))
+    print('the same bare reads with 8 doubles stored per wave per 8 KiB read (chunk, order, grid, stores):')
+    for chunk_kb, scattered, grid in ((32, 0, 4096), (512, 1, 2048), (512, 1, 1536)):
+        for writes, wname in ((0, 'none'), (1, '64 B / wave / 8 KiB'), (2, 'same, non-temporal'),
+                              (3, 'whole lines'), (4, 'half the bytes'),
+                              (5, '4 KiB / WG / 512 KB'), (6, 'all at the WG end'),
+                              (7, '4 KiB / WG, time order'), (8, '64 B / wave, time order'),
+                              (0, 'none')):
+            ms, nb = eng.stream_pattern(chunk_kb, scattered, grid, writes=writes)
+            print('  chunk %5d KB  %-9s  grid %5d  stores %-24s: %.3f ms = %.0f GB/s'
+                  % (chunk_kb, 'scattered' if scattered else 'in order', grid, wname, ms, nb / ms / 1e6))
     print('ld_sym_kernel by order of its work items (avg ms per launch, %d launches each):' % args.iters)
     names = {0: 'longest first', 1: 'store order', 2: 'store order per XCD'}
     for rep in range(2):
@@ -135,7 +164,7 @@ def main():
             ms = time_ld(eng, x, y, args.iters)
             print('  rep %d  %-20s %.4f ms' % (rep, names[order], ms))
     try:
-        buf = torch.zeros((400000, 4), dtype=torch.float64, device=x.device)
+        buf = torch.zeros((400000, 5), dtype=torch.float64, device=x.device)
         eng.ld_trace(buf)
     except Exception as exc:
         print('no trace in this build (%s)' % exc)

@@ -37,7 +37,79 @@ def test_mid_size_trajectory_with_inner_loops(lookahead):
     counts = check_compact_trajectory(vi, g, lookahead=lookahead)
     assert max(t for _, t in counts) >= 3          # a sweep with three or more beta trials
     if lookahead:
-        assert vi.n_stages_ahead >= 8               # most sweeps did run from the control block
+        # every sweep but the last one's tail ran from the control block: the inner beta loops and
+        # the both-candidates-rejected trial were decided on the device, nothing went to the host
+        assert vi.n_stages_ahead >= 15 and vi.n_stages_skipped == 0
+
+
+def test_inner_loops_on_the_device_equal_host_decided_bit_for_bit(monkeypatch):
+    """The mid-size problem's 16 sweeps (inner beta loops of up to eight updates, rejected steps, a
+    trial with both candidates rejected) decided on the device against the same fit with every
+    decision taken by the library's host code: ELBO, L, running change, convergence statistics per
+    sweep and the final vi_mu bit for bit."""
+    g = golden('traj_p2_mid.npz')
+
+    def run(lookahead):
+        monkeypatch.setenv('VILMA_LOOKAHEAD', '1' if lookahead else '0')
+        vi, _ = product_vi_from_traj(g)
+        np.random.seed(int(g['seed']))
+        vi._initialize()
+        state, trace = None, []
+        for k in range(len(g['elbo'])):
+            state, stats = vi.sweep(state, lookahead=k + 1 < len(g['elbo']))
+            trace.append((state['elbo'], tuple(state['L']), state['running'], tuple(stats)))
+        out = (trace, vi._params()[0].copy(), vi.n_trials, vi.n_evaluations, vi.n_stages_ahead,
+               vi.n_stages_skipped)
+        vi.engine.close()
+        return out
+    host, dev = run(False), run(True)
+    assert dev[0] == host[0]
+    assert np.array_equal(dev[1], host[1])
+    assert dev[2] == host[2] and dev[3] == host[3]
+    assert host[4] == 0 and dev[4] >= 15 and dev[5] == 0
+
+
+def test_changing_the_stream_between_queued_sweeps(monkeypatch):
+    """A fit that moves to another HIP stream while sweeps are queued ahead on the old one: the
+    library finishes what it queued there, puts the reported state back and carries on on the new
+    stream -- the same trajectory as a fit that never moved (to rounding: the moments of the
+    restored state are re-derived)."""
+    import torch
+    from vilma_amd.synthetic import SyntheticShard, WORKLOADS
+    from vilma_amd.engine import HipEngine
+    from vilma_amd.sharding import Comm
+    from vilma_amd.variational_inference import SweepDriver
+    device = torch.device('cuda', 0)
+
+    def run(switch):
+        sh = SyntheticShard(seed=5, **WORKLOADS['tiny']).build(device)
+        sh.finish_init(sh.inv_se2_local)
+        eng = HipEngine(sh.P, sh.N, sh.M, 1)
+        eng.set_snp_data(sh.adj, sh.se, sh.sld, sh.scalings, sh.annot)
+        eng.set_mixture(np.linalg.inv(sh.covs), np.linalg.slogdet(sh.covs)[1])
+        for p in range(sh.P):
+            eng.load_ld(p, sh.ld_blocks_torch(p, device), sh.perm, sh.n_ld, specs=sh.block_specs())
+        drv = SweepDriver()
+        drv._setup_driver(eng, Comm(), sh.P, sh.M, 1, sh.chi_local, sh.rank_local, [sh.N_global],
+                          np.linalg.slogdet(sh.covs)[1], scale_se=False, num_its=100)
+        drv.initialize_from(sh.fake_mu)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        state, trace = None, []
+        for k in range(12):
+            which = streams[(k // 4) % 2] if switch else streams[0]
+            with torch.cuda.stream(which):
+                eng.refresh_stream()
+                state, stats = drv.sweep(state, lookahead=k < 11)
+            trace.append((state['elbo'], tuple(state['L'])))
+        torch.cuda.synchronize()
+        mu = eng.get_mu()
+        eng.close()
+        return trace, mu
+    one, mu_one = run(False)
+    two, mu_two = run(True)
+    for a, b in zip(two, one):
+        assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and a[1] == b[1]
+    np.testing.assert_allclose(mu_two, mu_one, rtol=1e-9, atol=1e-300)
 
 
 @pytest.mark.parametrize('form', ['dense', 'eig'])

@@ -2,6 +2,7 @@
 // evaluation entry points.  Device memory is owned by the context (hipMalloc); kernels run on
 // the stream the caller passes.
 #include "ctx.h"
+#include "detmath.h"
 
 namespace vilma_detail { std::string g_create_error; }
 
@@ -287,7 +288,7 @@ void prof_end(vilma_ctx *c, hipStream_t s, hipEvent_t e0, int kind) {
     hipEvent_t e1 = prof_event(c);
     if (!e1) { c->event_pool.push_back(e0); return; }
     (void)hipEventRecord(e1, s);
-    c->pending.push_back({e0, e1, kind});
+    c->pending.push_back({e0, e1, kind, c->prof_tag});
 }
 void prof_resolve(vilma_ctx *c) {
     for (auto &pr : c->pending) {
@@ -364,7 +365,8 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
     a.pp = nullptr;
     a.lse_ref = c->have_moments ? c->lse[cur] : nullptr;
     a.sum_partials = nullptr;
-    a.scal = c->scal; a.snapshot = c->snapshot; a.diff = 0;
+    a.scal = c->scal; a.snapshot = c->snap[c->snap_cur]; a.snapshot_out = c->snap[c->snap_cur];
+    a.diff = 0;
     a.step = step;
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
 }
@@ -372,6 +374,7 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
 // trial_mu / trial_mom: 0 = current, 1 = candidate A, 2 = candidate B
 void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out, int trial_mu = 0, int trial_mom = 0) {
     a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
+    a.pp = nullptr;
     a.mu = c->mu[trial_mu == 2 ? c->mu_tb : trial_mu == 1 ? c->mu_ta : c->mu_cur];
     a.sld = c->sld; a.annot = c->annot;
     a.prec = c->prec; a.log_det = c->log_det; a.lh = c->lh;
@@ -472,14 +475,35 @@ int vilma_detail::queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, 
                                    double *dmax) {
     return evaluate(c, s, false, 0.0, totals, dsum, dmax, 0.0, nullptr, VILMA_PHASE_EVAL);
 }
-size_t vilma_detail::prof_pending(vilma_ctx *c) { return c->pending.size(); }
-void vilma_detail::prof_truncate(vilma_ctx *c, size_t mark) {
-    while (c->pending.size() > mark) {
-        c->event_pool.push_back(c->pending.back().e0);
-        c->event_pool.push_back(c->pending.back().e1);
-        c->pending.pop_back();
-    }
+int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev) {
+    DeltaArgs a;
+    fill_delta_args(c, a, c->delta_partials);
+    set_launch_phase(&c->ctl->phase[VILMA_PHASE_EVAL]);
+    launch_delta_sums(a, sums_dev, s);
+    set_launch_phase(nullptr);
+    HIPCHK(c, hipGetLastError());
+    return 0;
 }
+int vilma_detail::queue_mstep(vilma_ctx *c, hipStream_t s, const double *sums_dev, double *hyper_dev) {
+    launch_mstep(sums_dev, c->counts, c->log_det, c->A, c->M, hyper_dev, c->lh, s);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+static void prof_drop_if(vilma_ctx *c, int64_t lo, int64_t hi) {
+    size_t keep = 0;
+    for (size_t i = 0; i < c->pending.size(); ++i) {
+        const auto &pr = c->pending[i];
+        if (pr.tag >= lo && pr.tag <= hi && pr.tag != 0) {
+            c->event_pool.push_back(pr.e0);
+            c->event_pool.push_back(pr.e1);
+        } else {
+            c->pending[keep++] = pr;
+        }
+    }
+    c->pending.resize(keep);
+}
+void vilma_detail::prof_drop_tag(vilma_ctx *c, int64_t tag) { prof_drop_if(c, tag, tag); }
+void vilma_detail::prof_drop_tags(vilma_ctx *c, int64_t from_tag) { prof_drop_if(c, from_tag, INT64_MAX); }
 
 // A bare read of the LD store: what this placement of the store in HBM streams at, with nothing
 // else in the way (16 B per lane, non-temporal, 8 loads in flight per thread, 32 KB per workgroup
@@ -504,20 +528,60 @@ __global__ __launch_bounds__(256) void store_stream_kernel(const probe_v2d *__re
 // (mult = 1: store order; an odd multiplier coprime to n_chunks: scattered).  What an access
 // pattern alone costs: the LD kernels' workgroups each stream their own panel chunk (up to 512 KB)
 // from wherever it lies, some two thousand of them at a time.
+// writes != 0: a thin stream of stores beside the read stream, 1/128 of the bytes read unless
+// stated (ld_sym_kernel's partial sums are that much), into `wbuf`:
+//   1  every wave stores 8 doubles (64 B, lanes 0, 8, ..., 56: the shape of ld_sym_kernel's row-sum
+//      partials) per 8 KiB it reads; 2 = the same, non-temporal
+//   3  every wave stores one whole 128-B line (16 lanes) per 16 KiB it reads
+//   4  as 1 but every other step only: half the bytes
+//   5  the workgroup stores 4 KiB contiguous (256 threads x 16 B) per 512 KB it reads
+//   6  nothing while it streams; at the end of its loop the workgroup stores everything it would
+//      have stored, contiguously
+//   7  the workgroup stores 4 KiB per 512 KB it reads (as 5), at an address that follows the ORDER
+//      IN TIME of the chunks (chunk c of the grid-stride loop -> record c) instead of where the
+//      chunk lies in the store: workgroups that run side by side write side by side
+//   8  as 1 (64 B per wave per 8 KiB), addressed as 7
 __global__ __launch_bounds__(256) void store_pattern_kernel(const probe_v2d *__restrict__ p,
                                                             int64_t n_chunks, int steps,
-                                                            int64_t mult, double *sink) {
+                                                            int64_t mult, double *sink, int writes,
+                                                            double *__restrict__ wbuf,
+                                                            int64_t wbuf_per_wg) {
     double acc = 0.0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t done = 0;                   // 32-KB steps this workgroup has read
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         const int64_t src = mult == 1 ? ch : (int64_t)(((unsigned __int128)ch * (uint64_t)mult) % (uint64_t)n_chunks);
         const probe_v2d *q = p + src * steps * 2048 + threadIdx.x;
-        for (int st = 0; st < steps; ++st, q += 2048) {
+        for (int st = 0; st < steps; ++st, q += 2048, ++done) {
             probe_v2d t[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(q + u * 256);
+            double part = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += t[u].x + t[u].y;
+            for (int u = 0; u < 8; ++u) part += t[u].x + t[u].y;
+            acc += part;
+            const int64_t gstep = src * steps + st;         // this 32-KB step of the store
+            if ((writes == 1 || writes == 2 || (writes == 4 && (st & 1) == 0)) && (lane & 7) == 0) {
+                double *dst = wbuf + (gstep * 4 + w) * 8 + (lane >> 3);     // [step][wave][8]
+                if (writes == 2) __builtin_nontemporal_store(part, dst);
+                else *dst = part;
+            } else if (writes == 3 && (st & 1) == 0 && lane < 16) {
+                wbuf[(gstep * 4 + w) * 8 + lane] = part;                    // 16 doubles = a line
+            } else if (writes == 5 && (done & 15) == 15) {
+                probe_v2d *dst = (probe_v2d *)(wbuf + (gstep - 15) * 32) + threadIdx.x;     // 4 KiB
+                *dst = probe_v2d{part, acc};
+            } else if (writes == 7 && (done & 15) == 15) {
+                probe_v2d *dst = (probe_v2d *)(wbuf + ((ch * steps + st) - 15) * 32) + threadIdx.x;
+                *dst = probe_v2d{part, acc};
+            } else if (writes == 8 && (lane & 7) == 0) {
+                wbuf[((ch * steps + st) * 4 + w) * 8 + (lane >> 3)] = part;
+            }
         }
+    }
+    if (writes == 6) {
+        double *dst = wbuf + (int64_t)blockIdx.x * wbuf_per_wg;
+        const int64_t n = done * 32 < wbuf_per_wg ? done * 32 : wbuf_per_wg;
+        for (int64_t i = 2 * threadIdx.x; i + 1 < n; i += 512) *(probe_v2d *)(dst + i) = probe_v2d{acc, acc};
     }
     if (acc == 1.2345e300) sink[0] = acc;
 }
@@ -558,7 +622,8 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         rc |= dev_alloc(c, &c->m[s], PN); rc |= dev_alloc(c, &c->v[s], PN);
         rc |= dev_alloc(c, &c->lse[s], N);
     }
-    rc |= dev_alloc(c, &c->snapshot, PN);
+    rc |= dev_alloc(c, &c->snap[0], PN);
+    rc |= dev_alloc(c, &c->snap[1], PN);
     rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_tile_grid(N) * (2 * (2 * P + 2) + 6));
     if (snp_pass_can_stash(M, P, 1)) {
         const char *st = std::getenv("VILMA_TILE_SUMS");        // =0: always delta_kernel (A/B)
@@ -633,7 +698,7 @@ void vilma_destroy(vilma_ctx *c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
                     c->lh, c->counts, c->sum_partials, c->mu[0], c->mu[1], c->mu[2], c->m[0], c->m[1], c->m[2], c->v[0],
-                    c->v[1], c->v[2], c->lse[0], c->lse[1], c->lse[2], c->snapshot, c->snp_partials, c->delta_partials, c->diff_partials};
+                    c->v[1], c->v[2], c->lse[0], c->lse[1], c->lse[2], c->snap[0], c->snap[1], c->snp_partials, c->delta_partials, c->diff_partials};
     for (void *p : ptrs) dev_free(p);
     delete c;
 }
@@ -680,7 +745,8 @@ int vilma_set_hyper(vilma_ctx *c, const double *hyper) {
         for (int k = 0; k < c->M; ++k) {
             const double h = hyper[(size_t)a * c->M + k];
             if (!(h > 0.0)) return fail(c, "hyper_delta entries must be positive");
-            lh[(size_t)a * c->M + k] = std::log(h) - 0.5 * c->log_det_host[k];
+            // det_lh: the same bits the device's M-step (mstep_row) would have produced
+            lh[(size_t)a * c->M + k] = det_lh(h, c->log_det_host[k]);
         }
     // ordered behind kernels already queued on any stream of this device
     HIPCHK(c, hipDeviceSynchronize());
@@ -948,10 +1014,11 @@ int vilma_init_state(vilma_ctx *c, void *stream, const double *fake_mu, double *
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipDeviceSynchronize());
     // the snapshot buffer ([P][N]) is free until the sweep loop starts: staging for fake_mu
-    HIPCHK(c, hipMemcpy(c->snapshot, fake_mu, (size_t)c->P * c->N * sizeof(double), hipMemcpyDefault));
+    double *stage = c->snap[c->snap_cur];
+    HIPCHK(c, hipMemcpy(stage, fake_mu, (size_t)c->P * c->N * sizeof(double), hipMemcpyDefault));
     InitArgs a;
     a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
-    a.fake_mu = c->snapshot; a.sld = c->sld; a.annot = c->annot;
+    a.fake_mu = stage; a.sld = c->sld; a.annot = c->annot;
     a.prec = c->prec; a.log_det = c->log_det;
     a.mu_out = c->mu[c->mu_cur];
     a.partials = c->delta_partials;
@@ -1040,7 +1107,7 @@ int vilma_mean_diff(vilma_ctx *c, void *stream, double *out_sum3_dev, double *ou
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     hipStream_t s = (hipStream_t)stream;
     hipStream_t q = side_begin(c, s);
-    launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,
+    launch_mean_diff(c->m[c->mom_cur], c->scal, c->snap[c->snap_cur], (int64_t)c->P * c->N,
                      c->diff_partials, out_sum3_dev, out_max3_dev, true, q);
     side_end(c, s, q);
     HIPCHK(c, hipGetLastError());
@@ -1052,7 +1119,7 @@ int vilma_snapshot_mean(vilma_ctx *c, void *stream) {
     if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     if (!c->have_moments) return fail(c, "no accepted evaluation of the current state");
     c->snp_marked = false;      // the snapshot is written on `stream`: a following mean_diff stays there
-    launch_mean_diff(c->m[c->mom_cur], c->scal, c->snapshot, (int64_t)c->P * c->N,
+    launch_mean_diff(c->m[c->mom_cur], c->scal, c->snap[c->snap_cur], (int64_t)c->P * c->N,
                      c->diff_partials, nullptr, nullptr, false, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1129,7 +1196,7 @@ int vilma_prof_stream_store(vilma_ctx *c, void *stream, int passes, double *ms_p
 }
 
 int vilma_prof_stream_pattern(vilma_ctx *c, void *stream, int passes, int chunk_kb, int scattered,
-                              int grid, double *ms_per_pass, int64_t *bytes_per_pass) {
+                              int grid, int writes, double *ms_per_pass, int64_t *bytes_per_pass) {
     if (!c) return 1;
     if (passes < 1 || chunk_kb < 32 || chunk_kb % 32 || grid < 1)
         return fail(c, "vilma_prof_stream_pattern: passes >= 1, chunk_kb a multiple of 32, grid >= 1");
@@ -1141,6 +1208,16 @@ int vilma_prof_stream_pattern(vilma_ctx *c, void *stream, int passes, int chunk_
     const int steps = chunk_kb / 32;
     int64_t bytes = 0;
     double total = 0.0;
+    // the sprinkled writes land in the product scratch (2 x s_stride doubles): one store of 8
+    // doubles per 8 KiB read = store bytes / 128
+    double *wbuf = nullptr;
+    if (writes) {
+        int64_t need = 0;
+        for (const CohortLd &co : c->ld) need = std::max<int64_t>(need, co.store_used / 128 + 64 + (int64_t)grid * (chunk_kb + 32));
+        if (ensure_ready(c)) return 1;
+        if (need > 2 * c->s_stride) return fail(c, "the product scratch is too small for the write probe");
+        wbuf = c->sym_scratch;
+    }
     for (int it = 0; it <= passes; ++it) {          // the first pass warms up and is not counted
         bytes = 0;
         HIPCHK(c, hipEventRecord(e0, st));
@@ -1155,7 +1232,10 @@ int vilma_prof_stream_pattern(vilma_ctx *c, void *stream, int passes, int chunk_
             }
             hipLaunchKernelGGL(store_pattern_kernel, dim3((unsigned)std::min<int64_t>(chunks, grid)),
                                dim3(256), 0, st, (const probe_v2d *)co.store, chunks, steps, mult,
-                               c->diff_partials);
+                               c->diff_partials, writes, wbuf,
+                               // mode 6: room per workgroup for everything it would have stored
+                               (int64_t)((chunks * steps + std::min<int64_t>(chunks, grid) - 1) /
+                                         std::min<int64_t>(chunks, grid) + steps) * 32);
             bytes += chunks * steps * 32768;
         }
         HIPCHK(c, hipEventRecord(e1, st));

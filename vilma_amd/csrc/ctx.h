@@ -145,7 +145,13 @@ struct vilma_ctx {
     // LAST trial have them (0: none -- the sums come from delta_kernel)
     double *sum_partials = nullptr;
     int tile_sums_ns = 0;
-    double *snapshot = nullptr, *snp_partials = nullptr, *dot_partials = nullptr;
+    // real_posterior_mean of the last completed sweep (convergence statistics).  Two buffers: the
+    // host-decided path works in place on snap[snap_cur]; a queued sweep's evaluations read
+    // snap[snap_cur] and write the other one, and the decision that ends the sweep flips snap_cur
+    // (an error-scaling re-evaluation in the same sweep must compare with the same old means)
+    double *snap[2] = {nullptr, nullptr};
+    int snap_cur = 0;
+    double *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;
     std::vector<int32_t> dot_start;     // first y.z partial slot of each cohort (+ end)
 
@@ -191,7 +197,9 @@ struct vilma_ctx {
     int prof = 0;                   // 0 off, k >= 1: bracket every k-th LD launch
     int64_t prof_tick = 0;
     bool prof_now = false;
-    struct Pending { hipEvent_t e0, e1; int kind; };
+    struct Pending { hipEvent_t e0, e1; int kind; int64_t tag; };
+    int64_t prof_tag = 0;           // stamped on the brackets recorded while it is set (sweep.hip drops
+                                    // the brackets of queued launches that turned out empty)
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[VILMA_PROF_KINDS] = {0, 0, 0, 0, 0, 0};
@@ -231,7 +239,13 @@ void sweep_destroy(vilma_ctx *c);
 int queue_trial_phase(vilma_ctx *c, hipStream_t s, bool two, double *totals_a, double *totals_b,
                       double *sums_a, double *sums_b);
 int queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, double *dsum, double *dmax);
-size_t prof_pending(vilma_ctx *c);
-void prof_truncate(vilma_ctx *c, size_t mark);
+// responsibility sums of the state the queued EVAL phase starts from (the candidate the decision
+// accepted), for mixtures too large for the trial pass's on-chip stash; and the M-step from them
+int queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev);
+int queue_mstep(vilma_ctx *c, hipStream_t s, const double *sums_dev, double *hyper_dev);
+// HIP-event brackets recorded with vilma_ctx::prof_tag == tag / >= tag are forgotten (launches of
+// a queued phase that did not happen exit at once: their microseconds are not kernel times)
+void prof_drop_tag(vilma_ctx *c, int64_t tag);
+void prof_drop_tags(vilma_ctx *c, int64_t from_tag);
 
 }  // namespace vilma_detail

@@ -100,31 +100,48 @@ struct PhasePtrs {
     const double *pool_cur, *m_cur, *lse_ref;
     double *pool_out, *m_out, *v_out, *lse_out;
     double *pool_out2, *m_out2, *v_out2, *lse_out2;
+    // real_posterior_mean of the last completed sweep, and where an evaluation that carries the
+    // convergence statistics leaves the means it has just formed (the same buffer unless an
+    // error-scaling re-evaluation may follow in the same sweep)
+    const double *snap_in;
+    double *snap_out;
     double step, step2;
+    double tau[VILMA_MAX_P];            // error_scaling in force (the device may have updated it)
 };
-#define VILMA_PHASE_EVAL 0      // the evaluation after the M-step
-#define VILMA_PHASE_TRIAL 1     // the next sweep's beta trial
+#define VILMA_PHASE_EVAL 0      // an evaluation of the current vi_mu (after the M-step / a tau update)
+#define VILMA_PHASE_TRIAL 1     // a beta trial from the current state
 struct SweepCtl {
     int32_t alive;              // 0: every kernel queued under this block exits at once
-    int32_t choice;             // last decision: 1 = candidate A accepted, 2 = B, 0 = none
+    int32_t run_eval;           // the evaluation queued behind the last TRIAL decision runs (that
+                                // decision ended the sweep's beta loop and did the M-step)
+    int32_t run_eval2;          // the re-evaluation queued behind the last EVAL decision runs (that
+                                // decision updated the error scaling)
+    int32_t choice;             // last trial decision: 1 = candidate A accepted, 2 = B, 0 = neither
     int32_t stage;              // decisions taken since the block was armed
     int32_t running_none;       // running ELBO change not defined yet (first sweep)
-    int32_t have_prev;          // a sweep has completed on the device since the block was armed
+    int32_t eval_pending;       // an evaluation has run whose sums no decision has looked at yet:
+                                // 1 = the one after the M-step, 2 = the one after a tau update
+    int32_t inner_it;           // beta updates accepted so far in the sweep in progress
+    int32_t snap_cur;           // which of the two snapshot buffers holds the last completed sweep's means
     int32_t pad;
     int32_t mu_role[3], mom_role[3];    // buffer indices in the roles current / candidate A / B
-    double L_try;               // L[0] of the queued trial's candidate A (B: L_try * rate)
+    double L_try;               // L[0] of the next (or just evaluated) trial's candidate A (B: L_try * rate)
     double L0;                  // L[0] after the last accepted line search
-    double obj_start;           // objective the last accepted beta step started from
-    double obj_beta;            // objective of the candidate it accepted
-    double running;             // running ELBO change (after the sweep before the last decision)
+    double cur_obj;             // objective of the current (accepted) state
+    double delta_sum;           // _nat_grad_step's delta_sum of the sweep in progress
+    double running;             // running ELBO change as of the start of the sweep in progress
+    double tau[VILMA_MAX_P];    // error_scaling in force
+    double hrl[VILMA_MAX_P];    // 0.5 * ld_rank * log(tau) (det_log: the host gets the same bits)
     PhasePtrs phase[2];
 };
-// base pointers of the three buffers of each kind
-struct BufferBases { double *mu[3], *pool[3], *m[3], *v[3], *lse[3]; };
+// base pointers of the three buffers of each kind, and the two snapshot buffers
+struct BufferBases { double *mu[3], *pool[3], *m[3], *v[3], *lse[3], *snap[2]; };
 // The pointers of a phase from the roles at the start of its stage (cur, ta, tb).  The
 // evaluation reads the current vi_mu and writes the moments of role ta; the trial that follows
 // treats those as current (the evaluation is accepted unconditionally), writes candidate A into
-// the old current moments and role ta of vi_mu, candidate B into role tb.
+// the old current moments and role ta of vi_mu, candidate B into role tb.  (A trial that follows a
+// trial -- the inner beta loop -- finds the roles arranged by the decision so that the same rule
+// holds: the accepted candidate's moments sit in role ta.)
 static __host__ __device__ inline void phase_ptrs(const BufferBases &b, const int32_t (&mu)[3],
                                                   const int32_t (&mom)[3], int phase, double step,
                                                   double step2, PhasePtrs &o) {
@@ -136,6 +153,14 @@ static __host__ __device__ inline void phase_ptrs(const BufferBases &b, const in
     o.pool_out = b.pool[ta]; o.m_out = b.m[ta]; o.v_out = b.v[ta]; o.lse_out = b.lse[ta];
     o.pool_out2 = b.pool[tb]; o.m_out2 = b.m[tb]; o.v_out2 = b.v[tb]; o.lse_out2 = b.lse[tb];
     o.step = step; o.step2 = step2;
+}
+// (snap_in / snap_out and tau of a PhasePtrs are set by set_phase_extras)
+static __host__ __device__ inline void set_phase_extras(const BufferBases &b, int snap_cur,
+                                                        bool two_snapshots, const double *tau,
+                                                        PhasePtrs &o) {
+    o.snap_in = b.snap[snap_cur];
+    o.snap_out = b.snap[two_snapshots ? 1 - snap_cur : snap_cur];
+    for (int p = 0; p < VILMA_MAX_P; ++p) o.tau[p] = tau[p];
 }
 // launch attribute of the calling thread like set_launch_predicate: kernels launched while it is
 // set work on *pp's buffers (read on the device when the kernel starts); nullptr = their arguments
@@ -158,8 +183,9 @@ struct SnpKernelArgs {
     double *lse_out;          // [N]
     double *partials;         // [2P+2 | 6 | 2P+2][grid] (column-major: finalize reads columns):
                               // candidate sums, fused statistics, second candidate's sums
-    const double *scal;       // [P][N] scalings            } used when diff != 0 (plain
-    double *snapshot;         // [P][N] real_posterior_mean } evaluations only)
+    const double *scal;       // [P][N] scalings                          } used when diff != 0
+    const double *snapshot;   // [P][N] real_posterior_mean to compare with } (plain evaluations
+    double *snapshot_out;     // [P][N] where the new means go (may be the same) } only)
     int32_t diff;             // fuse the convergence statistics into this evaluation
     double step;
     // second candidate of a two-step beta trial (launch_snp_pass with ns = 2)
@@ -225,7 +251,8 @@ void launch_repack_columns(const double *src, int n, int r, int64_t ldc, double 
 void launch_ld_sym(const SymItem *items, int n_items, const double *pool0, const double *pool1,
                    double *scratch, int64_t s_stride, hipStream_t s);
 // per-workgroup trace of ld_sym_kernel (builds with -DLD_TRACE=1 only; else returns 1): row b of
-// buf = {s_memrealtime at start, at end (100 MHz ticks), XCC id, bytes of the chunk}
+// buf = {s_memrealtime at start, at end (100 MHz ticks), XCC id, bytes of the chunk, core-clock
+// cycles (s_memtime) between start and end}
 int set_ld_trace(double *buf_dev, int64_t capacity_rows);
 void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0, double *pool1,
                            const double *scratch, int64_t s_stride, double *dot_partials,
@@ -245,6 +272,9 @@ void launch_finalize(const double *snp_partials, int snp_rows, int P, const doub
 
 struct DeltaArgs {
     int32_t N, M, A, P;
+    const PhasePtrs *pp;      // non-null: vi_mu, lse and tau of the state a queued sweep's EVAL
+                              // phase starts from (PhasePtrs::mu_in, lse_ref, tau) instead of the
+                              // three fields below
     const double *mu;         // [M][P][N]
     const double *sld;        // [P][N]
     const int32_t *annot;
@@ -295,13 +325,38 @@ void launch_mean_diff(const double *m_cur, const double *scalings, double *snaps
 int mean_diff_grid(int64_t PN);
 
 // ---- device-resident sweep: the decision kernel (see kernels.hip) ----
-#define VILMA_SNAP_EXTRA 20     // scalars of the control block behind the result vector in a
+#define VILMA_SNAP_EXTRA 48     // scalars of the control block behind the result vector in a
                                 // snapshot; the last one is the serial number that completes it
+// what a decision reports in its snapshot (offsets behind the result vector)
+enum {
+    SNAP_ALIVE = 0, SNAP_KIND, SNAP_OUTCOME, SNAP_STAGE, SNAP_CHOICE, SNAP_L_TRY, SNAP_L0,
+    SNAP_CUR_OBJ, SNAP_DELTA_SUM, SNAP_RUNNING, SNAP_RUNNING_NONE, SNAP_INNER_IT, SNAP_ORIG,
+    SNAP_FA, SNAP_FB, SNAP_EVAL_OBJ, SNAP_CONSUMED, SNAP_SWEEP_END, SNAP_SWEEP_CHANGE,
+    SNAP_L_TRIED, SNAP_SNAP_CUR, SNAP_RUN_EVAL, SNAP_RUN_EVAL2, SNAP_EVAL_PENDING,
+    SNAP_MU_ROLE = 24, SNAP_MOM_ROLE = 27, SNAP_TAU = 30, SNAP_HRL = 38,
+    SNAP_SERIAL = VILMA_SNAP_EXTRA - 1
+};
+#define VILMA_DECIDE_TRIAL 0    // behind a beta trial (and the evaluation in front of it, if one ran)
+#define VILMA_DECIDE_EVAL 1     // behind an evaluation: consume it; with scale_se decide the tau update
+// outcomes
+#define VILMA_OUT_NONE 0        // nothing to decide (dead block, or no evaluation had run)
+#define VILMA_OUT_ACCEPT_MSTEP 1    // candidate accepted, beta loop over, M-step done: evaluation runs
+#define VILMA_OUT_ACCEPT_CONTINUE 2 // candidate accepted, the inner beta loop goes on: next trial
+#define VILMA_OUT_REJECTED 3        // every candidate rejected: next trial at larger L
+#define VILMA_OUT_DEAD 4            // the host has to take this decision
+#define VILMA_OUT_SWEEP_END 5       // (EVAL) evaluation consumed, sweep over
+#define VILMA_OUT_TAU_UPDATED 6     // (EVAL) evaluation consumed, tau updated: re-evaluation runs
 struct SweepDecideParams {
+    int mode;                       // VILMA_DECIDE_TRIAL / VILMA_DECIDE_EVAL
     int P, A, M;
     int check_convergence, have_b, have_sums_b;
-    const double *chi, *tau, *half_rank_log_tau;      // host [P]
-    double rel_tol, abs_tol, rate, l_max;
+    int mstep_inside;               // the TRIAL decision does the M-step itself (the accepted
+                                    // candidate's responsibility sums are in the result vector)
+    int scale_se;                   // an EVAL decision may update tau
+    int two_snapshots;              // evaluations write their means to the other snapshot buffer
+    int max_inner;                  // MAX_NUM_ITERS
+    const double *chi, *ranks;      // host [P]
+    double rel_tol, abs_tol, rate, l_max, em_tol;
     SweepCtl *ctl;
     double *results;
     int o_dsum, o_tot, o_ta, o_tb, o_sa, o_sb, o_hyper, n_results;

@@ -24,6 +24,8 @@
 // are never materialised: they are recomputed per (component, SNP) from mixture_prec [M,P,P]
 // and scaled_ld_diags/tau, which turns ~5 full-array streams per pass into ALU work.
 #include "kernels.h"
+#include "detmath.h"
+#include "decide.h"
 
 #include <algorithm>
 
@@ -71,6 +73,20 @@ typedef const v2d __attribute__((address_space(1))) *gd2_ptr;
 #define LD_STREAM_LOAD(p) __builtin_nontemporal_load((gd2_ptr)(p))
 #else
 #define LD_STREAM_LOAD(p) (*(gd2_ptr)(p))
+#endif
+// -DLD_STORE_MODE=k, diagnostic builds only (profiles/ld_levels_probe.py): how ld_sym_kernel's
+// partial sums leave the workgroup.  0 = plain stores (the product); 1 = NO stores (results are
+// wrong: timing only); 2 = non-temporal stores; 3 = row sums staged in LDS and written out, whole
+// and contiguous, when the workgroup has finished streaming its chunk.
+#ifndef LD_STORE_MODE
+#define LD_STORE_MODE 0
+#endif
+#if LD_STORE_MODE == 1
+#define LD_PARTIAL_STORE(p, v) do { if ((v) == 1.2345e300) *(p) = (v); } while (0)
+#elif LD_STORE_MODE == 2
+#define LD_PARTIAL_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define LD_PARTIAL_STORE(p, v) (*(p) = (v))
 #endif
 // Wave-uniform reads of the small per-component tables (mixture precisions, log-weights): through
 // the constant address space the compiler may use scalar loads (SGPR results, scalar cache) even
@@ -302,7 +318,7 @@ static __device__ __forceinline__ void sym_group(const v2d (&v)[CS_ROWS], const 
     int rsub;
     const double t1 = sym_rowsum8(p, lane, rsub);
     const int rr = r0 + rsub;
-    if ((lane & 7) == 0 && (FULL || rr < rows)) srow[rr] = t1;
+    if ((lane & 7) == 0 && (FULL || rr < rows)) LD_PARTIAL_STORE(&srow[rr], t1);
 }
 
 // one group of 8 rows INSIDE the diagonal tile (row r, column c of the tile): only the lower
@@ -359,6 +375,7 @@ static __device__ __forceinline__ void sym_group_diag(const v2d (&v)[CS_ROWS],
 #ifndef LD_TRACE
 #define LD_TRACE 0
 #endif
+
 #if LD_TRACE
 __device__ double *g_ld_trace = nullptr;
 __device__ long long g_ld_trace_cap = 0;
@@ -377,9 +394,13 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     int64_t s_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double red[NR][CS_WAVES][128];
     __shared__ double rs_diag[NR][128];
+#if LD_STORE_MODE == 3
+    __shared__ double rs_stage[NR][512];
+#endif
     PRED_EXIT(pred);
 #if LD_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long trace_c0 = __builtin_amdgcn_s_memtime();
 #endif
     PoolPair pools = pools_arg;
     if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
@@ -401,7 +422,11 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
         // x of this lane's two columns (the slab's columns are rows j0.. of the same vector)
         xs0[r] = active ? xcol[cl] : 0.0;
         xs1[r] = (cl + 1 < it.w) ? xcol[cl + 1] : 0.0;
+#if LD_STORE_MODE == 3
+        srow[r] = it.rows <= 512 ? rs_stage[r] : scratch + r * s_stride + it.s_off + it.j0 + it.r0;
+#else
         srow[r] = scratch + r * s_stride + it.s_off + it.j0 + it.r0;
+#endif
         acc0[r] = 0.0;
         acc1[r] = 0.0;
     }
@@ -484,6 +509,15 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
         red[r][w][2 * lane + 1] = acc1[r];
     }
     __syncthreads();
+#if LD_STORE_MODE == 3
+    if (rows <= 512) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double *dst = scratch + r * s_stride + it.s_off + it.j0 + it.r0;
+            for (int t = ndiag * CS_ROWS + (int)threadIdx.x; t < rows; t += CS_WAVES * 64) dst[t] = rs_stage[r][t];
+        }
+    }
+#endif
     if ((int)threadIdx.x < it.w) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -492,16 +526,18 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
             for (int ww = 1; ww < CS_WAVES; ++ww) s += red[r][ww][threadIdx.x];
             // this chunk's share of the slab's own entries: its column sums (+ the diagonal
             // tile's row sums, which belong to the same entries)
-            scratch[r * s_stride + it.c_off + threadIdx.x] = has_diag ? s + rs_diag[r][threadIdx.x] : s;
+            LD_PARTIAL_STORE(&scratch[r * s_stride + it.c_off + threadIdx.x],
+                             has_diag ? s + rs_diag[r][threadIdx.x] : s);
         }
     }
 #if LD_TRACE
     if (threadIdx.x == 0 && g_ld_trace != nullptr && (long long)blockIdx.x < g_ld_trace_cap) {
-        double *row = g_ld_trace + 4 * (long long)blockIdx.x;
+        double *row = g_ld_trace + 5 * (long long)blockIdx.x;
         row[0] = (double)trace_t0;
         row[1] = (double)__builtin_amdgcn_s_memrealtime();
         row[2] = (double)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xf);    // HW_REG_XCC_ID[3:0]
         row[3] = 8.0 * (double)it.rows * (double)it.ld;
+        row[4] = (double)(__builtin_amdgcn_s_memtime() - trace_c0);      // core-clock cycles
     }
 #endif
 }
@@ -1270,12 +1306,18 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         q.pool_out = t->pool_out; q.m_out = t->m_out; q.v_out = t->v_out; q.lse_out = t->lse_out;
         q.pool_out2 = t->pool_out2; q.m_out2 = t->m_out2; q.v_out2 = t->v_out2; q.lse_out2 = t->lse_out2;
         q.step = t->step; q.step2 = t->step2;
+        q.snap_in = t->snap_in; q.snap_out = t->snap_out;
+#pragma unroll
+        for (int p = 0; p < P; ++p) q.tau[p] = t->tau[p];
     } else {
         q.mu_in = a.mu_in; q.mu_out = a.mu_out; q.mu_out2 = a.mu_out2;
         q.pool_cur = a.pool_cur; q.m_cur = a.m_cur; q.lse_ref = a.lse_ref;
         q.pool_out = a.pool_out; q.m_out = a.m_out; q.v_out = a.v_out; q.lse_out = a.lse_out;
         q.pool_out2 = a.pool_out2; q.m_out2 = a.m_out2; q.v_out2 = a.v_out2; q.lse_out2 = a.lse_out2;
         q.step = a.step; q.step2 = a.step2;
+        q.snap_in = a.snapshot; q.snap_out = a.snapshot_out;
+#pragma unroll
+        for (int p = 0; p < P; ++p) q.tau[p] = a.tau.v[p];
     }
     const int N = a.N, M = a.M;
     const int64_t N64 = N;
@@ -1319,7 +1361,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         se[p] = a.se[p * N64 + ii];
         adj[p] = a.adj[p * N64 + ii];
         sld[p] = a.sld[p * N64 + ii];
-        d[p] = sld[p] / a.tau.v[p];
+        d[p] = sld[p] / q.tau[p];
         g[p] = 0.0;
     }
     if (BLEND) {
@@ -1329,7 +1371,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
             const int pos = a.invperm[p * N64 + ii];
             const double linked = q.pool_cur[(int64_t)(P + p) * N64 + pos];
             const double m = q.m_cur[p * N64 + ii];
-            g[p] = (adj[p] - (linked / se[p] - m * sld[p])) / a.tau.v[p];
+            g[p] = (adj[p] - (linked / se[p] - m * sld[p])) / q.tau[p];
         }
     }
     const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
@@ -1628,7 +1670,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const double nw = mpost[p] * a.scal[p * N64 + i];
-                    const double od = a.snapshot[p * N64 + i];
+                    const double od = q.snap_in[p * N64 + i];
                     const double df = fabs(nw - od);
                     dv[0] += (df <= 1e-6 + 1e-6 * fabs(od)) ? 0.0 : 1.0;
                     dv[1] += df;
@@ -1636,7 +1678,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                     dv[3] = fmax(dv[3], fabs(nw));
                     dv[4] = fmax(dv[4], df);
                     dv[5] = fmax(dv[5], fabs((nw - od) / (od + 1e-100)));
-                    a.snapshot[p * N64 + i] = nw;
+                    q.snap_out[p * N64 + i] = nw;
                 }
             }
 #pragma unroll
@@ -1738,12 +1780,23 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     const int i = (blockIdx.x * (SNP_THREADS / 64) + w) * SPW + (lane % SPW);
     const bool live = i < N;
     const int ii = live ? i : N - 1;
+    // the state: from the arguments, or -- behind a queued sweep's decision -- the one its EVAL
+    // phase starts from (the candidate the decision accepted)
+    const double *mu_state = a.mu, *lse_state = a.lse;
     double d[P];
+    if (a.pp != nullptr) {
+        const phase_tab t = PHASE(a.pp);
+        mu_state = t->mu_in;
+        lse_state = t->lse_ref;
 #pragma unroll
-    for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / a.tau.v[p];
+        for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / t->tau[p];
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / a.tau.v[p];
+    }
     const int ann = ONE_ANNOT ? 0 : a.annot[ii];
     const double *lh = a.lh + (int64_t)ann * M;
-    const double lse = a.lse[ii];
+    const double lse = lse_state[ii];
     double *prow = WRITE ? nullptr : a.out + ((int64_t)blockIdx.x * (SNP_THREADS / 64) + w) * A * M;
     // with KS = 4 the quarter-waves take components k = ks, ks+4, ... of the same 16 SNPs; the
     // per-component sum over SNPs is then a 16-lane (segmented) shuffle reduction
@@ -1760,7 +1813,7 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
         for (int u = 0; u < KD; ++u) {
             const int kc = min(k0 + u * KS, M - 1);       // unconditional loads; extras ignored
 #pragma unroll
-            for (int p = 0; p < P; ++p) mu[u][p] = MU_LOAD(&a.mu[((int64_t)kc * P + p) * N64 + ii]);
+            for (int p = 0; p < P; ++p) mu[u][p] = MU_LOAD(&mu_state[((int64_t)kc * P + p) * N64 + ii]);
         }
 #pragma unroll
         for (int u = 0; u < KD; ++u) {
@@ -1914,6 +1967,7 @@ template <bool WRITE>
 static void launch_delta_any(const DeltaArgs &args, hipStream_t s) {
     DeltaArgs a = args;
     a.pred = g_pred;
+    a.pp = g_phase;
     switch (a.P) {
         case 1: launch_delta_p<1, WRITE>(a, s); break;
         case 2: launch_delta_p<2, WRITE>(a, s); break;
@@ -2551,7 +2605,8 @@ static __device__ __forceinline__ void mstep_row(const double *__restrict__ sums
     for (int k = threadIdx.x; k < M; k += 256) {
         const double h = fmax(sums[(int64_t)a * M + k] * inv, 1e-100) / total;
         hyper[(int64_t)a * M + k] = h;
-        lh[(int64_t)a * M + k] = log(h) - 0.5 * log_det[k];
+        // det_lh: the host rebuilds this table (vilma_set_hyper) to the same bits
+        lh[(int64_t)a * M + k] = det_lh(h, log_det[k]);
     }
 }
 
@@ -2572,162 +2627,66 @@ void launch_mstep(const double *sums, const double *counts, const double *log_de
 }
 
 // --------------------------------------------------------------------------------------------
-// The decision of a device-resident sweep (sweep.hip).  One workgroup, run behind a queued beta
-// trial (candidates A at L = L_try and B at L_try * rate) and the all-reduce of its sums:
-//   - the line search of _update_beta (variational_inference.py:777-800) on the two candidates:
-//     A if it passes the accept test, else B; neither -> the block goes dead and the host, which
-//     reads the snapshot taken here, carries on with its own line search;
-//   - _nat_grad_step's break rule after the accepted step (:432-435) with the running ELBO change
-//     of _optimize_step (:406-409), both in the host's operation order without fused multiply-add,
-//     so host and device can never disagree; an inner loop that has to go on -> dead;
-//   - optimize()'s "no posterior mean moved" stop (:374-382) as a veto -> dead;
-//   - on success: buffers swap roles (vilma_accept's bookkeeping, here on the device), the M-step
-//     of _update_hyper_delta (:837-848) from the accepted candidate's responsibility sums, the
-//     step sizes of the NEXT trial (L / 1.25 floored at 1, :424) and the pointers both phases of
-//     the next stage will work on.
-// Before anything is overwritten the result vector and the block's scalars are written straight
-// into host memory (one snapshot per decision; the host polls the serial number behind it -- no
-// copy kernel, no event).
+// The decisions of a device-resident sweep (sweep.hip).  One workgroup; everything it needs is in
+// the control block (SweepCtl) and the context's result vector, everything it decides goes back
+// into the control block -- the kernels queued behind read their buffers, step sizes, tau and
+// whether to run at all from there -- and, as a snapshot, straight into host memory.
+//
+// The host queues groups  [beta trial (two candidates) -> all-reduce -> TRIAL decision -> evaluation
+// (-> all-reduce -> EVAL decision -> re-evaluation, with --learn-scaling)]  and the device walks
+// the reference's loop through them (variational_inference.py:419-450):
+//   TRIAL decision:
+//   - an evaluation that ran since the last decision (the one after the previous sweep's M-step or
+//     tau update) is looked at first: its objective closes that sweep -- _nat_grad_step's delta_sum,
+//     _optimize_step's running ELBO change (:403-409), optimize()'s "no posterior mean moved" stop
+//     (:374-382) as a veto;
+//   - the line search of _update_beta (:777-800) on the two candidates: A if it passes the accept
+//     test, else B; neither -> the next group's trial runs at the next larger L (this group's
+//     evaluation is skipped);
+//   - _nat_grad_step's break rule after an accepted step (:432-438): the inner loop goes on -> the
+//     next group's trial starts from the accepted candidate (evaluation skipped); it ends -> the
+//     M-step of _update_hyper_delta (:837-848) from the accepted candidate's responsibility sums
+//     and the group's evaluation runs;
+//   - in every case the buffers swap roles (vilma_accept's bookkeeping) and the next trial's step
+//     sizes are set (L / 1.25 floored at 1, :430).
+//   EVAL decision (--learn-scaling): looks at the evaluation after the M-step; if the sweep has
+//     gained less than EM_TOL so far, _update_error_scaling (:472-486): tau from the sums, and the
+//     re-evaluation queued behind runs.
+// What the device will not decide -- L beyond L_MAX, a non-positive tau, the veto -- turns the block
+// dead (every kernel queued behind exits) and the host carries on from the snapshot.  All of this
+// in the host's operation order without fused multiply-add (detmath.h), so the host, which replays
+// every decision from the snapshot's sums, can never disagree.
 // --------------------------------------------------------------------------------------------
-struct SweepDecideArgs {
-    int32_t P, A, M;
-    int32_t check_convergence;       // veto when dsum[0] == 0
-    int32_t have_b, have_sums_b;     // candidate B evaluated / its responsibility sums available
-    double chi[VILMA_MAX_P], tau[VILMA_MAX_P], half_rank_log_tau[VILMA_MAX_P];
-    double rel_tol, abs_tol, rate, l_max;
-    SweepCtl *ctl;
-    const double *results;           // the context's result vector (include/vilma_hip.h layout)
-    int32_t o_dsum, o_tot, o_ta, o_tb, o_sa, o_sb, o_hyper, n_results;
-    double *hyper;                   // results + o_hyper
-    double *lh;
-    const double *counts, *log_det;
-    double *snap;                    // [n_results + VILMA_SNAP_EXTRA], host memory mapped for the device
-    double serial;                   // written behind the snapshot when it is complete
-    BufferBases bases;
-};
-
-static __device__ double sweep_objective(const SweepDecideArgs &a, const double *t) {
-#pragma clang fp contract(off)
-    const int P = a.P;
-    double lik = 0.0;
-    for (int p = 0; p < P; ++p) {
-        const double inner = ((-0.5 * (t[P + p] + t[2 * P + p]) + t[p]) - 0.5 * a.chi[p]) / a.tau[p];
-        lik = lik + (inner - a.half_rank_log_tau[p]);
-    }
-    return lik - (t[3 * P] + t[3 * P + 1]);
-}
-
 __global__ __launch_bounds__(256) void sweep_decide_kernel(const SweepDecideArgs a) {
-#pragma clang fp contract(off)
     __shared__ double red[4];
-    __shared__ int sh_choice;
-    SweepCtl *ctl = a.ctl;
-    double orig = 0.0, fa = 0.0, fb = 0.0;
+    __shared__ double sh_x[VILMA_SNAP_EXTRA];
+    __shared__ int sh_mstep;
     if (threadIdx.x == 0) {
-        int choice = 0;
-        if (ctl->alive) {
-            orig = sweep_objective(a, a.results + a.o_tot);
-            fa = sweep_objective(a, a.results + a.o_ta);
-            fb = a.have_b ? sweep_objective(a, a.results + a.o_tb) : 0.0;
-            // running ELBO change: as armed by the host, or updated with the sweep that has just
-            // completed on the device (its beta step obj_start -> obj_beta, its M-step -> orig)
-            double r = ctl->running;
-            int r_none = ctl->running_none;
-            if (ctl->have_prev) {
-                const double delta_beta = 0.0 + (ctl->obj_beta - ctl->obj_start);
-                const double change = delta_beta + (orig - ctl->obj_beta);
-                r = r_none ? change : r;
-                r = r * 0.5;
-                r = r + 0.5 * (change > 0.0 ? change : 0.0);
-                r_none = 0;
-            }
-            const double L = ctl->L_try;
-            double Lacc = L, fresh = fa;
-            if (fa >= (orig - a.rel_tol * fabs(orig)) - a.abs_tol) {
-                choice = 1;
-            } else if (a.have_b && !(L > a.l_max)) {
-                const double L2 = L * a.rate;
-                if (fb >= (orig - a.rel_tol * fabs(orig)) - a.abs_tol) {
-                    choice = a.have_sums_b ? 2 : 0;
-                    Lacc = L2;
-                    fresh = fb;
-                }
-            }
-            bool ok = choice != 0 && !(Lacc > a.l_max);
-            const bool ends = Lacc == 1.0 || (!r_none && fabs(fresh - orig) <= 0.1 * r) || r_none;
-            ok = ok && ends;
-            if (a.check_convergence && a.results[a.o_dsum] == 0.0) ok = false;
-            if (ok) {
-                // vilma_accept(0) of the evaluation behind the last M-step, then of the candidate
-                const int mc = ctl->mom_role[0], ma = ctl->mom_role[1], mb = ctl->mom_role[2];
-                const int uc = ctl->mu_role[0], ua = ctl->mu_role[1], ub = ctl->mu_role[2];
-                if (choice == 1) {
-                    ctl->mom_role[0] = mc; ctl->mom_role[1] = ma; ctl->mom_role[2] = mb;
-                    ctl->mu_role[0] = ua; ctl->mu_role[1] = uc; ctl->mu_role[2] = ub;
-                } else {
-                    ctl->mom_role[0] = mb; ctl->mom_role[1] = mc; ctl->mom_role[2] = ma;
-                    ctl->mu_role[0] = ub; ctl->mu_role[1] = ua; ctl->mu_role[2] = uc;
-                }
-                ctl->obj_start = orig;
-                ctl->obj_beta = fresh;
-                ctl->running = r;
-                ctl->running_none = r_none;
-                ctl->have_prev = 1;
-                ctl->L0 = Lacc;
-                double Lnext = Lacc / 1.25;
-                Lnext = Lnext > 1.0 ? Lnext : 1.0;
-                ctl->L_try = Lnext;
-                phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_EVAL, 0.0, 0.0, ctl->phase[0]);
-                phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_TRIAL, 1.0 / Lnext,
-                           1.0 / (Lnext * a.rate), ctl->phase[1]);
-            } else {
-                ctl->alive = 0;
-            }
-            ctl->choice = choice;
-            ctl->stage += 1;
-        }
-        sh_choice = ctl->alive ? choice : 0;
+        DecideReport rep;
+        decide_core(a, a.ctl, a.results, rep);
+        sh_mstep = rep.mstep;
+        decide_snapshot_scalars(a, a.ctl, rep, sh_x);
     }
     __syncthreads();
     // snapshot for the host: the result vector as the decision saw it (hyper_delta still the one
     // of the sweep just completed), then the block's scalars after the decision
     for (int t = threadIdx.x; t < a.n_results; t += blockDim.x) a.snap[t] = a.results[t];
-    if (threadIdx.x == 0) {
-        double *x = a.snap + a.n_results;
-        x[0] = (double)ctl->alive; x[1] = (double)ctl->choice; x[2] = (double)ctl->stage;
-        x[3] = ctl->L_try; x[4] = ctl->L0; x[5] = ctl->obj_start; x[6] = ctl->obj_beta;
-        x[7] = ctl->running; x[8] = (double)ctl->running_none;
-        x[9] = orig; x[10] = fa; x[11] = fb;
-        for (int q = 0; q < 3; ++q) { x[12 + q] = (double)ctl->mu_role[q]; x[15 + q] = (double)ctl->mom_role[q]; }
-    }
+    if (threadIdx.x < VILMA_SNAP_EXTRA - 1) a.snap[a.n_results + threadIdx.x] = sh_x[threadIdx.x];
     // the snapshot lives in host memory the device writes directly: data first, then the serial
     // number the host polls for
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        *(volatile double *)(a.snap + a.n_results + VILMA_SNAP_EXTRA - 1) = a.serial;
+        *(volatile double *)(a.snap + a.n_results + SNAP_SERIAL) = a.serial;
         __threadfence_system();
     }
-    const int choice = sh_choice;
-    if (choice == 0) return;
-    const double *sums = a.results + (choice == 1 ? a.o_sa : a.o_sb);
+    const int mstep = sh_mstep;
+    if (mstep == 0) return;
+    const double *sums = a.results + (mstep == 1 ? a.o_sa : a.o_sb);
     for (int an = 0; an < a.A; ++an) mstep_row(sums, a.counts, a.log_det, a.M, an, a.hyper, a.lh, red);
 }
 
 void launch_sweep_decide(const SweepDecideParams &p, hipStream_t s) {
-    SweepDecideArgs a;
-    a.P = p.P; a.A = p.A; a.M = p.M;
-    a.check_convergence = p.check_convergence; a.have_b = p.have_b; a.have_sums_b = p.have_sums_b;
-    for (int q = 0; q < VILMA_MAX_P; ++q) {
-        a.chi[q] = q < p.P ? p.chi[q] : 0.0;
-        a.tau[q] = q < p.P ? p.tau[q] : 1.0;
-        a.half_rank_log_tau[q] = q < p.P ? p.half_rank_log_tau[q] : 0.0;
-    }
-    a.rel_tol = p.rel_tol; a.abs_tol = p.abs_tol; a.rate = p.rate; a.l_max = p.l_max;
-    a.ctl = p.ctl; a.results = p.results;
-    a.o_dsum = p.o_dsum; a.o_tot = p.o_tot; a.o_ta = p.o_ta; a.o_tb = p.o_tb; a.o_sa = p.o_sa;
-    a.o_sb = p.o_sb; a.o_hyper = p.o_hyper; a.n_results = p.n_results;
-    a.hyper = p.results + p.o_hyper; a.lh = p.lh; a.counts = p.counts; a.log_det = p.log_det;
-    a.snap = p.snap; a.serial = p.serial; a.bases = p.bases;
+    const SweepDecideArgs a = decide_args(p);
     hipLaunchKernelGGL(sweep_decide_kernel, dim3(1), dim3(256), 0, s, a);
 }

@@ -7,7 +7,9 @@
 // exactly as the reference takes them from its objectives (same tests, same order), so every
 // rank walks the same accept / reject sequence and the L trajectory is the reference's.
 #include "ctx.h"
+#include "decide.h"
 
+#include <deque>
 #include <dlfcn.h>
 
 namespace {
@@ -122,25 +124,43 @@ struct SweepState {
     bool pend_valid = false;
     double pend_step = 0.0;
 
-    // ---- sweeps queued ahead: [trial, decision, evaluation] per sweep, roles on the device ----
+    // ---- sweeps queued ahead (see "Sweeps queued ahead" below): groups of [trial, decision,
+    // evaluation (, decision, re-evaluation)] run from the control block on the device; the host
+    // reads one snapshot per decision and replays it on its mirror of the block
     bool armed = false;                     // the control block drives the stream
     hipStream_t pipe_stream = nullptr;      // ... this one
-    bool cur_decided = false;               // the decision of the sweep about to be reported is known
-    bool next_queued = false;               // ... and the sweep after it is queued too
     bool pipe_diff = false;                 // queued evaluations carry the convergence statistics
     double pipe_rate = 2.0;
-    int slot = 0;                           // snapshot buffer of the next decision queued
-    int cur_slot = 0, next_slot = 0;
-    double *land[2] = {nullptr, nullptr};   // snapshots: host memory the decision kernel writes
-    double land_serial[2] = {0.0, 0.0};     // the serial number that completes each
+    static constexpr int RING = 8;          // snapshot buffers (at most 2 groups = 4 decisions are outstanding)
+    double *land[RING] = {};                // host memory the decision kernels write
+    int next_land = 0;
     double serial = 0.0;
-    size_t mark_eval[2] = {0, 0};           // profiling brackets pending before a sweep's evaluation
+    struct Queued {                         // a decision queued, its snapshot not looked at yet
+        int land;                           // snapshot buffer
+        double serial;                      // the serial number that completes it
+        SweepDecideArgs args;               // what the kernel was launched with (the mirror replays it)
+        int64_t tag;                        // serial number of its group (profiling brackets: 4 tag + phase)
+        bool first_of_group;                // a TRIAL decision: one group of kernels sits in front of it
+    };
+    std::deque<Queued> outq;
+    int groups_out = 0;                     // trial groups whose TRIAL decision is in outq
+    int64_t group_serial = 0;
+    bool fresh = false;                     // armed, no group queued yet
+    SweepCtl mirror;                        // the control block as of the last decision looked at
     SweepCtl *ctl_host = nullptr;           // pinned staging of the control block
-    // what the decision of the sweep being reported found (from its snapshot)
-    double cur_orig = 0.0, cur_new = 0.0, cur_L0 = 1.0, cur_running = 0.0;
-    int cur_choice = 0;
-    bool cur_running_none = true;
-    int mu_state_before = 0;                // vi_mu buffer of the state before that decision
+    // the state at the end of the last sweep reported from the device (what a caller who breaks
+    // the LOOKAHEAD promise gets back): roles, tau, snapshot buffer
+    struct Reported { int32_t mu_role[3], mom_role[3], snap_cur; double tau[VILMA_MAX_P]; bool valid = false; } rep_end;
+    // statistics of decisions looked at in one call that belong to the next sweep
+    int carry_trials = 0, carry_evals = 0, carry_products = 0;
+    // the host's line search resumes a sweep the device began (see Resume)
+    struct Resume {
+        bool active = false;
+        int it0 = 0;                        // beta updates the device had accepted in this sweep
+        double delta_sum = 0.0;             // ... and what they (and, after_mstep, the M-step) gained
+        bool after_mstep = false;           // the M-step's evaluation has been looked at already
+        double L_try = 0.0;                 // L[0] of the trial waiting in the pend cache
+    } resume;
 
     // per-call
     int flags = 0;
@@ -153,7 +173,7 @@ void vilma_detail::sweep_destroy(vilma_ctx *c) {
     SweepState *s = c->sw;
     if (!s) return;
     if (s->nccl_comm && rccl().CommDestroy) (void)rccl().CommDestroy(s->nccl_comm);
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < SweepState::RING; ++b)
         if (s->land[b]) (void)hipHostFree(s->land[b]);
     if (s->ctl_host) (void)hipHostFree(s->ctl_host);
     dev_free(c->ctl);
@@ -215,16 +235,12 @@ int comm_allreduce(vilma_ctx *c, SweepState *s, hipStream_t st, double *buf, int
 }
 
 // fast_likelihood (numerics.py:31-46) minus _beta_KL (variational_inference.py:873-885) from the
-// all-reduced sums, in the operation order the device decision uses (no fused multiply-add)
+// all-reduced sums: the very function the device decisions use (detmath.h; no fused multiply-add,
+// a logarithm that gives the same bits on both sides)
 double objective_from(const vilma_ctx *c, const SweepState *s, const double *t) {
-#pragma clang fp contract(off)
-    const int P = s->P;
-    double lik = 0.0;
-    for (int p = 0; p < P; ++p) {
-        const double inner = ((-0.5 * (t[P + p] + t[2 * P + p]) + t[p]) - 0.5 * s->chi[p]) / c->tau[p];
-        lik = lik + (inner - 0.5 * s->ranks[p] * std::log(c->tau[p]));
-    }
-    return lik - (t[3 * P] + t[3 * P + 1]);
+    double hrl[VILMA_MAX_P];
+    for (int p = 0; p < s->P; ++p) hrl[p] = det_hrl(s->ranks[p], c->tau[p]);
+    return det_objective(s->P, s->chi.data(), c->tau, hrl, t);
 }
 
 bool is_close(double a, double b) {     // numpy.isclose defaults (rtol 1e-5, atol 1e-8)
@@ -406,8 +422,7 @@ int update_error_scaling(vilma_ctx *c, SweepState *s, hipStream_t st, double *ne
     const int P = s->P;
     double tau[VILMA_MAX_P];
     const double *t = s->totals.data();
-    for (int p = 0; p < P; ++p)
-        tau[p] = (((s->chi[p] - 2 * t[p]) + t[2 * P + p]) + t[P + p]) / s->ranks[p];
+    for (int p = 0; p < P; ++p) tau[p] = det_tau(s->chi[p], t[p], t[2 * P + p], t[P + p], s->ranks[p]);
     if (vilma_set_tau(c, tau)) return 1;
     double obj;
     if (evaluate_current(c, s, st, &obj)) return 1;
@@ -423,28 +438,36 @@ int nat_grad_step(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, double
                   double *delta_sum_out) {
     const double conv_tol = std::isnan(running) ? HUGE_VAL : 0.1 * running;
     double delta_sum = 0.0;
-    // ---- paramset 0: variational family of beta
+    // a sweep the device began and handed over (pipeline_takeover): the beta updates it had
+    // accepted, what they gained, and -- unless the M-step is behind us too -- a trial at L[0]
+    // already evaluated (the pend cache), whose L must not decay again
+    const SweepState::Resume resume = s->resume;
+    s->resume = SweepState::Resume();
+    if (resume.active) delta_sum = resume.delta_sum;
     double orig = s->objective;
-    for (int it = 0; it < MAX_NUM_ITERS; ++it) {
-        L[0] = std::max(1.0, L[0] / 1.25);
-        event(s, 0, 0, L[0], 0.0);
-        double nw;
-        if (update_beta(c, s, st, L, orig, &nw)) return 1;
-        delta_sum += nw - orig;
-        // == np.isclose(new - orig, 0, atol=conv_tol, rtol=0) for finite objectives
-        if (std::fabs(nw - orig) <= conv_tol || L[0] == 1.0 || L[0] > L_MAX) break;
-        orig = nw;
-    }
-    // ---- paramset 1: mixture weights (L[1] stays 1: exactly one pass)
-    L[1] = std::max(1.0, L[1] / 1.25);
-    event(s, 0, 1, L[1], 0.0);
-    // without --learn-scaling this is the sweep's last evaluation: the convergence statistics
-    // ride in its per-SNP pass
-    const bool last = !s->scale_se;
-    orig = s->objective;
     double nw;
-    if (update_hyper(c, s, st, (s->flags & VILMA_SWEEP_DIFF) && last, &nw)) return 1;
-    delta_sum += nw - orig;
+    if (!(resume.active && resume.after_mstep)) {
+        // ---- paramset 0: variational family of beta
+        const int it0 = resume.active ? resume.it0 : 0;
+        for (int it = it0; it < MAX_NUM_ITERS; ++it) {
+            if (!(resume.active && it == it0)) L[0] = std::max(1.0, L[0] / 1.25);
+            event(s, 0, 0, L[0], 0.0);
+            if (update_beta(c, s, st, L, orig, &nw)) return 1;
+            delta_sum += nw - orig;
+            // == np.isclose(new - orig, 0, atol=conv_tol, rtol=0) for finite objectives
+            if (std::fabs(nw - orig) <= conv_tol || L[0] == 1.0 || L[0] > L_MAX) break;
+            orig = nw;
+        }
+        // ---- paramset 1: mixture weights (L[1] stays 1: exactly one pass)
+        L[1] = std::max(1.0, L[1] / 1.25);
+        event(s, 0, 1, L[1], 0.0);
+        // without --learn-scaling this is the sweep's last evaluation: the convergence statistics
+        // ride in its per-SNP pass
+        const bool last = !s->scale_se;
+        orig = s->objective;
+        if (update_hyper(c, s, st, (s->flags & VILMA_SWEEP_DIFF) && last, &nw)) return 1;
+        delta_sum += nw - orig;
+    }
     // ---- paramset 2: annotations -- nothing to do in this scheme (:862-866)
     L[2] = std::max(1.0, L[2] / 1.25);
     event(s, 0, 2, L[2], 0.0);
@@ -460,15 +483,25 @@ int nat_grad_step(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, double
 
 
 // ---------------------------------------------------------------------------------------------
-// Sweeps queued ahead.  With VILMA_SWEEP_LOOKAHEAD the stream always holds one more sweep than the
-// host has reported: [beta trial at the device's L (two candidates) -> all-reduce -> decision
-// kernel (line search, break rule, veto, role swap, M-step, next steps) -> evaluation].  Nothing of
-// it needs the host: buffer roles, step sizes, L and the running ELBO change live in the control
-// block (SweepCtl) on the device.  The host reads one snapshot per decision (copy stream) and
-// replays the decision with the same arithmetic; a decision the device cannot take alone (both
-// candidates rejected, an inner loop that goes on, L beyond L_MAX, the convergence veto) turns the
-// block dead -- every kernel queued behind exits at once -- and the host's own line search
-// continues from the trial already evaluated.
+// Sweeps queued ahead.  With VILMA_SWEEP_LOOKAHEAD the reference's loop (variational_inference.py:
+// 419-450) is walked by the DEVICE: the host queues groups of launches
+//     [beta trial (two candidates) -> all-reduce -> TRIAL decision -> evaluation
+//      (-> all-reduce -> EVAL decision -> re-evaluation, with --learn-scaling)]
+// and sweep_decide_kernel (kernels.hip, decide.h) decides from the control block what each group
+// is: the next step of the line search after a rejection, the next update of the inner beta loop,
+// or the first trial of the next sweep behind the M-step's evaluation.  Buffer roles, step sizes,
+// L, the running ELBO change, delta_sum, tau all live in the control block (SweepCtl); kernels
+// whose phase does not happen (the evaluation behind a trial that did not end the beta loop, the
+// re-evaluation when tau stays) read a flag there and exit at once.  The host reads ONE snapshot
+// per decision -- the decision kernel writes it straight into mapped host memory -- and replays
+// the decision with the same source code (decide_core) on its mirror of the block; it raises if
+// the two ever differ.  What the device will not decide (L beyond L_MAX, a non-positive tau, the
+// convergence veto) turns the block dead and the host's own line search (above) resumes from
+// where the device stood.
+//
+// Invariant: when vilma_sweep returns, at most ONE trial beyond the reported state has been queued,
+// so the reported state's vi_mu is still in its buffer and a caller who breaks the promise
+// (vilma_sweep_drain, any state read) gets exactly that state back.
 // ---------------------------------------------------------------------------------------------
 bool lookahead_enabled() {
     const char *e = std::getenv("VILMA_LOOKAHEAD");
@@ -477,9 +510,17 @@ bool lookahead_enabled() {
 
 // can this sweep run from the control block?
 bool pipeline_eligible(const vilma_ctx *c, const SweepState *s, int flags) {
-    if (!(flags & VILMA_SWEEP_LOOKAHEAD) || (flags & VILMA_SWEEP_VERBOSE) || s->scale_se) return false;
-    if (!lookahead_enabled()) return false;
-    // the decision kernel needs the responsibility sums of every candidate it may accept
+    (void)c; (void)s;
+    if (!(flags & VILMA_SWEEP_LOOKAHEAD) || (flags & VILMA_SWEEP_VERBOSE)) return false;
+    return lookahead_enabled();
+}
+
+// the trial's own per-SNP pass leaves every candidate's responsibility sums (LDS stash): the TRIAL
+// decision does the M-step itself.  Otherwise (mixtures beyond the stash) a pass over the accepted
+// candidate's vi_mu behind the decision forms them, then an M-step kernel.
+bool stash_sums(const vilma_ctx *c, const SweepState *s) {
+    const char *e = std::getenv("VILMA_PIPE_STASH");        // =0: always the pass behind the decision (A/B)
+    if (e && e[0] == '0') return false;
     return c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, s->two_step ? 2 : 1);
 }
 
@@ -487,7 +528,7 @@ int pipeline_buffers(vilma_ctx *c, SweepState *s) {
     if (c->ctl) return 0;
     if (dev_alloc(c, &c->ctl, 1)) return 1;
     HIPCHK(c, hipHostMalloc((void **)&s->ctl_host, sizeof(SweepCtl), hipHostMallocDefault));
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < SweepState::RING; ++b) {
         HIPCHK(c, hipHostMalloc((void **)&s->land[b], (size_t)(s->size + VILMA_SNAP_EXTRA) * sizeof(double),
                                 hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(s->land[b], 0, (size_t)(s->size + VILMA_SNAP_EXTRA) * sizeof(double));
@@ -500,309 +541,433 @@ BufferBases buffer_bases(const vilma_ctx *c) {
     for (int q = 0; q < 3; ++q) {
         b.mu[q] = c->mu[q]; b.pool[q] = c->pool[q]; b.m[q] = c->m[q]; b.v[q] = c->v[q]; b.lse[q] = c->lse[q];
     }
+    b.snap[0] = c->snap[0]; b.snap[1] = c->snap[1];
     return b;
 }
 
-// [trial, decision, evaluation] of one sweep, all behind the control block
-int queue_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool first = false) {
-    const bool two = s->two_step;
-    const int b = s->slot;
-    s->slot ^= 1;
+SweepDecideParams decide_params(vilma_ctx *c, SweepState *s, int mode, bool veto, bool allow_tau = true) {
+    SweepDecideParams p;
+    const bool two = s->two_step, stash = stash_sums(c, s);
+    p.mode = mode;
+    p.P = c->P; p.A = c->A; p.M = c->M;
+    p.check_convergence = veto ? 1 : 0;
+    p.have_b = two ? 1 : 0;
+    p.have_sums_b = (two && stash) ? 1 : 0;
+    p.mstep_inside = stash ? 1 : 0;
+    p.scale_se = (s->scale_se && allow_tau) ? 1 : 0;
+    p.two_snapshots = 1;
+    p.max_inner = MAX_NUM_ITERS;
+    p.chi = s->chi.data(); p.ranks = s->ranks.data();
+    p.rel_tol = REL_TOL; p.abs_tol = ABS_TOL; p.rate = s->pipe_rate; p.l_max = L_MAX; p.em_tol = EM_TOL;
+    p.ctl = c->ctl; p.results = s->results;
+    p.o_dsum = s->o_dsum; p.o_tot = s->o_tot; p.o_ta = s->o_ta; p.o_tb = s->o_tb;
+    p.o_sa = s->o_sa; p.o_sb = s->o_sb; p.o_hyper = s->o_hyper; p.n_results = s->size;
+    p.lh = c->lh; p.counts = c->counts; p.log_det = c->log_det;
+    p.snap = nullptr; p.serial = 0.0; p.bases = buffer_bases(c);
+    return p;
+}
+
+// one decision behind whatever has been queued; its snapshot goes to the next buffer of the ring
+int queue_decision(vilma_ctx *c, SweepState *s, hipStream_t st, int mode, bool veto,
+                   bool first_of_group, int64_t tag, bool allow_tau = true) {
+    if ((int)s->outq.size() >= SweepState::RING)
+        return fail(c, "internal: more decisions outstanding than snapshot buffers");
+    SweepDecideParams p = decide_params(c, s, mode, veto, allow_tau);
+    const int b = s->next_land;
+    s->next_land = (s->next_land + 1) % SweepState::RING;
+    void *dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, s->land[b], 0) != hipSuccess)
+        return fail(c, "the snapshot buffer is not mapped for the device");
+    s->serial += 1.0;
+    p.snap = (double *)dptr;
+    p.serial = s->serial;
+    launch_sweep_decide(p, st);
+    HIPCHK(c, hipGetLastError());
+    SweepState::Queued q;
+    q.land = b; q.serial = s->serial; q.args = decide_args(p); q.tag = tag;
+    q.first_of_group = first_of_group;
+    s->outq.push_back(q);
+    return 0;
+}
+
+// One group: [trial, all-reduce, TRIAL decision, (sums pass, all-reduce, M-step,) evaluation
+// (, all-reduce, EVAL decision, re-evaluation)], all behind the control block.  `fresh`: the first
+// group behind an arming -- the evaluation in front of it was the host's, its sums are reduced.
+int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fresh) {
+    const bool two = s->two_step, stash = stash_sums(c, s);
+    // profiling brackets of this group: 4 tag (trial), 4 tag + 1 (sums, M-step, evaluation),
+    // 4 tag + 2 (re-evaluation)
+    const int64_t tag = ++s->group_serial;
+    int rc = 0;
+    c->prof_tag = 4 * tag;
     set_launch_predicate(&c->ctl->alive);
-    int rc = queue_trial_phase(c, st, two, s->results + s->o_ta, s->results + s->o_tb,
-                               s->results + s->o_sa, s->results + s->o_sb);
-    // one all-reduce per sweep: the previous evaluation's sums and statistics and this trial's (the
-    // evaluation in front of the FIRST queued sweep was the host's: its sums are reduced already)
+    rc = queue_trial_phase(c, st, two, s->results + s->o_ta, s->results + s->o_tb,
+                           stash ? s->results + s->o_sa : nullptr,
+                           (stash && two) ? s->results + s->o_sb : nullptr);
+    set_launch_predicate(nullptr);
+    // one all-reduce: the evaluation before this trial (sums and statistics), the trial's sums
     if (!rc && s->comm_kind) {
-        const int lo = first ? s->o_ta : s->o_dsum;
-        rc = comm_allreduce(c, s, st, s->results + lo, (two ? s->o_sb + s->am : s->o_sa + s->am) - lo, 0);
+        const int lo = fresh ? s->o_ta : s->o_dsum;
+        const int hi = stash ? (two ? s->o_sb + s->am : s->o_sa + s->am)
+                             : (two ? s->o_tb + s->nt : s->o_ta + s->nt);
+        rc = comm_allreduce(c, s, st, s->results + lo, hi - lo, 0);
+    }
+    if (!rc) rc = queue_decision(c, s, st, VILMA_DECIDE_TRIAL, veto, true, tag);
+    c->prof_tag = 4 * tag + 1;
+    if (!rc && !stash) {
+        set_launch_predicate(&c->ctl->run_eval);
+        rc = queue_sums_phase(c, st, s->results + s->o_sa);
+        set_launch_predicate(nullptr);
+        if (!rc && s->comm_kind) rc = comm_allreduce(c, s, st, s->results + s->o_sa, s->am, 0);
+        set_launch_predicate(&c->ctl->run_eval);
+        if (!rc) rc = queue_mstep(c, st, s->results + s->o_sa, s->results + s->o_hyper);
+        set_launch_predicate(nullptr);
     }
     if (!rc) {
-        SweepDecideParams p;
-        double hrl[VILMA_MAX_P];
-        for (int q = 0; q < c->P; ++q) hrl[q] = 0.5 * s->ranks[q] * std::log(c->tau[q]);
-        p.P = c->P; p.A = c->A; p.M = c->M;
-        p.check_convergence = veto ? 1 : 0; p.have_b = two ? 1 : 0; p.have_sums_b = two ? 1 : 0;
-        p.chi = s->chi.data(); p.tau = c->tau; p.half_rank_log_tau = hrl;
-        p.rel_tol = REL_TOL; p.abs_tol = ABS_TOL; p.rate = s->pipe_rate; p.l_max = L_MAX;
-        p.ctl = c->ctl; p.results = s->results;
-        p.o_dsum = s->o_dsum; p.o_tot = s->o_tot; p.o_ta = s->o_ta; p.o_tb = s->o_tb;
-        p.o_sa = s->o_sa; p.o_sb = s->o_sb; p.o_hyper = s->o_hyper; p.n_results = s->size;
-        p.lh = c->lh; p.counts = c->counts; p.log_det = c->log_det;
-        // the kernel writes its snapshot straight into host memory and stamps it with this serial
-        // number: no copy, no event; the compute stream goes straight on
-        s->serial += 1.0;
-        s->land_serial[b] = s->serial;
-        void *dptr = nullptr;
-        if (hipHostGetDevicePointer(&dptr, s->land[b], 0) != hipSuccess)
-            rc = fail(c, "the snapshot buffer is not mapped for the device");
-        p.snap = (double *)dptr; p.serial = s->serial; p.bases = buffer_bases(c);
-        if (!rc) launch_sweep_decide(p, st);
-        s->pipe_stream = st;
-    }
-    if (!rc) {
-        s->mark_eval[b] = prof_pending(c);
+        set_launch_predicate(&c->ctl->run_eval);
         rc = queue_eval_phase(c, st, s->results + s->o_tot, s->pipe_diff ? s->results + s->o_dsum : nullptr,
                               s->pipe_diff ? s->results + s->o_dmax : nullptr);
+        set_launch_predicate(nullptr);
     }
-    set_launch_predicate(nullptr);
+    if (!rc && s->scale_se) {
+        if (s->comm_kind) rc = comm_allreduce(c, s, st, s->results + s->o_dsum, s->o_tot + s->nt - s->o_dsum, 0);
+        if (!rc) rc = queue_decision(c, s, st, VILMA_DECIDE_EVAL, false, false, tag);
+        c->prof_tag = 4 * tag + 2;
+        if (!rc) {
+            set_launch_predicate(&c->ctl->run_eval2);
+            rc = queue_eval_phase(c, st, s->results + s->o_tot, s->pipe_diff ? s->results + s->o_dsum : nullptr,
+                                  s->pipe_diff ? s->results + s->o_dmax : nullptr);
+            set_launch_predicate(nullptr);
+        }
+    }
+    c->prof_tag = 0;
+    if (!rc) s->groups_out += 1;
+    s->pipe_stream = st;
     return rc;
 }
 
-// Write the host's state into the control block and queue the first sweep behind it.
+// a decision that only looks at the evaluation that has just run (a sweep the caller did not
+// promise to follow with another: nothing else would)
+int queue_eval_decision(vilma_ctx *c, SweepState *s, hipStream_t st) {
+    if (s->comm_kind &&
+        comm_allreduce(c, s, st, s->results + s->o_dsum, s->o_tot + s->nt - s->o_dsum, 0)) return 1;
+    // (no tau update here: with --learn-scaling the group's own EVAL decision has taken that one)
+    return queue_decision(c, s, st, VILMA_DECIDE_EVAL, false, false, 0, /*allow_tau=*/false);
+}
+
+// Write the host's state into the control block; nothing is queued yet.
 int pipeline_arm(vilma_ctx *c, SweepState *s, hipStream_t st, const double *L, double running,
-                 double rate, bool diff, bool veto) {
+                 double rate, bool diff) {
     if (pipeline_buffers(c, s)) return 1;
+    s->pipe_rate = rate;
+    s->pipe_diff = diff;
+    s->pipe_stream = st;
     SweepCtl &k = *s->ctl_host;
     std::memset(&k, 0, sizeof(k));
     k.alive = 1;
     k.running_none = std::isnan(running) ? 1 : 0;
     k.running = std::isnan(running) ? 0.0 : running;
-    k.have_prev = 0;
-    // the trial phase treats the moments of role "ta" as current (the evaluation queued in front
-    // of it is accepted unconditionally); the host's current moments take that place
+    k.snap_cur = c->snap_cur;
+    // the trial phase treats the moments of role 1 as current (phase_ptrs): the host's current
+    // moments take that place
     k.mu_role[0] = c->mu_cur; k.mu_role[1] = c->mu_ta; k.mu_role[2] = c->mu_tb;
     k.mom_role[0] = c->mom_ta; k.mom_role[1] = c->mom_cur; k.mom_role[2] = c->mom_tb;
     k.L0 = L[0];
     k.L_try = std::max(1.0, L[0] / 1.25);
-    const BufferBases bases = buffer_bases(c);
-    phase_ptrs(bases, k.mu_role, k.mom_role, VILMA_PHASE_EVAL, 0.0, 0.0, k.phase[0]);
-    phase_ptrs(bases, k.mu_role, k.mom_role, VILMA_PHASE_TRIAL, 1.0 / k.L_try, 1.0 / (k.L_try * rate),
-               k.phase[1]);
+    k.cur_obj = s->objective;
+    for (int p = 0; p < VILMA_MAX_P; ++p) {
+        k.tau[p] = p < c->P ? c->tau[p] : 1.0;
+        k.hrl[p] = p < c->P ? det_hrl(s->ranks[p], c->tau[p]) : 0.0;
+    }
+    const SweepDecideArgs a = decide_args(decide_params(c, s, VILMA_DECIDE_TRIAL, false));
+    decide_set_phases(a, &k);
     HIPCHK(c, hipMemcpyAsync(c->ctl, &k, sizeof(k), hipMemcpyHostToDevice, st));
-    s->pipe_rate = rate;
-    s->pipe_diff = diff;
-    s->pipe_stream = st;
-    s->slot = 0;
+    s->mirror = k;
+    s->outq.clear();
+    s->groups_out = 0;
     s->armed = true;
-    s->cur_decided = false;
-    s->next_queued = false;
-    s->cur_slot = s->slot;
-    return queue_sweep(c, s, st, veto, /*first=*/true);
+    s->fresh = true;
+    s->carry_trials = s->carry_evals = s->carry_products = 0;
+    // what a drain before the first report has to give back: the state as it stands
+    s->rep_end.valid = true;
+    for (int q = 0; q < 3; ++q) { s->rep_end.mu_role[q] = k.mu_role[q]; s->rep_end.mom_role[q] = k.mom_role[q]; }
+    s->rep_end.snap_cur = k.snap_cur;
+    for (int p = 0; p < VILMA_MAX_P; ++p) s->rep_end.tau[p] = k.tau[p];
+    return 0;
 }
 
-struct Snapshot {
-    const double *r;            // result vector as the decision saw it
-    bool alive;
-    int choice;
-    double L_try, L0, obj_start, obj_beta, running, orig, fa, fb;
-    bool running_none;
-    int mu_role[3], mom_role[3];
-};
-
-int wait_snapshot(vilma_ctx *c, SweepState *s, int b, Snapshot *o) {
-    // poll the serial number the decision kernel writes behind its snapshot
-    volatile double *stamp = s->land[b] + s->size + VILMA_SNAP_EXTRA - 1;
-    const double want = s->land_serial[b];
-    for (uint64_t spins = 0; *stamp != want; ++spins) {
+// Wait for the oldest outstanding decision, replay it on the mirror, check the device's account of
+// it against the replay.  *r = the result vector as that decision saw it.
+int consume_decision(vilma_ctx *c, SweepState *s, DecideReport *rep, const double **r,
+                     SweepState::Queued *which) {
+    if (s->outq.empty()) return fail(c, "internal: no decision outstanding");
+    const SweepState::Queued q = s->outq.front();
+    volatile double *stamp = s->land[q.land] + s->size + SNAP_SERIAL;
+    for (uint64_t spins = 0; *stamp != q.serial; ++spins) {
         __builtin_ia32_pause();
         if ((spins & 0xfffff) == 0xfffff) {
             // a long wait: has the stream died (a failed launch would never write the stamp)?
-            const hipError_t q = hipStreamQuery(s->pipe_stream);
-            if (q != hipSuccess && q != hipErrorNotReady)
-                return fail(c, std::string("the queued sweep failed: ") + hipGetErrorString(q));
-            if (q == hipSuccess && *stamp != want)
+            const hipError_t e = hipStreamQuery(s->pipe_stream);
+            if (e != hipSuccess && e != hipErrorNotReady)
+                return fail(c, std::string("the queued sweep failed: ") + hipGetErrorString(e));
+            if (e == hipSuccess && *stamp != q.serial)
                 return fail(c, "the queued sweep finished without writing its decision");
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    const double *x = s->land[b] + s->size;
-    o->r = s->land[b];
-    o->alive = x[0] != 0.0; o->choice = (int)x[1];
-    o->L_try = x[3]; o->L0 = x[4]; o->obj_start = x[5]; o->obj_beta = x[6];
-    o->running = x[7]; o->running_none = x[8] != 0.0;
-    o->orig = x[9]; o->fa = x[10]; o->fb = x[11];
-    for (int q = 0; q < 3; ++q) { o->mu_role[q] = (int)x[12 + q]; o->mom_role[q] = (int)x[15 + q]; }
+    s->outq.pop_front();
+    if (q.first_of_group) s->groups_out -= 1;
+    const double *snap = s->land[q.land];
+    decide_core(q.args, &s->mirror, snap, *rep);
+    double want[VILMA_SNAP_EXTRA];
+    decide_snapshot_scalars(q.args, &s->mirror, *rep, want);
+    const double *got = snap + s->size;
+    for (int i = 0; i < SNAP_SERIAL; ++i) {
+        const bool same = want[i] == got[i] || (std::isnan(want[i]) && std::isnan(got[i]));
+        if (!same)
+            return fail(c, "device and host decisions disagree (snapshot field " + std::to_string(i) +
+                           ": device " + std::to_string(got[i]) + ", host " + std::to_string(want[i]) + ")");
+    }
+    *r = snap;
+    if (which) *which = q;
     return 0;
 }
 
-// The decision in snapshot `sn` went to the host: everything queued behind it has exited.  Make the
-// host-side roles and caches those of the device (state before the trial, both candidates
-// evaluated) so that the host's line search continues from there.
-int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const Snapshot &sn, int b) {
+// The block is dead (the decision just looked at went to the host): everything queued behind has
+// exited.  Make the host-side roles and caches those of the device so that the host's own line
+// search (nat_grad_step with s->resume) carries on from there.
+int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const DecideReport &rep,
+                      const double *r, const SweepState::Queued &q, bool sweep_ended) {
     HIPCHK(c, hipStreamSynchronize(st));
-    prof_truncate(c, s->mark_eval[b]);              // the brackets of launches that exited at once
-    c->mu_cur = sn.mu_role[0]; c->mu_ta = sn.mu_role[1]; c->mu_tb = sn.mu_role[2];
-    c->mom_cur = sn.mom_role[1]; c->mom_ta = sn.mom_role[0]; c->mom_tb = sn.mom_role[2];
+    // brackets of launches that exited at once: the rest of this group and every later group
+    if (q.tag) prof_drop_tags(c, 4 * q.tag + (q.args.mode == VILMA_DECIDE_TRIAL ? 1 : 2));
+    s->outq.clear();
+    s->groups_out = 0;
+    const SweepCtl &k = s->mirror;
+    c->mu_cur = k.mu_role[0]; c->mu_ta = k.mu_role[1]; c->mu_tb = k.mu_role[2];
+    c->mom_cur = k.mom_role[1]; c->mom_ta = k.mom_role[0]; c->mom_tb = k.mom_role[2];
+    c->snap_cur = k.snap_cur;
+    for (int p = 0; p < c->P; ++p) c->tau[p] = k.tau[p];
     c->have_moments = true;
-    c->have_b = s->two_step;
-    c->tile_sums_ns = s->two_step ? 2 : 1;
     c->snp_marked = false;
     c->trial_tainted = false;
-    // the device copy of the summed part may have gone through the all-reduces of dead sweeps
-    if (s->comm_kind)
-        HIPCHK(c, hipMemcpy(s->results + s->o_dsum, sn.r + s->o_dsum,
-                            (size_t)(s->reduce_end - s->o_dsum) * sizeof(double), hipMemcpyHostToDevice));
-    std::copy(sn.r, sn.r + s->size, s->host.begin());
-    std::copy(sn.r + s->o_tot, sn.r + s->o_tot + s->nt, s->totals.begin());
-    s->hyper.assign(sn.r + s->o_hyper, sn.r + s->o_hyper + s->am);
-    s->objective = objective_from(c, s, s->totals.data());
+    s->objective = k.cur_obj;
     s->cur_sums = -1;
-    s->pend_valid = true;
-    s->pend_step = 1.0 / sn.L_try;
-    s->trial_sums = true;
-    s->trial_sums_b = s->two_step;
-    s->alt_valid = s->two_step;
-    if (s->two_step) {
-        s->alt_step = 1.0 / (sn.L_try * s->pipe_rate);
-        std::copy(sn.r + s->o_tb, sn.r + s->o_tb + s->nt, s->alt_totals.begin());
-        s->alt_obj = objective_from(c, s, s->alt_totals.data());
-    }
     s->armed = false;
-    s->cur_decided = s->next_queued = false;
+    s->resume = SweepState::Resume();
+    const bool trial_pending = q.args.mode == VILMA_DECIDE_TRIAL;
+    if (trial_pending) {
+        // the trial's candidates are evaluated and nobody has used them: the host's line search
+        // starts with them (trial()'s pend / alt caches)
+        const bool stash = q.args.mstep_inside != 0;
+        c->have_b = s->two_step;
+        c->tile_sums_ns = stash ? (s->two_step ? 2 : 1) : 0;
+        // the device copy of the summed part may have gone through the all-reduces of dead groups
+        if (s->comm_kind)
+            HIPCHK(c, hipMemcpy(s->results + s->o_dsum, r + s->o_dsum,
+                                (size_t)(s->reduce_end - s->o_dsum) * sizeof(double), hipMemcpyHostToDevice));
+        std::copy(r, r + s->size, s->host.begin());
+        s->pend_valid = true;
+        s->pend_step = 1.0 / k.L_try;
+        s->trial_sums = stash;
+        s->trial_sums_b = stash && s->two_step;
+        s->alt_valid = s->two_step;
+        if (s->two_step) {
+            s->alt_step = 1.0 / (k.L_try * s->pipe_rate);
+            std::copy(r + s->o_tb, r + s->o_tb + s->nt, s->alt_totals.begin());
+            s->alt_obj = objective_from(c, s, s->alt_totals.data());
+        }
+        if (!sweep_ended) {
+            s->resume.active = true;
+            s->resume.it0 = k.inner_it;
+            s->resume.delta_sum = k.delta_sum;
+            s->resume.L_try = k.L_try;
+        }
+    } else {
+        // an EVAL decision the device would not take (a tau it could not accept): the evaluation has
+        // been looked at; the host goes on behind the M-step
+        c->have_b = false;
+        c->tile_sums_ns = 0;
+        s->pend_valid = s->alt_valid = false;
+        s->trial_sums = s->trial_sums_b = false;
+        s->resume.active = true;
+        s->resume.after_mstep = true;
+        s->resume.delta_sum = k.delta_sum;
+    }
+    (void)rep;
     return 0;
 }
 
-// The caller does not go on with the sweep queued ahead: wait for it and put the state the last
-// reported sweep ended in back (the vi_mu it ended with is still in its buffer; its moments are
-// re-derived by one evaluation).
+// The caller does not go on with what is queued ahead: wait for it and put the state the last
+// reported sweep ended in back (its vi_mu is still in its buffer -- see the invariant above; its
+// moments are re-derived by one evaluation: equal to rounding, not to the bit).
 int pipeline_rollback(vilma_ctx *c, SweepState *s, hipStream_t st) {
     if (!s->armed) return 0;
-    Snapshot sn;
     HIPCHK(c, hipStreamSynchronize(st));
-    // the last decision the device took (or refused)
-    const int b = s->cur_slot;
-    if (wait_snapshot(c, s, b, &sn)) return 1;
-    s->armed = false;
-    if (!sn.alive) {
-        // it went dead at that decision: nothing behind it ran
-        if (pipeline_takeover(c, s, st, sn, b)) return 1;
-        s->pend_valid = false;          // the caller is not going to use the trial
-        s->alt_valid = false;
-        s->trial_sums = s->trial_sums_b = false;
-        return 0;
+    // look at everything outstanding (keeps the mirror and the device's block in step; errors here
+    // are real errors)
+    int64_t first_tag = 0;
+    while (!s->outq.empty()) {
+        DecideReport rep;
+        const double *r;
+        SweepState::Queued q;
+        if (consume_decision(c, s, &rep, &r, &q)) return 1;
+        if (!first_tag) first_tag = q.tag;
     }
-    // the device accepted a candidate and evaluated the state after its M-step: one sweep beyond
-    // what was reported.  The reported state's vi_mu: role ta (candidate A taken) or tb (B).
-    prof_truncate(c, s->mark_eval[b]);
-    const int before = sn.choice == 1 ? sn.mu_role[1] : sn.mu_role[2];
-    const int other1 = sn.mu_role[0], other2 = sn.choice == 1 ? sn.mu_role[2] : sn.mu_role[1];
-    c->mu_cur = before; c->mu_ta = other1; c->mu_tb = other2;
-    c->mom_cur = sn.mom_role[0]; c->mom_ta = sn.mom_role[1]; c->mom_tb = sn.mom_role[2];
+    // their launches' brackets describe work the caller never asked for
+    if (first_tag) prof_drop_tags(c, 4 * first_tag);
+    s->armed = false;
+    s->groups_out = 0;
+    s->pend_valid = s->alt_valid = false;
+    s->trial_sums = s->trial_sums_b = false;
+    s->resume = SweepState::Resume();
+    s->carry_trials = s->carry_evals = s->carry_products = 0;
+    if (!s->rep_end.valid) return fail(c, "internal: nothing to roll back to");
+    const int cur = s->rep_end.mu_role[0];
+    c->mu_cur = cur; c->mu_ta = (cur + 1) % 3; c->mu_tb = (cur + 2) % 3;
+    c->mom_cur = 0; c->mom_ta = 1; c->mom_tb = 2;
+    c->snap_cur = s->rep_end.snap_cur;
+    for (int p = 0; p < c->P; ++p) c->tau[p] = s->rep_end.tau[p];
     c->have_moments = false;
     c->have_b = false;
     c->tile_sums_ns = 0;
     c->snp_marked = false;
-    s->cur_decided = s->next_queued = false;
-    s->pend_valid = s->alt_valid = false;
+    // hyper_delta of the reported state (the host's copy): its table comes out to the same bits
+    // the device's M-step gave it (det_lh)
     if (vilma_set_hyper(c, s->hyper.data())) return 1;
     vilma_sweep_stats *keep = s->stats;
     s->stats = nullptr;
     double obj;
-    int rc = evaluate_current(c, s, st, &obj);
+    const int rc = evaluate_current(c, s, st, &obj);
     s->stats = keep;
     if (rc) return 1;
     std::vector<double> tot(s->host.begin() + s->o_tot, s->host.begin() + s->o_tot + s->nt);
     if (accept(c, s, 0, obj, tot.data())) return 1;
     s->cur_sums = -1;
-    if (s->pipe_diff && vilma_snapshot_mean(c, (void *)st)) return 1;
     return 0;
 }
 
 // One sweep from the control block: see the comment above.  *done = false: the sweep has to be run
-// (or finished) by the host's own line search (the caches say where it stands).
+// (or finished) by the host's own line search (s->resume and the caches say where it stands).
 int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, double *elbo,
                    double *running_delta, double rate, int flags, vilma_sweep_stats *out, bool *done) {
     *done = false;
-    const bool ahead = pipeline_eligible(c, s, flags);
+    const bool promise = pipeline_eligible(c, s, flags);
     const bool diff = (flags & VILMA_SWEEP_DIFF) != 0;
-    if (s->armed && (rate != s->pipe_rate || diff != s->pipe_diff)) {
-        if (pipeline_rollback(c, s, st)) return 1;
+    if (s->armed && (rate != s->pipe_rate || diff != s->pipe_diff || st != s->pipe_stream)) {
+        // (a different stream: what is queued sits on the old one, and nothing orders the two)
+        if (pipeline_rollback(c, s, s->pipe_stream)) return 1;
     }
     if (!s->armed) {
-        if (!ahead || s->pend_valid) return 0;              // host path
-        // (no veto on the first decision: the host has looked at the statistics in front of it)
-        if (pipeline_arm(c, s, st, L, *running_delta, rate, diff, false)) return 1;
+        if (!promise || s->pend_valid || s->resume.active) return 0;          // host path
+        if (pipeline_arm(c, s, st, L, *running_delta, rate, diff)) return 1;
     }
-    // the sweep to report ("this" sweep) is queued; keep one more behind it if the caller promised
-    if (ahead && !s->next_queued) {
-        s->next_slot = s->slot;
-        // its decision sits behind THIS sweep's evaluation: the veto is about this sweep's statistics
-        if (queue_sweep(c, s, st, (flags & VILMA_SWEEP_VETO) != 0)) return 1;
-        s->next_queued = true;
+    const bool veto = (flags & VILMA_SWEEP_VETO) != 0;
+    out->n_trials = s->carry_trials; out->n_evaluations = s->carry_evals; out->n_products = s->carry_products;
+    s->carry_trials = s->carry_evals = s->carry_products = 0;
+    bool ended = false;
+    double change = 0.0, running_after = 0.0, L0_after = L[0];
+    for (;;) {
+        // ---- keep the stream fed without ever queuing a second trial beyond the sweep's end
+        if (s->mirror.eval_pending != 0) {
+            // the beta loop of the sweep being reported is over; its evaluation runs (or has run)
+            if (s->outq.empty()) {
+                if (promise) { if (queue_group(c, s, st, veto, false)) return 1; }
+                else if (queue_eval_decision(c, s, st)) return 1;
+            }
+        } else {
+            const int target = promise ? 2 : 1;
+            while (s->groups_out < target) {
+                if (queue_group(c, s, st, veto, s->fresh)) return 1;
+                s->fresh = false;
+            }
+        }
+        // ---- the oldest outstanding decision
+        DecideReport rep;
+        const double *r;
+        SweepState::Queued q;
+        if (consume_decision(c, s, &rep, &r, &q)) return 1;
+        if (rep.consumed) {
+            // an evaluation of the sweep being reported has been looked at
+            std::copy(r + s->o_tot, r + s->o_tot + s->nt, s->totals.begin());
+            s->hyper.assign(r + s->o_hyper, r + s->o_hyper + s->am);
+            s->objective = rep.eval_obj;
+            out->n_evaluations += 1;
+            out->n_products += 1;
+            if (diff)
+                for (int t = 0; t < 3; ++t) {
+                    out->diff_sum[t] = r[s->o_dsum + t];
+                    out->diff_max[t] = r[s->o_dmax + t];
+                }
+        }
+        if (rep.outcome == VILMA_OUT_TAU_UPDATED)
+            for (int p = 0; p < c->P; ++p) c->tau[p] = s->mirror.tau[p];
+        if (rep.sweep_end) {
+            ended = true;
+            change = rep.sweep_change;
+            running_after = rep.end_running;
+            L0_after = rep.end_L0;
+            for (int t = 0; t < 3; ++t) { s->rep_end.mu_role[t] = rep.end_mu_role[t]; s->rep_end.mom_role[t] = rep.end_mom_role[t]; }
+            s->rep_end.snap_cur = rep.end_snap_cur;
+            for (int p = 0; p < VILMA_MAX_P; ++p) s->rep_end.tau[p] = rep.end_tau[p];
+            s->rep_end.valid = true;
+        }
+        if (q.args.mode == VILMA_DECIDE_TRIAL && rep.L_tried != 0.0) {
+            // the line search looked at one or two candidates; behind a sweep's end they belong to
+            // the next sweep (the next call reports them)
+            const bool both = rep.outcome == VILMA_OUT_REJECTED ? q.args.have_b != 0
+                              : (s->mirror.choice == 2 || (rep.outcome == VILMA_OUT_DEAD && q.args.have_b != 0 &&
+                                                           !(rep.fa >= (rep.orig - REL_TOL * std::fabs(rep.orig)) - ABS_TOL)));
+            if (rep.outcome != VILMA_OUT_DEAD) {
+                const int n = both ? 2 : 1;
+                if (ended) { s->carry_trials += n; s->carry_evals += n; s->carry_products += 1; }
+                else { out->n_trials += n; out->n_evaluations += n; out->n_products += 1; }
+            }
+            // a trial that did not end the beta loop leaves its group's evaluation launches empty
+            if (rep.outcome == VILMA_OUT_ACCEPT_CONTINUE || rep.outcome == VILMA_OUT_REJECTED) {
+                prof_drop_tag(c, 4 * q.tag + 1);
+                prof_drop_tag(c, 4 * q.tag + 2);
+            }
+        } else if (q.args.mode == VILMA_DECIDE_EVAL && q.tag && rep.outcome != VILMA_OUT_TAU_UPDATED) {
+            prof_drop_tag(c, 4 * q.tag + 2);        // the re-evaluation's launches exit at once
+        }
+        if (!s->mirror.alive) {
+            out->skipped_ahead = 1;
+            if (pipeline_takeover(c, s, st, rep, r, q, ended)) return 1;
+            if (!ended) {
+                // the host finishes this sweep: what the device had done of it is in s->resume
+                if (s->resume.active && !s->resume.after_mstep) L[0] = s->resume.L_try;
+                else L[0] = s->mirror.L0;
+                return 0;
+            }
+            break;
+        }
+        if (ended) break;
     }
-    Snapshot sn;
-    if (!s->cur_decided) {
-        if (wait_snapshot(c, s, s->cur_slot, &sn)) return 1;
-        if (!sn.alive) return pipeline_takeover(c, s, st, sn, s->cur_slot);     // host path from here
-        s->cur_orig = sn.orig; s->cur_new = sn.choice == 1 ? sn.fa : sn.fb; s->cur_L0 = sn.L0;
-        s->cur_choice = sn.choice;
-        s->cur_decided = true;
-    }
-    // this sweep's beta step was taken on the device.  The same decision with the host's arithmetic:
-    {
-        const double orig = s->objective;
-        const double nw = s->cur_new;
-        if (!(nw >= orig - REL_TOL * std::fabs(orig) - ABS_TOL) || s->cur_orig != orig)
-            return fail(c, "device and host line-search decisions disagree");
-    }
-    // its evaluation after the M-step: in the next decision's snapshot, or fetched directly
-    const double *r;
-    bool next_dead = false;
-    Snapshot nx;
-    if (s->next_queued) {
-        if (wait_snapshot(c, s, s->next_slot, &nx)) return 1;
-        r = nx.r;
-        next_dead = !nx.alive;
-    } else {
-        // no decision behind it whose all-reduce would cover it: reduce it here
-        if (reduce_and_fetch(c, s, st, diff ? s->o_dsum : s->o_tot, s->o_tot + s->nt, false)) return 1;
-        r = s->host.data();
-    }
-    const double obj_start = s->objective, obj_beta = s->cur_new;
-    std::copy(r + s->o_tot, r + s->o_tot + s->nt, s->totals.begin());
-    s->hyper.assign(r + s->o_hyper, r + s->o_hyper + s->am);
-    s->objective = objective_from(c, s, s->totals.data());
-    // _nat_grad_step's bookkeeping (variational_inference.py:419-450) for a one-step inner loop
-    double change = 0.0;
-    change += obj_beta - obj_start;
-    change += s->objective - obj_beta;
-    double running = std::isnan(*running_delta) ? change : *running_delta;
-    running *= ELBO_MOMENTUM;
-    running += (1 - ELBO_MOMENTUM) * std::max(change, 0.0);
-    L[0] = s->cur_L0;
+    // _optimize_step's bookkeeping (variational_inference.py:403-409), as the device did it
+    L[0] = L0_after;
     L[1] = std::max(1.0, L[1] / 1.25);
     L[2] = std::max(1.0, L[2] / 1.25);
     *elbo = *elbo + change;
-    *running_delta = running;
-    out->n_trials = s->cur_choice == 1 ? 1 : 2;
-    out->n_evaluations = out->n_trials + 1;
-    out->n_products = 2;
+    *running_delta = running_after;
     out->ran_ahead = 1;
-    if (diff)
-        for (int q = 0; q < 3; ++q) {
-            out->diff_sum[q] = r[s->o_dsum + q];
-            out->diff_max[q] = r[s->o_dmax + q];
-        }
     s->have_diff = diff;
     s->cur_sums = -1;
     s->trial_sums = s->trial_sums_b = false;
-    s->alt_valid = false;
-    // advance: the sweep queued behind becomes the one to report
-    if (s->next_queued) {
-        s->cur_slot = s->next_slot;
-        s->next_queued = false;
-        if (next_dead) {
-            out->skipped_ahead = 1;
-            if (pipeline_takeover(c, s, st, nx, s->cur_slot)) return 1;
-        } else {
-            s->cur_orig = nx.orig; s->cur_new = nx.choice == 1 ? nx.fa : nx.fb; s->cur_L0 = nx.L0;
-            s->cur_choice = nx.choice;
-            s->cur_decided = true;
-        }
-    } else {
-        // nothing queued behind: the host-side roles become the device's (after this sweep's
-        // evaluation, which is accepted unconditionally)
-        Snapshot last;
-        if (wait_snapshot(c, s, s->cur_slot, &last)) return 1;
-        c->mu_cur = last.mu_role[0]; c->mu_ta = last.mu_role[1]; c->mu_tb = last.mu_role[2];
-        c->mom_cur = last.mom_role[1]; c->mom_ta = last.mom_role[0]; c->mom_tb = last.mom_role[2];
+    if (s->armed) s->alt_valid = false;
+    if (s->armed && !promise && s->outq.empty() && s->mirror.eval_pending == 0 && s->groups_out == 0) {
+        // nothing queued behind and no promise of another sweep: the host-side roles become the
+        // device's (the sweep's last evaluation is accepted unconditionally)
+        const SweepCtl &k = s->mirror;
+        c->mu_cur = k.mu_role[0]; c->mu_ta = k.mu_role[1]; c->mu_tb = k.mu_role[2];
+        c->mom_cur = k.mom_role[1]; c->mom_ta = k.mom_role[0]; c->mom_tb = k.mom_role[2];
+        c->snap_cur = k.snap_cur;
+        for (int p = 0; p < c->P; ++p) c->tau[p] = k.tau[p];
         c->have_moments = true;
         c->have_b = false;
         c->tile_sums_ns = 0;
         c->snp_marked = false;
         s->armed = false;
-        s->cur_decided = false;
     }
     *done = true;
     return 0;

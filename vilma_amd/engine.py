@@ -512,13 +512,14 @@ class HipEngine:
                                                      C.byref(ms), C.byref(nbytes)))
         return ms.value, nbytes.value
 
-    def stream_pattern(self, chunk_kb, scattered, grid=4096, passes=5):
+    def stream_pattern(self, chunk_kb, scattered, grid=4096, passes=5, writes=0):
         """(milliseconds, bytes) of a bare read of the LD store in chunks of `chunk_kb`, one
         workgroup per chunk, in store order or scattered (vilma_prof_stream_pattern)."""
         ms, nbytes = C.c_double(), C.c_int64()
         self._check(self.lib.vilma_prof_stream_pattern(self.ctx, self._stream(), int(passes),
                                                        int(chunk_kb), 1 if scattered else 0,
-                                                       int(grid), C.byref(ms), C.byref(nbytes)))
+                                                       int(grid), int(writes), C.byref(ms),
+                                                       C.byref(nbytes)))
         return ms.value, nbytes.value
 
     def ld_order(self, order):
