@@ -216,7 +216,16 @@ def test_device_resident_sweeps_equal_host_decided_sweeps(shape, monkeypatch):
     dev = run(True)
     if scale_se:
         assert any(t[3] != (1.0,) * pr['P'] for t in host[0])      # tau did get updated
-    assert dev[0] == host[0]
+    if scale_se:
+        # with --learn-scaling the host-decided path forms the convergence statistics in a pass of
+        # its own (vilma_mean_diff), the queued path inside the sweep's last evaluation: two
+        # summation orders.  The count of moved means is exact either way; the rest to rounding.
+        for d, h in zip(dev[0], host[0]):
+            assert d[0] == h[0] and d[1] == h[1] and d[3] == h[3]
+            assert d[2][0] == h[2][0]
+            np.testing.assert_allclose(d[2], h[2], rtol=1e-12)
+    else:
+        assert dev[0] == host[0]
     assert np.array_equal(dev[1], host[1]) and np.array_equal(dev[2], host[2])
     assert dev[3] == host[3] and host[4] == 0
     # sweeps did run from the control block -- p2_m130 too: a mixture beyond the on-chip stash gets
