@@ -11,8 +11,9 @@ process (profiles/r03r_placement_probe.txt)?  One process, one placement of a C3
      per-workgroup trace of one launch per order -- per-XCD bytes, span and finish time, the tail
      of the launch, the spread of per-workgroup streaming rates, the core clock the workgroups saw;
   4. the same bare reads with the thin stream of small stores ld_sym_kernel makes beside them,
-     and (other builds made by --build-variants: VILMA_HIP_LIB=.../libvilma_hip_nostore.so,
-     ..._ntstore.so) ld_sym_kernel without its stores / with non-temporal stores.
+     and (other builds made by --build-variants, VILMA_HIP_LIB=.../libvilma_hip_<variant>.so)
+     ld_sym_kernel without its stores, with the plain stores of rounds 1 - 3, non-temporal, staged
+     but plain, write-through but not staged (the product stages AND writes through).
 
     python profiles/ld_levels_probe.py [--iters 20] [--workload C3]
 """
@@ -117,18 +118,20 @@ def main():
     ap.add_argument('--shard', type=int, default=1)
     ap.add_argument('--build-variants', action='store_true',
                     help='only build the diagnostic variants of the library next to it and exit: '
-                         'libvilma_hip_trace.so (-DLD_TRACE=1), _nostore.so (-DLD_STORE_MODE=1: '
-                         'wrong results, timing only), _ntstore.so (-DLD_STORE_MODE=2), '
-                         '_ldsstage.so (-DLD_STORE_MODE=3)')
+                         'libvilma_hip_trace.so (-DLD_TRACE=1) and the LD_STORE_MODE builds of '
+                         'kernels.hip: _nostore (1: wrong results, timing only), _plainstore (2: '
+                         'rounds 1 - 3), _ntstore (3), _stagedplain (4), _sc1store (5)')
     args = ap.parse_args()
     if args.build_variants:
         from concurrent.futures import ThreadPoolExecutor
         from vilma_amd import build
         jobs = [(['-DLD_TRACE=1'], TRACE_LIB),
                 (['-DLD_STORE_MODE=1'], TRACE_LIB.replace('_trace', '_nostore')),
-                (['-DLD_STORE_MODE=2'], TRACE_LIB.replace('_trace', '_ntstore')),
-                (['-DLD_STORE_MODE=3'], TRACE_LIB.replace('_trace', '_ldsstage'))]
-        with ThreadPoolExecutor(max_workers=4) as pool:
+                (['-DLD_STORE_MODE=2'], TRACE_LIB.replace('_trace', '_plainstore')),
+                (['-DLD_STORE_MODE=3'], TRACE_LIB.replace('_trace', '_ntstore')),
+                (['-DLD_STORE_MODE=4'], TRACE_LIB.replace('_trace', '_stagedplain')),
+                (['-DLD_STORE_MODE=5'], TRACE_LIB.replace('_trace', '_sc1store'))]
+        with ThreadPoolExecutor(max_workers=6) as pool:
             list(pool.map(lambda j: build.build_library(extra_flags=j[0], out=j[1], verbose=False), jobs))
         return
     import torch
@@ -152,6 +155,7 @@ def main():
                               (3, 'whole lines'), (4, 'half the bytes'),
                               (5, '4 KiB / WG / 512 KB'), (6, 'all at the WG end'),
                               (7, '4 KiB / WG, time order'), (8, '64 B / wave, time order'),
+                              (9, '64 B / wave, sc1'), (10, '4 KiB / WG, sc1'),
                               (0, 'none')):
             ms, nb = eng.stream_pattern(chunk_kb, scattered, grid, writes=writes)
             print('  chunk %5d KB  %-9s  grid %5d  stores %-24s: %.3f ms = %.0f GB/s'

@@ -363,6 +363,7 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
     a.pool_out = c->pool[tr]; a.m_out = c->m[tr]; a.v_out = c->v[tr]; a.lse_out = c->lse[tr];
     a.partials = c->snp_partials;
     a.pp = nullptr;
+    a.g_out = c->gbuf; a.no_store = 0;
     a.lse_ref = c->have_moments ? c->lse[cur] : nullptr;
     a.sum_partials = nullptr;
     a.scal = c->scal; a.snapshot = c->snap[c->snap_cur]; a.snapshot_out = c->snap[c->snap_cur];
@@ -375,6 +376,7 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
 void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out, int trial_mu = 0, int trial_mom = 0) {
     a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
     a.pp = nullptr;
+    a.mat = 0; a.mu_mat = nullptr; a.g = nullptr; a.step = 0.0;
     a.mu = c->mu[trial_mu == 2 ? c->mu_tb : trial_mu == 1 ? c->mu_ta : c->mu_cur];
     a.sld = c->sld; a.annot = c->annot;
     a.prec = c->prec; a.log_det = c->log_det; a.lh = c->lh;
@@ -415,7 +417,8 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     a.diff = (!blend && dsum_dev && dmax_dev) ? 1 : 0;
     // a beta trial also leaves the per-tile responsibility sums of its candidates (vilma_trial_sums)
     const int ns = two ? 2 : 1;
-    const bool stash = blend && c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, ns);
+    a.no_store = (blend && queued && c->lazy_trial) ? 1 : 0;
+    const bool stash = blend && !a.no_store && c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, ns);
     if (stash) a.sum_partials = c->sum_partials;
     if (sums_a_dev && !stash) return fail(c, "this trial cannot deliver the responsibility sums");
     if (!queued) c->tile_sums_ns = stash ? ns : 0;
@@ -478,7 +481,8 @@ int vilma_detail::queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, 
 int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev) {
     DeltaArgs a;
     fill_delta_args(c, a, c->delta_partials);
-    set_launch_phase(&c->ctl->phase[VILMA_PHASE_EVAL]);
+    a.mat = c->lazy_trial ? 1 : 0;       // behind a lazy trial the pass also stores the candidate
+    set_launch_phase(&c->ctl->phase[VILMA_PHASE_SUMS]);
     launch_delta_sums(a, sums_dev, s);
     set_launch_phase(nullptr);
     HIPCHK(c, hipGetLastError());
@@ -541,6 +545,8 @@ __global__ __launch_bounds__(256) void store_stream_kernel(const probe_v2d *__re
 //      IN TIME of the chunks (chunk c of the grid-stride loop -> record c) instead of where the
 //      chunk lies in the store: workgroups that run side by side write side by side
 //   8  as 1 (64 B per wave per 8 KiB), addressed as 7
+//   9  as 1 with write-through stores (sc1: the line does not stay dirty in L2)
+//  10  as 5 (4 KiB per workgroup per 512 KB) with write-through stores
 __global__ __launch_bounds__(256) void store_pattern_kernel(const probe_v2d *__restrict__ p,
                                                             int64_t n_chunks, int steps,
                                                             int64_t mult, double *sink, int writes,
@@ -561,15 +567,20 @@ __global__ __launch_bounds__(256) void store_pattern_kernel(const probe_v2d *__r
             for (int u = 0; u < 8; ++u) part += t[u].x + t[u].y;
             acc += part;
             const int64_t gstep = src * steps + st;         // this 32-KB step of the store
-            if ((writes == 1 || writes == 2 || (writes == 4 && (st & 1) == 0)) && (lane & 7) == 0) {
+            if ((writes == 1 || writes == 2 || writes == 9 || (writes == 4 && (st & 1) == 0)) && (lane & 7) == 0) {
                 double *dst = wbuf + (gstep * 4 + w) * 8 + (lane >> 3);     // [step][wave][8]
                 if (writes == 2) __builtin_nontemporal_store(part, dst);
+                else if (writes == 9) __hip_atomic_store(dst, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *dst = part;
             } else if (writes == 3 && (st & 1) == 0 && lane < 16) {
                 wbuf[(gstep * 4 + w) * 8 + lane] = part;                    // 16 doubles = a line
             } else if (writes == 5 && (done & 15) == 15) {
                 probe_v2d *dst = (probe_v2d *)(wbuf + (gstep - 15) * 32) + threadIdx.x;     // 4 KiB
                 *dst = probe_v2d{part, acc};
+            } else if (writes == 10 && (done & 15) == 15) {
+                double *dst = wbuf + (gstep - 15) * 32 + 2 * threadIdx.x;
+                __hip_atomic_store(dst, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (writes == 7 && (done & 15) == 15) {
                 probe_v2d *dst = (probe_v2d *)(wbuf + ((ch * steps + st) - 15) * 32) + threadIdx.x;
                 *dst = probe_v2d{part, acc};
@@ -622,6 +633,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         rc |= dev_alloc(c, &c->m[s], PN); rc |= dev_alloc(c, &c->v[s], PN);
         rc |= dev_alloc(c, &c->lse[s], N);
     }
+    rc |= dev_alloc(c, &c->gbuf, PN);
     rc |= dev_alloc(c, &c->snap[0], PN);
     rc |= dev_alloc(c, &c->snap[1], PN);
     rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_tile_grid(N) * (2 * (2 * P + 2) + 6));
@@ -658,7 +670,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     }
     if (const char *cr = std::getenv("VILMA_LD_CHUNK_ROWS")) {
         const int v = std::atoi(cr);
-        if (v >= 128) c->chunk_rows = (v + 31) / 32 * 32;
+        if (v >= 128) c->chunk_rows = std::min((v + 31) / 32 * 32, 512);    // LD_MAX_CHUNK_ROWS (kernels.hip)
     }
     // VILMA_OVERLAP=0 keeps everything on the caller's stream (A/B measurements)
     const char *ov = std::getenv("VILMA_OVERLAP");
@@ -698,7 +710,7 @@ void vilma_destroy(vilma_ctx *c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
                     c->lh, c->counts, c->sum_partials, c->mu[0], c->mu[1], c->mu[2], c->m[0], c->m[1], c->m[2], c->v[0],
-                    c->v[1], c->v[2], c->lse[0], c->lse[1], c->lse[2], c->snap[0], c->snap[1], c->snp_partials, c->delta_partials, c->diff_partials};
+                    c->v[1], c->v[2], c->lse[0], c->lse[1], c->lse[2], c->snap[0], c->snap[1], c->gbuf, c->snp_partials, c->delta_partials, c->diff_partials};
     for (void *p : ptrs) dev_free(p);
     delete c;
 }

@@ -151,6 +151,8 @@ struct vilma_ctx {
     // (an error-scaling re-evaluation in the same sweep must compare with the same old means)
     double *snap[2] = {nullptr, nullptr};
     int snap_cur = 0;
+    double *gbuf = nullptr;         // [P][N]: the natural gradient a lazy trial leaves (kernels.h)
+    bool lazy_trial = false;        // the trials being queued store no vi_mu (set by sweep.hip)
     double *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;
     std::vector<int32_t> dot_start;     // first y.z partial slot of each cohort (+ end)

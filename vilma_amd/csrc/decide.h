@@ -12,7 +12,7 @@ struct SweepDecideArgs {
     int32_t mode, P, A, M;
     int32_t check_convergence;       // veto when dsum[0] == 0
     int32_t have_b, have_sums_b;     // candidate B evaluated / its responsibility sums available
-    int32_t mstep_inside, scale_se, two_snapshots, max_inner;
+    int32_t mstep_inside, lazy, scale_se, two_snapshots, max_inner;
     double chi[VILMA_MAX_P], ranks[VILMA_MAX_P];
     double rel_tol, abs_tol, rate, l_max, em_tol;
     SweepCtl *ctl;
@@ -30,7 +30,8 @@ static inline SweepDecideArgs decide_args(const SweepDecideParams &p) {
     SweepDecideArgs a;
     a.mode = p.mode; a.P = p.P; a.A = p.A; a.M = p.M;
     a.check_convergence = p.check_convergence; a.have_b = p.have_b; a.have_sums_b = p.have_sums_b;
-    a.mstep_inside = p.mstep_inside; a.scale_se = p.scale_se; a.two_snapshots = p.two_snapshots;
+    a.mstep_inside = p.mstep_inside; a.lazy = p.lazy; a.scale_se = p.scale_se;
+    a.two_snapshots = p.two_snapshots;
     a.max_inner = p.max_inner;
     for (int q = 0; q < VILMA_MAX_P; ++q) {
         a.chi[q] = q < p.P ? p.chi[q] : 0.0;
@@ -64,6 +65,8 @@ static __host__ __device__ inline void decide_set_phases(const SweepDecideArgs &
     phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_TRIAL, s1, s2, ctl->phase[1]);
     set_phase_extras(a.bases, ctl->snap_cur, a.two_snapshots != 0, ctl->tau, ctl->phase[0]);
     set_phase_extras(a.bases, ctl->snap_cur, a.two_snapshots != 0, ctl->tau, ctl->phase[1]);
+    // the sums pass works on the state the evaluation starts from (a lazy accept overrides this)
+    ctl->phase[VILMA_PHASE_SUMS] = ctl->phase[VILMA_PHASE_EVAL];
 }
 
 static __host__ __device__ inline double decide_abs(double x) { return x < 0.0 ? -x : x; }
@@ -146,6 +149,10 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
     // ---- (2) the line search on the trial's candidates
     if (a.mode == VILMA_DECIDE_TRIAL && !dead) {
         ctl->run_eval2 = 0;
+        ctl->run_sums = 0;
+        int32_t lazy_uc = 0, lazy_ua = 0, lazy_macc = 0;
+        double lazy_step = 0.0;
+        bool lazy_accept = false;
         rep.orig = ctl->cur_obj;
         rep.fa = det_objective(P, a.chi, ctl->tau, ctl->hrl, results + a.o_ta);
         rep.fb = a.have_b ? det_objective(P, a.chi, ctl->tau, ctl->hrl, results + a.o_tb) : 0.0;
@@ -191,7 +198,12 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                 // vilma_accept's bookkeeping: the accepted candidate's vi_mu becomes current
                 const int32_t mc = ctl->mom_role[0], ma = ctl->mom_role[1], mb = ctl->mom_role[2];
                 const int32_t uc = ctl->mu_role[0], ua = ctl->mu_role[1], ub = ctl->mu_role[2];
-                if (choice == 1) {
+                // (lazy trials stored nothing: the sums pass behind this decision writes the
+                // accepted candidate, A or B alike, into role ua)
+                const double step_acc = choice == 1 ? ctl->phase[VILMA_PHASE_TRIAL].step
+                                                    : ctl->phase[VILMA_PHASE_TRIAL].step2;
+                const int32_t macc = choice == 1 ? mc : mb;        // the accepted candidate's moments
+                if (choice == 1 || a.lazy) {
                     ctl->mu_role[0] = ua; ctl->mu_role[1] = uc; ctl->mu_role[2] = ub;
                 } else {
                     ctl->mu_role[0] = ub; ctl->mu_role[1] = ua; ctl->mu_role[2] = uc;
@@ -213,10 +225,24 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                     ctl->run_eval = 0;
                     rep.outcome = VILMA_OUT_ACCEPT_CONTINUE;
                 }
+                ctl->run_sums = (!a.mstep_inside && (ends || a.lazy)) ? 1 : 0;
+                lazy_uc = uc; lazy_ua = ua; lazy_macc = macc; lazy_step = step_acc;
+                lazy_accept = a.lazy != 0;
                 double Lnext = Lacc / 1.25;
                 Lnext = Lnext > 1.0 ? Lnext : 1.0;
                 ctl->L_try = Lnext;
                 decide_set_phases(a, ctl);
+                if (lazy_accept) {
+                    // the sums pass re-derives the accepted candidate from the state the trial
+                    // started from and the trial's natural gradient, and writes it where the roles
+                    // above already say the current vi_mu is
+                    PhasePtrs &sp = ctl->phase[VILMA_PHASE_SUMS];
+                    sp.mu_in = a.bases.mu[lazy_uc];
+                    sp.mu_mat = a.bases.mu[lazy_ua];
+                    sp.g_pend = a.bases.g;
+                    sp.step_pend = lazy_step;
+                    sp.lse_ref = a.bases.lse[lazy_macc];
+                }
             }
         }
         ctl->choice = (rep.outcome == VILMA_OUT_ACCEPT_MSTEP ||
@@ -226,6 +252,7 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
         ctl->alive = 0;
         ctl->run_eval = 0;
         ctl->run_eval2 = 0;
+        ctl->run_sums = 0;
         rep.outcome = VILMA_OUT_DEAD;
         rep.mstep = 0;
     }
@@ -247,6 +274,7 @@ static __host__ __device__ inline void decide_snapshot_scalars(const SweepDecide
     x[SNAP_SWEEP_CHANGE] = rep.sweep_change; x[SNAP_L_TRIED] = rep.L_tried;
     x[SNAP_SNAP_CUR] = (double)ctl->snap_cur; x[SNAP_RUN_EVAL] = (double)ctl->run_eval;
     x[SNAP_RUN_EVAL2] = (double)ctl->run_eval2; x[SNAP_EVAL_PENDING] = (double)ctl->eval_pending;
+    x[SNAP_RUN_SUMS] = (double)ctl->run_sums;
     for (int q = 0; q < 3; ++q) {
         x[SNAP_MU_ROLE + q] = (double)ctl->mu_role[q];
         x[SNAP_MOM_ROLE + q] = (double)ctl->mom_role[q];

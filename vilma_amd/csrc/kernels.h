@@ -107,15 +107,28 @@ struct PhasePtrs {
     double *snap_out;
     double step, step2;
     double tau[VILMA_MAX_P];            // error_scaling in force (the device may have updated it)
+    // "lazy" trials (mixtures beyond the on-chip stash, see SnpKernelArgs::g_out): the trial leaves
+    // its natural gradient g [P][N] instead of the candidates' vi_mu; the pass that forms the
+    // accepted candidate's responsibility sums re-derives that candidate from (mu_in, g_pend,
+    // step_pend) and writes it to mu_mat -- one vi_mu array written per accepted update instead
+    // of two per trial
+    double *mu_mat;                     // SUMS phase: where the accepted candidate's vi_mu goes, or nullptr
+    const double *g_pend;               // ... the trial's natural gradient
+    double step_pend;                   // ... the accepted step
+    double *g_out;                      // TRIAL phase: where a lazy trial leaves its natural gradient
 };
 #define VILMA_PHASE_EVAL 0      // an evaluation of the current vi_mu (after the M-step / a tau update)
 #define VILMA_PHASE_TRIAL 1     // a beta trial from the current state
+#define VILMA_PHASE_SUMS 2      // responsibility sums of the candidate a TRIAL decision accepted
+                                // (mixtures beyond the stash), materialising it after a lazy trial
 struct SweepCtl {
     int32_t alive;              // 0: every kernel queued under this block exits at once
     int32_t run_eval;           // the evaluation queued behind the last TRIAL decision runs (that
                                 // decision ended the sweep's beta loop and did the M-step)
     int32_t run_eval2;          // the re-evaluation queued behind the last EVAL decision runs (that
                                 // decision updated the error scaling)
+    int32_t run_sums;           // the sums pass queued behind the last TRIAL decision runs (mixtures
+                                // beyond the stash: that decision accepted a candidate)
     int32_t choice;             // last trial decision: 1 = candidate A accepted, 2 = B, 0 = neither
     int32_t stage;              // decisions taken since the block was armed
     int32_t running_none;       // running ELBO change not defined yet (first sweep)
@@ -123,7 +136,6 @@ struct SweepCtl {
                                 // 1 = the one after the M-step, 2 = the one after a tau update
     int32_t inner_it;           // beta updates accepted so far in the sweep in progress
     int32_t snap_cur;           // which of the two snapshot buffers holds the last completed sweep's means
-    int32_t pad;
     int32_t mu_role[3], mom_role[3];    // buffer indices in the roles current / candidate A / B
     double L_try;               // L[0] of the next (or just evaluated) trial's candidate A (B: L_try * rate)
     double L0;                  // L[0] after the last accepted line search
@@ -132,10 +144,10 @@ struct SweepCtl {
     double running;             // running ELBO change as of the start of the sweep in progress
     double tau[VILMA_MAX_P];    // error_scaling in force
     double hrl[VILMA_MAX_P];    // 0.5 * ld_rank * log(tau) (det_log: the host gets the same bits)
-    PhasePtrs phase[2];
+    PhasePtrs phase[3];
 };
-// base pointers of the three buffers of each kind, and the two snapshot buffers
-struct BufferBases { double *mu[3], *pool[3], *m[3], *v[3], *lse[3], *snap[2]; };
+// base pointers of the three buffers of each kind, the two snapshot buffers, the gradient buffer
+struct BufferBases { double *mu[3], *pool[3], *m[3], *v[3], *lse[3], *snap[2], *g; };
 // The pointers of a phase from the roles at the start of its stage (cur, ta, tb).  The
 // evaluation reads the current vi_mu and writes the moments of role ta; the trial that follows
 // treats those as current (the evaluation is accepted unconditionally), writes candidate A into
@@ -161,6 +173,7 @@ static __host__ __device__ inline void set_phase_extras(const BufferBases &b, in
     o.snap_in = b.snap[snap_cur];
     o.snap_out = b.snap[two_snapshots ? 1 - snap_cur : snap_cur];
     for (int p = 0; p < VILMA_MAX_P; ++p) o.tau[p] = tau[p];
+    o.mu_mat = nullptr; o.g_pend = nullptr; o.step_pend = 0.0; o.g_out = b.g;
 }
 // launch attribute of the calling thread like set_launch_predicate: kernels launched while it is
 // set work on *pp's buffers (read on the device when the kernel starts); nullptr = their arguments
@@ -196,6 +209,12 @@ struct SnpKernelArgs {
     // per-tile responsibility sums [candidate][tile][A*M] of the candidates (nullptr: not wanted)
     double *sum_partials;
     TauArg tau;
+    // a LAZY beta trial (no_store != 0; launch_snp_pass without the stash only): the candidates'
+    // vi_mu are not stored -- every candidate is mu(s) = Sig_k (s g + (1 - s) Lam_k mu_k), so the
+    // natural gradient g [P][N] (written to g_out) and the accepted step describe it -- and the pass
+    // that needs the accepted one re-derives it (DeltaArgs::mat)
+    double *g_out;
+    int32_t no_store;
     const int *pred;          // filled by the launcher (set_launch_predicate)
     const PhasePtrs *pp;      // filled by the launcher (set_launch_phase)
 };
@@ -280,6 +299,13 @@ struct DeltaArgs {
     const int32_t *annot;
     const double *prec, *log_det, *lh;
     const double *lse;        // [N]
+    // mat != 0: `mu` is the state a lazy trial started from; the state whose sums are wanted is the
+    // candidate mu_k' = Sig_k (step g + (1 - step) Lam_k mu_k), which is also written to mu_mat
+    // (with pp non-null: PhasePtrs::mu_mat / g_pend / step_pend)
+    int32_t mat;
+    double *mu_mat;           // [M][P][N]
+    const double *g;          // [P][N]
+    double step;
     double *out;              // mode 0: partial rows [grid*4][A*M]; mode 1: delta [M][N]
     TauArg tau;
     const int *pred;          // filled by the launcher (set_launch_predicate)
@@ -325,15 +351,15 @@ void launch_mean_diff(const double *m_cur, const double *scalings, double *snaps
 int mean_diff_grid(int64_t PN);
 
 // ---- device-resident sweep: the decision kernel (see kernels.hip) ----
-#define VILMA_SNAP_EXTRA 48     // scalars of the control block behind the result vector in a
+#define VILMA_SNAP_EXTRA 56     // scalars of the control block behind the result vector in a
                                 // snapshot; the last one is the serial number that completes it
 // what a decision reports in its snapshot (offsets behind the result vector)
 enum {
     SNAP_ALIVE = 0, SNAP_KIND, SNAP_OUTCOME, SNAP_STAGE, SNAP_CHOICE, SNAP_L_TRY, SNAP_L0,
     SNAP_CUR_OBJ, SNAP_DELTA_SUM, SNAP_RUNNING, SNAP_RUNNING_NONE, SNAP_INNER_IT, SNAP_ORIG,
     SNAP_FA, SNAP_FB, SNAP_EVAL_OBJ, SNAP_CONSUMED, SNAP_SWEEP_END, SNAP_SWEEP_CHANGE,
-    SNAP_L_TRIED, SNAP_SNAP_CUR, SNAP_RUN_EVAL, SNAP_RUN_EVAL2, SNAP_EVAL_PENDING,
-    SNAP_MU_ROLE = 24, SNAP_MOM_ROLE = 27, SNAP_TAU = 30, SNAP_HRL = 38,
+    SNAP_L_TRIED, SNAP_SNAP_CUR, SNAP_RUN_EVAL, SNAP_RUN_EVAL2, SNAP_EVAL_PENDING, SNAP_RUN_SUMS,
+    SNAP_MU_ROLE = 26, SNAP_MOM_ROLE = 29, SNAP_TAU = 32, SNAP_HRL = 40,
     SNAP_SERIAL = VILMA_SNAP_EXTRA - 1
 };
 #define VILMA_DECIDE_TRIAL 0    // behind a beta trial (and the evaluation in front of it, if one ran)
@@ -352,6 +378,8 @@ struct SweepDecideParams {
     int check_convergence, have_b, have_sums_b;
     int mstep_inside;               // the TRIAL decision does the M-step itself (the accepted
                                     // candidate's responsibility sums are in the result vector)
+    int lazy;                       // the trials store no vi_mu: the sums pass behind an accepting
+                                    // decision materialises the accepted candidate
     int scale_se;                   // an EVAL decision may update tau
     int two_snapshots;              // evaluations write their means to the other snapshot buffer
     int max_inner;                  // MAX_NUM_ITERS

@@ -74,19 +74,30 @@ typedef const v2d __attribute__((address_space(1))) *gd2_ptr;
 #else
 #define LD_STREAM_LOAD(p) (*(gd2_ptr)(p))
 #endif
-// -DLD_STORE_MODE=k, diagnostic builds only (profiles/ld_levels_probe.py): how ld_sym_kernel's
-// partial sums leave the workgroup.  0 = plain stores (the product); 1 = NO stores (results are
-// wrong: timing only); 2 = non-temporal stores; 3 = row sums staged in LDS and written out, whole
-// and contiguous, when the workgroup has finished streaming its chunk.
+// How ld_sym_kernel's partial sums leave the workgroup.  They are 0.8 % of the bytes the kernel
+// reads (55 MB beside 6.4 GB at C3) and cost it 8 - 12 % when written the obvious way: a thin stream
+// of small plain stores beside a read stream that saturates HBM (profiles/r04a_ld_levels_probe.txt:
+// without the stores the kernel reads at the bare read's rate; a bare read with the same stores
+// beside it slows down as much).  What helps is to write each chunk's row sums ONCE, whole, when
+// the workgroup has finished streaming (staged in LDS meanwhile), with write-through stores (sc1:
+// the lines do not linger dirty in L2 until the read stream evicts them): 1.03 -> 0.92 - 1.00 ms per
+// launch at C3 (profiles/r04c_ld_partial_stores.txt; either half alone buys nothing).
+// -DLD_STORE_MODE=k makes diagnostic builds (profiles/ld_levels_probe.py --build-variants):
+// 1 = NO stores (results wrong: timing only); 2 = plain stores as they come (rounds 1 - 3);
+// 3 = 2 non-temporal; 4 = staged, plain stores; 5 = as they come, write-through.
 #ifndef LD_STORE_MODE
 #define LD_STORE_MODE 0
 #endif
+#define LD_STAGED (LD_STORE_MODE == 0 || LD_STORE_MODE == 4)
+#define LD_MAX_CHUNK_ROWS 512       // rows of a work item (vilma_ctx::chunk_rows is capped at this)
 #if LD_STORE_MODE == 1
 #define LD_PARTIAL_STORE(p, v) do { if ((v) == 1.2345e300) *(p) = (v); } while (0)
-#elif LD_STORE_MODE == 2
+#elif LD_STORE_MODE == 2 || LD_STORE_MODE == 4
+#define LD_PARTIAL_STORE(p, v) (*(p) = (v))
+#elif LD_STORE_MODE == 3
 #define LD_PARTIAL_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #else
-#define LD_PARTIAL_STORE(p, v) (*(p) = (v))
+#define LD_PARTIAL_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 // Wave-uniform reads of the small per-component tables (mixture precisions, log-weights): through
 // the constant address space the compiler may use scalar loads (SGPR results, scalar cache) even
@@ -318,7 +329,11 @@ static __device__ __forceinline__ void sym_group(const v2d (&v)[CS_ROWS], const 
     int rsub;
     const double t1 = sym_rowsum8(p, lane, rsub);
     const int rr = r0 + rsub;
+#if LD_STAGED
+    if ((lane & 7) == 0 && (FULL || rr < rows)) srow[rr] = t1;          // into the LDS stage
+#else
     if ((lane & 7) == 0 && (FULL || rr < rows)) LD_PARTIAL_STORE(&srow[rr], t1);
+#endif
 }
 
 // one group of 8 rows INSIDE the diagonal tile (row r, column c of the tile): only the lower
@@ -394,8 +409,8 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
     int64_t s_stride, const int *pred, const PhasePtrs *pp) {
     __shared__ double red[NR][CS_WAVES][128];
     __shared__ double rs_diag[NR][128];
-#if LD_STORE_MODE == 3
-    __shared__ double rs_stage[NR][512];
+#if LD_STAGED
+    __shared__ double rs_stage[NR][LD_MAX_CHUNK_ROWS];
 #endif
     PRED_EXIT(pred);
 #if LD_TRACE
@@ -422,8 +437,8 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
         // x of this lane's two columns (the slab's columns are rows j0.. of the same vector)
         xs0[r] = active ? xcol[cl] : 0.0;
         xs1[r] = (cl + 1 < it.w) ? xcol[cl + 1] : 0.0;
-#if LD_STORE_MODE == 3
-        srow[r] = it.rows <= 512 ? rs_stage[r] : scratch + r * s_stride + it.s_off + it.j0 + it.r0;
+#if LD_STAGED
+        srow[r] = rs_stage[r];          // this chunk's row sums, written out whole at the end
 #else
         srow[r] = scratch + r * s_stride + it.s_off + it.j0 + it.r0;
 #endif
@@ -509,13 +524,13 @@ __global__ __launch_bounds__(CS_WAVES * 64) void ld_sym_kernel(
         red[r][w][2 * lane + 1] = acc1[r];
     }
     __syncthreads();
-#if LD_STORE_MODE == 3
-    if (rows <= 512) {
+#if LD_STAGED
+    // the rows below the diagonal tile (its own row sums went into rs_diag)
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            double *dst = scratch + r * s_stride + it.s_off + it.j0 + it.r0;
-            for (int t = ndiag * CS_ROWS + (int)threadIdx.x; t < rows; t += CS_WAVES * 64) dst[t] = rs_stage[r][t];
-        }
+    for (int r = 0; r < NR; ++r) {
+        double *dst = scratch + r * s_stride + it.s_off + it.j0 + it.r0;
+        for (int t = ndiag * CS_ROWS + (int)threadIdx.x; t < rows; t += CS_WAVES * 64)
+            LD_PARTIAL_STORE(&dst[t], rs_stage[r][t]);
     }
 #endif
     if ((int)threadIdx.x < it.w) {
@@ -868,8 +883,9 @@ static __device__ __forceinline__ void eig_fused_body(
 #pragma unroll
         for (int i = 0; i < H; ++i) {
             const int row = row0 + 512 * i;
-            if (row < n) so[row] = y[r][2 * i];
-            if (row + 1 < n) so[row + 1] = y[r][2 * i + 1];
+            // (write-through, like ld_sym_kernel's partial sums: see LD_PARTIAL_STORE)
+            if (row < n) LD_PARTIAL_STORE(&so[row], y[r][2 * i]);
+            if (row + 1 < n) LD_PARTIAL_STORE(&so[row + 1], y[r][2 * i + 1]);
         }
     }
 }
@@ -971,8 +987,8 @@ static __device__ __forceinline__ void eig_wave_body(const EigItem &it, const Po
 #pragma unroll
         for (int i = 0; i < H; ++i) {
             const int row = row0 + 128 * i;
-            if (row < n) so[row] = y[r][2 * i];
-            if (row + 1 < n) so[row + 1] = y[r][2 * i + 1];
+            if (row < n) LD_PARTIAL_STORE(&so[row], y[r][2 * i]);
+            if (row + 1 < n) LD_PARTIAL_STORE(&so[row + 1], y[r][2 * i + 1]);
         }
     }
 }
@@ -1287,9 +1303,10 @@ static __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH>
+template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH, bool NOSTORE = false>
 __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel(const SnpKernelArgs a) {
     static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
+    static_assert(!NOSTORE || (BLEND && !STASH), "lazy trials are the no-stash trials");
     constexpr int NT = 2 * P + 2;
     constexpr int NTP = (NT + 7) / 8 * 8;
     constexpr int NACC = 2 + 2 * P;
@@ -1307,6 +1324,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         q.pool_out2 = t->pool_out2; q.m_out2 = t->m_out2; q.v_out2 = t->v_out2; q.lse_out2 = t->lse_out2;
         q.step = t->step; q.step2 = t->step2;
         q.snap_in = t->snap_in; q.snap_out = t->snap_out;
+        q.g_out = t->g_out;
 #pragma unroll
         for (int p = 0; p < P; ++p) q.tau[p] = t->tau[p];
     } else {
@@ -1316,6 +1334,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         q.pool_out2 = a.pool_out2; q.m_out2 = a.m_out2; q.v_out2 = a.v_out2; q.lse_out2 = a.lse_out2;
         q.step = a.step; q.step2 = a.step2;
         q.snap_in = a.snapshot; q.snap_out = a.snapshot_out;
+        q.g_out = a.g_out;
 #pragma unroll
         for (int p = 0; p < P; ++p) q.tau[p] = a.tau.v[p];
     }
@@ -1372,6 +1391,8 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
             const double linked = q.pool_cur[(int64_t)(P + p) * N64 + pos];
             const double m = q.m_cur[p * N64 + ii];
             g[p] = (adj[p] - (linked / se[p] - m * sld[p])) / q.tau[p];
+            // a lazy trial leaves g instead of its candidates' vi_mu (one wave per tile writes it)
+            if (NOSTORE && (SNP_SPLIT != 4 || w == 0) && live) q.g_out[p * N64 + i] = g[p];
         }
     }
     const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
@@ -1457,12 +1478,15 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                         t = 0.0;
 #pragma unroll
                         for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+                        if (!NOSTORE) {
 #ifndef SNP_DIAG_NOSTORE                 // (diagnostic builds of profiles/microbench_snp.py only)
-                        // no `if (live)`: a lane past the end works on a copy of SNP N-1 and stores
-                        // the value that SNP's own lane stores, to the same place -- cheaper than
-                        // four exec-mask branches per component (C3 trial pass 0.48 -> 0.44 ms)
-                        MU_STORE(&mu_out[c][((int64_t)k * P + p) * N64 + ii], t);
+                            // no `if (live)`: a lane past the end works on a copy of SNP N-1 and
+                            // stores the value that SNP's own lane stores, to the same place --
+                            // cheaper than four exec-mask branches per component (C3 trial pass
+                            // 0.48 -> 0.44 ms)
+                            MU_STORE(&mu_out[c][((int64_t)k * P + p) * N64 + ii], t);
 #endif
+                        }
                     }
                     mun[p] = t;
                     quad += t * nat[p];
@@ -1707,6 +1731,12 @@ static void launch_snp_pass_s(const SnpKernelArgs &a, bool stash, hipStream_t s)
             return;
         }
     }
+    if constexpr (BLEND) {
+        if (a.no_store) {       // lazy trial: g instead of the candidates' vi_mu
+            hipLaunchKernelGGL((snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, false, true>), grid, block, lds, s, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, false>), grid, block, lds, s, a);
 }
 
@@ -1744,7 +1774,7 @@ void launch_snp_pass(const SnpKernelArgs &args, bool blend, int ns, hipStream_t 
     SnpKernelArgs a = args;
     a.pred = g_pred;
     a.pp = g_phase;
-    const bool stash = a.sum_partials != nullptr && snp_pass_can_stash(a.M, a.P, ns);
+    const bool stash = !a.no_store && a.sum_partials != nullptr && snp_pass_can_stash(a.M, a.P, ns);
     switch (a.P) {
         case 1: launch_snp_pass_p<1>(a, blend, ns, stash, s); break;
         case 2: launch_snp_pass_p<2>(a, blend, ns, stash, s); break;
@@ -1769,7 +1799,11 @@ void launch_snp_pass(const SnpKernelArgs &args, bool blend, int ns, hipStream_t 
 // k = ks, ks+4, ... of the same 16 SNPs: 4x the waves for the same work, which small shards (an
 // 8-GPU rank holds ~130 k SNPs = 2 waves per SIMD at KS = 1) need to hide latency, and the
 // per-component sum over SNPs becomes a 16-lane shuffle reduction (29 vs 39 us at 131 k SNPs).
-template <int P, bool ONE_ANNOT, bool WRITE, int KS>
+// MAT: the state is not stored yet -- it is the candidate a lazy beta trial's decision accepted,
+// mu_k' = Sig_k (step g + (1 - step) Lam_k mu_k) in terms of the state the trial started from (the
+// very expressions of snp_pass_kernel's blend, so the same bits) -- and this pass stores it on its
+// way (the one vi_mu array written per accepted update).
+template <int P, bool ONE_ANNOT, bool WRITE, int KS, bool MAT = false>
 __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     constexpr int SPW = 64 / KS;
     PRED_EXIT(a.pred);
@@ -1783,17 +1817,26 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     // the state: from the arguments, or -- behind a queued sweep's decision -- the one its EVAL
     // phase starts from (the candidate the decision accepted)
     const double *mu_state = a.mu, *lse_state = a.lse;
+    double *mu_mat = a.mu_mat;
+    const double *g_state = a.g;
+    double step = a.step;
     double d[P];
     if (a.pp != nullptr) {
         const phase_tab t = PHASE(a.pp);
         mu_state = t->mu_in;
         lse_state = t->lse_ref;
+        mu_mat = t->mu_mat;
+        g_state = t->g_pend;
+        step = t->step_pend;
 #pragma unroll
         for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / t->tau[p];
     } else {
 #pragma unroll
         for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / a.tau.v[p];
     }
+    double g[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) g[p] = MAT ? g_state[p * N64 + ii] : 0.0;
     const int ann = ONE_ANNOT ? 0 : a.annot[ii];
     const double *lh = a.lh + (int64_t)ann * M;
     const double lse = lse_state[ii];
@@ -1807,14 +1850,19 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     constexpr int KD = 4;
     const const_tab prec_tab = as_table(a.prec);
     const const_tab lh_tab = as_table(a.lh);
-    for (int k0 = ks; k0 < M; k0 += KS * KD) {
-        double mu[KD][P], delta[KD];
+    // Double buffering as in snp_pass_kernel: the loads of the next batch are issued BEFORE this
+    // batch's stores (on gfx9 loads and stores retire through one in-order counter, so a wave that
+    // stores and then loads waits for its own stores to reach memory before it sees the loaded data)
+    auto fetch = [&](double (&dst)[KD][P], int k0) {
 #pragma unroll
         for (int u = 0; u < KD; ++u) {
             const int kc = min(k0 + u * KS, M - 1);       // unconditional loads; extras ignored
 #pragma unroll
-            for (int p = 0; p < P; ++p) mu[u][p] = MU_LOAD(&mu_state[((int64_t)kc * P + p) * N64 + ii]);
+            for (int p = 0; p < P; ++p) dst[u][p] = MU_LOAD(&mu_state[((int64_t)kc * P + p) * N64 + ii]);
         }
+    };
+    auto work = [&](double (&mu)[KD][P], int k0) {
+        double delta[KD];
 #pragma unroll
         for (int u = 0; u < KD; ++u) {
             const int k = min(k0 + u * KS, M - 1);
@@ -1828,7 +1876,30 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
                 lam[p][p] += d[p];
             }
             const double lhk = (KS == 1 && ONE_ANNOT) ? lh_tab[k] : lh[k];
-            const double wdet = spd_rsqrt_det<P>(lam);
+            double wdet;
+            if (MAT) {
+                double sig[P][P], told[P], nat[P];
+                wdet = spd_inverse<P>(lam, sig);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int q = 0; q < P; ++q) t += lam[p][q] * mu[u][q];
+                    told[p] = t;
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p) nat[p] = step * g[p] + (1.0 - step) * told[p];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+                    mu[u][p] = t;
+                    MU_STORE(&mu_mat[((int64_t)k * P + p) * N64 + ii], t);
+                }
+            } else {
+                wdet = spd_rsqrt_det<P>(lam);
+            }
             double quad = 0.0;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -1867,6 +1938,15 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
                 }
             }
         }
+    };
+    double bufA[KD][P], bufB[KD][P];
+    fetch(bufA, ks);
+    for (int k0 = ks; k0 < M; k0 += 2 * KS * KD) {
+        fetch(bufB, k0 + KS * KD);          // (past the end the clamped loads re-read component M-1)
+        work(bufA, k0);
+        if (k0 + KS * KD >= M) break;
+        fetch(bufA, k0 + 2 * KS * KD);
+        work(bufB, k0 + KS * KD);
     }
 }
 
@@ -1953,6 +2033,13 @@ static void reduce_cols(const double *in, int rows, int ncols, double *scratch, 
 template <int P, bool WRITE, int KS>
 static void launch_delta_pk(const DeltaArgs &a, hipStream_t s) {
     const dim3 grid(delta_grid(a.N)), block(SNP_THREADS);
+    if constexpr (!WRITE) {
+        if (a.mat) {
+            if (a.A == 1) hipLaunchKernelGGL((delta_kernel<P, true, false, KS, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((delta_kernel<P, false, false, KS, true>), grid, block, 0, s, a);
+            return;
+        }
+    }
     if (a.A == 1) hipLaunchKernelGGL((delta_kernel<P, true, WRITE, KS>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((delta_kernel<P, false, WRITE, KS>), grid, block, 0, s, a);
 }

@@ -524,6 +524,15 @@ bool stash_sums(const vilma_ctx *c, const SweepState *s) {
     return c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, s->two_step ? 2 : 1);
 }
 
+// Without the stash the candidates' responsibility sums need a pass over the accepted candidate
+// anyway; the trials then need not store their candidates' vi_mu at all ("lazy": that pass
+// re-derives the accepted one and stores it) -- at M = 582 a trial writes 19.6 GB less.
+bool lazy_trials(const vilma_ctx *c, const SweepState *s) {
+    const char *e = std::getenv("VILMA_PIPE_LAZY");         // =0: the trials store both candidates (A/B)
+    if (e && e[0] == '0') return false;
+    return !stash_sums(c, s);
+}
+
 int pipeline_buffers(vilma_ctx *c, SweepState *s) {
     if (c->ctl) return 0;
     if (dev_alloc(c, &c->ctl, 1)) return 1;
@@ -542,6 +551,7 @@ BufferBases buffer_bases(const vilma_ctx *c) {
         b.mu[q] = c->mu[q]; b.pool[q] = c->pool[q]; b.m[q] = c->m[q]; b.v[q] = c->v[q]; b.lse[q] = c->lse[q];
     }
     b.snap[0] = c->snap[0]; b.snap[1] = c->snap[1];
+    b.g = c->gbuf;
     return b;
 }
 
@@ -554,6 +564,7 @@ SweepDecideParams decide_params(vilma_ctx *c, SweepState *s, int mode, bool veto
     p.have_b = two ? 1 : 0;
     p.have_sums_b = (two && stash) ? 1 : 0;
     p.mstep_inside = stash ? 1 : 0;
+    p.lazy = lazy_trials(c, s) ? 1 : 0;
     p.scale_se = (s->scale_se && allow_tau) ? 1 : 0;
     p.two_snapshots = 1;
     p.max_inner = MAX_NUM_ITERS;
@@ -600,6 +611,7 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     const int64_t tag = ++s->group_serial;
     int rc = 0;
     c->prof_tag = 4 * tag;
+    c->lazy_trial = lazy_trials(c, s);
     set_launch_predicate(&c->ctl->alive);
     rc = queue_trial_phase(c, st, two, s->results + s->o_ta, s->results + s->o_tb,
                            stash ? s->results + s->o_sa : nullptr,
@@ -615,7 +627,8 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     if (!rc) rc = queue_decision(c, s, st, VILMA_DECIDE_TRIAL, veto, true, tag);
     c->prof_tag = 4 * tag + 1;
     if (!rc && !stash) {
-        set_launch_predicate(&c->ctl->run_eval);
+        // (behind a lazy trial the pass runs on every accept: it is what stores the candidate)
+        set_launch_predicate(&c->ctl->run_sums);
         rc = queue_sums_phase(c, st, s->results + s->o_sa);
         set_launch_predicate(nullptr);
         if (!rc && s->comm_kind) rc = comm_allreduce(c, s, st, s->results + s->o_sa, s->am, 0);
@@ -641,6 +654,7 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
         }
     }
     c->prof_tag = 0;
+    c->lazy_trial = false;
     if (!rc) s->groups_out += 1;
     s->pipe_stream = st;
     return rc;
@@ -756,7 +770,23 @@ int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const DecideR
     s->armed = false;
     s->resume = SweepState::Resume();
     const bool trial_pending = q.args.mode == VILMA_DECIDE_TRIAL;
-    if (trial_pending) {
+    if (trial_pending && q.args.lazy) {
+        // the trial's candidates exist as sums only (no vi_mu was stored): the host's line search
+        // evaluates that trial again, with its own kernels
+        c->have_b = false;
+        c->tile_sums_ns = 0;
+        if (s->comm_kind)
+            HIPCHK(c, hipMemcpy(s->results + s->o_dsum, r + s->o_dsum,
+                                (size_t)(s->reduce_end - s->o_dsum) * sizeof(double), hipMemcpyHostToDevice));
+        s->pend_valid = s->alt_valid = false;
+        s->trial_sums = s->trial_sums_b = false;
+        if (!sweep_ended) {
+            s->resume.active = true;
+            s->resume.it0 = k.inner_it;
+            s->resume.delta_sum = k.delta_sum;
+            s->resume.L_try = k.L_try;
+        }
+    } else if (trial_pending) {
         // the trial's candidates are evaluated and nobody has used them: the host's line search
         // starts with them (trial()'s pend / alt caches)
         const bool stash = q.args.mstep_inside != 0;
