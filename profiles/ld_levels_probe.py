@@ -120,7 +120,8 @@ def main():
                     help='only build the diagnostic variants of the library next to it and exit: '
                          'libvilma_hip_trace.so (-DLD_TRACE=1) and the LD_STORE_MODE builds of '
                          'kernels.hip: _nostore (1: wrong results, timing only), _plainstore (2: '
-                         'rounds 1 - 3), _ntstore (3), _stagedplain (4), _sc1store (5)')
+                         'rounds 1 - 3), _ntstore (3), _stagedplain (4), _sc1store (5), _staged8 (6: staged, '
+                         '8-byte write-through stores)')
     args = ap.parse_args()
     if args.build_variants:
         from concurrent.futures import ThreadPoolExecutor
@@ -130,8 +131,9 @@ def main():
                 (['-DLD_STORE_MODE=2'], TRACE_LIB.replace('_trace', '_plainstore')),
                 (['-DLD_STORE_MODE=3'], TRACE_LIB.replace('_trace', '_ntstore')),
                 (['-DLD_STORE_MODE=4'], TRACE_LIB.replace('_trace', '_stagedplain')),
-                (['-DLD_STORE_MODE=5'], TRACE_LIB.replace('_trace', '_sc1store'))]
-        with ThreadPoolExecutor(max_workers=6) as pool:
+                (['-DLD_STORE_MODE=5'], TRACE_LIB.replace('_trace', '_sc1store')),
+                (['-DLD_STORE_MODE=6'], TRACE_LIB.replace('_trace', '_staged8'))]
+        with ThreadPoolExecutor(max_workers=7) as pool:
             list(pool.map(lambda j: build.build_library(extra_flags=j[0], out=j[1], verbose=False), jobs))
         return
     import torch

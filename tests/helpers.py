@@ -1,4 +1,5 @@
 """Shared test helpers: golden loading and oracle construction (tests may import oracle/)."""
+import contextlib
 import os
 
 import numpy as np
@@ -6,6 +7,22 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 TRAJ_NAMES = ['p1_dense', 'p2_lowrank', 'p2_scale_se', 'p4_general', 'p1_scaled', 'p4_m81',
               'p2_bigblock', 'p2_bigblock_lr']
+
+
+@contextlib.contextmanager
+def engine_class(cls):
+    """TESTS ONLY.  The product has no parameter for its engine: MultiPopVI builds
+    vilma_amd.engine.HipEngine(...), which needs a GPU.  The CPU tests of the host-side logic
+    (driver loop, sharding, CLI plumbing) swap that module attribute for the oracle-backed test
+    engine while they construct their objects, and put it back."""
+    from vilma_amd import engine
+    old = engine.HipEngine
+    if cls is not None:
+        engine.HipEngine = cls
+    try:
+        yield
+    finally:
+        engine.HipEngine = old
 
 
 def golden(name):
@@ -107,13 +124,14 @@ def product_vi_from_traj(g, num_its=None, engine_factory=None, comm=None, form='
     ld = [BlockDiagonalMatrix([LowRankMatrix(X, t) for X in blocks], perm=g['perm'],
                               missing=g['missing'])
           for blocks in traj_blocks(g)]
-    vi = MultiPopVI(marginal_effects=g['betahat'], std_errs=g['se'], ld_mats=ld,
-                    mixture_covs=list(g['covs']), annotations=g['annotations'],
-                    checkpoint=False, checkpoint_freq=-1, output='t',
-                    scaled=bool(g['scaled']), scale_se=bool(g['scale_se']),
-                    gwas_N=g['gwas_N'], init_hg=g['init_hg'],
-                    num_its=len(g['elbo']) if num_its is None else num_its, form=form,
-                    _engine_factory=engine_factory, _comm=comm)
+    with engine_class(engine_factory):
+        vi = MultiPopVI(marginal_effects=g['betahat'], std_errs=g['se'], ld_mats=ld,
+                        mixture_covs=list(g['covs']), annotations=g['annotations'],
+                        checkpoint=False, checkpoint_freq=-1, output='t',
+                        scaled=bool(g['scaled']), scale_se=bool(g['scale_se']),
+                        gwas_N=g['gwas_N'], init_hg=g['init_hg'],
+                        num_its=len(g['elbo']) if num_its is None else num_its, form=form,
+                        _comm=comm)
     return vi, ld
 
 

@@ -19,7 +19,9 @@ EX = os.path.join(GOLDEN, 'example')
 
 def run_fit(argv, engine_factory):
     args = frontend.build_parser().parse_args(['fit'] + argv)
-    vi_options.main(args, _engine_factory=engine_factory)
+    from helpers import engine_class
+    with engine_class(engine_factory):
+        vi_options.main(args)
 
 
 def check_frames(truth, got):

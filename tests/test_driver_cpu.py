@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import golden, product_vi_from_traj, check_trajectory, TRAJ_NAMES
+from helpers import golden, product_vi_from_traj, check_trajectory, engine_class, TRAJ_NAMES
 from oracle_engine import OracleEngine
 
 
@@ -64,23 +64,23 @@ def test_validation_errors():
     vi, ld = product_vi_from_traj(g, engine_factory=OracleEngine)
     kw = dict(marginal_effects=g['betahat'], std_errs=g['se'], ld_mats=ld,
               mixture_covs=list(g['covs']), annotations=g['annotations'], gwas_N=g['gwas_N'],
-              init_hg=g['init_hg'], num_its=3, _engine_factory=OracleEngine)
+              init_hg=g['init_hg'], num_its=3)
     for drop in ('init_hg', 'gwas_N', 'num_its', 'annotations', 'std_errs'):
         bad = dict(kw)
         bad[drop] = None
-        with pytest.raises(ValueError):
+        with pytest.raises(ValueError), engine_class(OracleEngine):
             MultiPopVI(**bad)
     bad = dict(kw); bad['marginal_effects'] = np.where(np.arange(g['betahat'].size).reshape(g['betahat'].shape) == 3, np.nan, g['betahat'])
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError), engine_class(OracleEngine):
         MultiPopVI(**bad)
     bad = dict(kw); bad['mixture_covs'] = [-np.eye(1)] * 3
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError), engine_class(OracleEngine):
         MultiPopVI(**bad)
     bad = dict(kw); bad['annotations'] = np.zeros_like(g['annotations'])
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError), engine_class(OracleEngine):
         MultiPopVI(**bad)
     bad = dict(kw); bad['ld_mats'] = ld + ld
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError), engine_class(OracleEngine):
         MultiPopVI(**bad)
 
 
@@ -139,9 +139,9 @@ def test_every_rank_detects_an_empty_shard():
     n_comp = len(ld[0].matrices) + len(g['missing'])
     kw = dict(marginal_effects=g['betahat'], std_errs=g['se'], ld_mats=ld,
               mixture_covs=list(g['covs']), annotations=g['annotations'], gwas_N=g['gwas_N'],
-              init_hg=g['init_hg'], num_its=3, _engine_factory=OracleEngine)
+              init_hg=g['init_hg'], num_its=3)
     for rank in (0, n_comp):                  # a rank that has SNPs and one that has none
-        with pytest.raises(ValueError, match='no SNPs'):
+        with pytest.raises(ValueError, match='no SNPs'), engine_class(OracleEngine):
             MultiPopVI(_comm=FakeComm(rank, n_comp + 1), **kw)
 
 
@@ -221,9 +221,11 @@ def _eight_main(rank, world, port, q):
         ovi = MultiPopVIOracle(ld_mats=[BlockDiagonalLD([EigenBlock(X, 1.0) for X in pr['blocks'][p]],
                                                         perm=pr['perm'], missing=pr['missing'])
                                         for p in range(pr['P'])], **common)
-        vi = MultiPopVI(ld_mats=[BlockDiagonalMatrix([LowRankMatrix(X, 1.0) for X in pr['blocks'][p]],
-                                                     perm=pr['perm'], missing=pr['missing'])
-                                 for p in range(pr['P'])], _engine_factory=OracleEngine, **common)
+        from helpers import engine_class as _engine_class
+        with _engine_class(OracleEngine):
+            vi = MultiPopVI(ld_mats=[BlockDiagonalMatrix([LowRankMatrix(X, 1.0) for X in pr['blocks'][p]],
+                                                         perm=pr['perm'], missing=pr['missing'])
+                                     for p in range(pr['P'])], **common)
         assert vi.comm.world == world and 0 < len(vi._snps) < pr['N']
         np.random.seed(7)
         op = ovi._initialize()

@@ -172,27 +172,30 @@ def test_random_configurations(seed):
     _compare(pr, sweeps=3, scaled=bool(rng.integers(0, 2)), scale_se=bool(rng.integers(0, 2)))
 
 
-@pytest.mark.parametrize('shape', ['p1', 'p2_a2', 'p3', 'p4_m81', 'p2_m130', 'p2_scale_se',
+@pytest.mark.parametrize('shape', ['p1', 'p2_a2', 'p3', 'p4_m81', 'p2_m130', 'p5', 'p2_scale_se',
                                    'p1_scale_se', 'p3_scale_se'])
 def test_device_resident_sweeps_equal_host_decided_sweeps(shape, monkeypatch):
     """The sweeps queued ahead (roles, L, step sizes on the device; decision kernel) against the
     same fit with every decision taken on the host side of the library (VILMA_LOOKAHEAD=0), on
     shapes the synthetic benchmark does not cover: one cohort, several annotations (the M-step
     of the decision kernel row by row), three and four cohorts (one candidate per trial: a
-    rejected step makes the next queued trial run at twice the L), many components (no stash: the
-        responsibility sums come from a pass over the accepted candidate behind the decision).
+    rejected step makes the next queued trial run at twice the L), five cohorts (the general P x P
+    Cholesky kernels, never a stash), many components (no stash: the trials store no vi_mu, the
+    pass behind the decision forms the accepted candidate's responsibility sums and stores it).
     The *_scale_se shapes fit with --learn-scaling: the error-scaling update
     (_update_error_scaling, reference variational_inference.py:441-448, 472-486) and the
     re-evaluation behind it are decided and run on the device too.
     ELBO, L, error_scaling, convergence statistics after every sweep and the final state: bit for
     bit; and the device handed no decision back to the host."""
     rng = np.random.default_rng({'p1': 1, 'p2_a2': 2, 'p3': 3, 'p4_m81': 4, 'p2_m130': 5,
-                                 'p2_scale_se': 6, 'p1_scale_se': 7, 'p3_scale_se': 8}[shape])
+                                 'p2_scale_se': 6, 'p1_scale_se': 7, 'p3_scale_se': 8, 'p5': 9}[shape])
     pr = {'p1': lambda: _problem(rng, 1, [[60, 45, 70, 30]], N=215, M=9),
           'p2_a2': lambda: _problem(rng, 2, [[80, 60, 40], [90, 50, 40]], N=190, M=8, A=3),
           'p3': lambda: _problem(rng, 3, [[50, 40], [45, 45], [30, 30, 30]], N=100, M=6, A=2),
           'p4_m81': lambda: _problem(rng, 4, [[70, 60], [130], [65, 65], [40, 40, 50]], N=140, M=81),
           'p2_m130': lambda: _problem(rng, 2, [[60, 50], [55, 55]], N=120, M=130),
+          'p5': lambda: _problem(rng, 5, [[40, 30, 25], [60, 35], [95], [20, 20, 20, 20], [50, 45]],
+                                 N=110, M=7),
           'p2_scale_se': lambda: _problem(rng, 2, [[80, 60, 40], [90, 50, 40]], N=190, M=8, A=2),
           'p1_scale_se': lambda: _problem(rng, 1, [[60, 45, 70, 30]], N=215, M=130),
           'p3_scale_se': lambda: _problem(rng, 3, [[50, 40], [45, 45], [30, 30, 30]], N=100, M=6)}[shape]()

@@ -153,3 +153,52 @@ def test_lazy_schema_streams_to_the_device(tmp_path):
         vi.engine.close()
     for a, b in zip(fits[False], fits[True]):
         np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-14)
+
+
+def test_ridge_start_fallback_end_to_end(monkeypatch, caplog):
+    """When conjugate gradients cannot deliver the ridge start (RidgeStalled), MultiPopVI answers
+    with the reference's per-block solve on the host (matrix_structures.py:349-387) -- through
+    blocks the streaming loader has already dropped from host memory (they are decomposed again)
+    and blocks given as factors alike -- and ends with the reference's inverse_betas."""
+    import logging
+    from helpers import golden, traj_blocks
+    from vilma_amd import ld_device
+    from vilma_amd.matrix_structures import LowRankMatrix, BlockDiagonalMatrix
+    from vilma_amd.variational_inference import MultiPopVI
+    g = golden('traj_p2_lowrank.npz')
+    t = float(g['ldthresh'])
+    made = []
+
+    def thunk(X):
+        def make():
+            made.append(X.shape[0])
+            return X
+        return make
+    ld = []
+    for p, blocks in enumerate(traj_blocks(g)):
+        mats = []
+        for b, X in enumerate(blocks):
+            if b % 2 == 0:          # decomposed lazily (and forgotten once in HBM) ...
+                mats.append(LowRankMatrix.deferred(thunk(X), X.shape[0], t))
+            else:                   # ... or handed over as factors
+                m = LowRankMatrix(X, t)
+                mats.append(LowRankMatrix(u=m.u, s=m.s, v=m.v, D=np.zeros(X.shape[0])))
+        ld.append(BlockDiagonalMatrix(mats, perm=g['perm'], missing=g['missing']))
+
+    def stalled(*a, **k):
+        raise ld_device.RidgeStalled('ridge start: forced by the test')
+    monkeypatch.setattr(ld_device, 'ridge_start', stalled)
+    with caplog.at_level(logging.WARNING):
+        vi = MultiPopVI(marginal_effects=g['betahat'], std_errs=g['se'], ld_mats=ld,
+                        mixture_covs=list(g['covs']), annotations=g['annotations'],
+                        checkpoint=False, scaled=bool(g['scaled']), scale_se=bool(g['scale_se']),
+                        gwas_N=g['gwas_N'], init_hg=g['init_hg'], num_its=3)
+    assert any('falling back to the per-block ridge solve' in r.getMessage() for r in caplog.records)
+    n_lazy = sum((len(blocks) + 1) // 2 for blocks in traj_blocks(g))
+    assert len(made) == 2 * n_lazy          # once for the device store, once more for the fallback
+    np.testing.assert_allclose(vi.inverse_betas, g['inverse_betas'], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(vi.adj_marginal_effects, g['adj_marginal_effects'], rtol=1e-8, atol=1e-12)
+    np.random.seed(int(g['seed']))
+    params = vi._initialize()
+    assert abs(vi.elbo(params) - float(g['init_elbo'])) < 1e-9 * abs(float(g['init_elbo']))
+    vi.engine.close()

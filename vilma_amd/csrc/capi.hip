@@ -49,14 +49,14 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
             const int ns = n_slabs(b.n);
             const int CH = c->chunk_rows;
             const int nch_max = (b.n + CH - 1) / CH;
-            const int32_t c_base = s_off + ns * b.n;         // C[slab][chunk][128] behind S[slab][n]
+            const int32_t c_base = s_off + ns * pad2(b.n);   // C[slab][chunk][128] behind S[slab][pad2(n)]
             for (int J = 0; J < ns; ++J) {
                 const int rows = b.n - 128 * J, wJ = slab_width(b.n, J), ldJ = pad_ld(wJ);
                 for (int r0 = 0, ch = 0; r0 < rows; r0 += CH, ++ch) {
                     SymItem it;
                     it.a = co.store + off + (int64_t)r0 * ldJ;
                     it.rows = std::min(CH, rows - r0); it.w = wJ; it.ld = ldJ; it.j0 = 128 * J;
-                    it.x_off = pN + b.start; it.s_off = s_off + J * b.n; it.r0 = r0;
+                    it.x_off = pN + b.start; it.s_off = s_off + J * pad2(b.n); it.r0 = r0;
                     it.c_off = c_base + (J * nch_max + ch) * 128;
                     H.sym.push_back(it);
                 }
@@ -81,7 +81,7 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
                 it.a = U + (int64_t)c0 * ldc;
                 it.scale = sv + c0;
                 it.n = b.n; it.ncols = std::min(cols, b.r - c0); it.ldc = ldc;
-                it.x_off = pN + b.start; it.s_off = s_off + J * b.n; it.pad = 0;
+                it.x_off = pN + b.start; it.s_off = s_off + J * pad2(b.n); it.pad = 0;
                 H.eig[eig_class(R)].push_back(it);
             }
             for (int i0 = 0; i0 < b.n; i0 += 256) {
@@ -90,7 +90,7 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
                 cb.dot_off = pN + b.start; cb.dot_slot = slot++; cb.i0 = i0; cb.pad = 0;
                 H.fcomb.push_back(cb);
             }
-            s_off += ns * b.n;
+            s_off += ns * pad2(b.n);
         } else {
             // eigen form: U [n x ld(r)] then s [ld(r)].  New group when this block would push the
             // group's U past the budget (a block larger than the budget gets a group of its own)
@@ -117,7 +117,7 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
                     RowItem it;
                     it.a = U + (int64_t)r0 * ldr + 128 * J; it.rows = std::min(CH, b.n - r0);
                     it.ld = ldr; it.w = std::min(128, b.r - 128 * J); it.t_off = t_pool + 128 * J;
-                    it.s_off = s_off + J * b.n + r0; it.pad = 0;
+                    it.s_off = s_off + J * pad2(b.n) + r0; it.pad = 0;
                     H.row.push_back(it);
                     ++g.nr;
                 }
@@ -128,7 +128,7 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
                 H.rcomb.push_back(cb);
                 ++g.nc;
             }
-            s_off += ns * b.n;
+            s_off += ns * pad2(b.n);
         }
     }
 }
@@ -886,7 +886,7 @@ int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U
     co.next_start += n;
     co.t_used += pad_ld(r);
     // partial row sums S[slab][n]
-    co.s_used += (int64_t)(W > 0 ? eig_n_slabs(n, r, W) : (r + 127) / 128) * n;
+    co.s_used += (int64_t)(W > 0 ? eig_n_slabs(n, r, W) : (r + 127) / 128) * pad2(n);
     co.alg_bytes += (int64_t)8 * n * r;
     return 0;
 }

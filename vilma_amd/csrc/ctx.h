@@ -104,8 +104,10 @@ inline int64_t sym_panel_elems(int n, int J) {
 inline int n_slabs(int n) { return (n + 127) / 128; }
 // scratch of the symmetric product for one block: row sums S[slab][n] and the column-sum chunks
 // C[slab][chunk][128] (laid out for ceil(n / chunk_rows) chunks per slab)
+// (rows of S are pad2(n) apart: every partial-sum record then starts 16-byte aligned and goes out
+// in 16-byte write-through stores)
 inline int32_t sym_scratch_elems(int n, int chunk_rows) {
-    return n_slabs(n) * (n + ((n + chunk_rows - 1) / chunk_rows) * 128);
+    return n_slabs(n) * (pad2(n) + ((n + chunk_rows - 1) / chunk_rows) * 128);
 }
 
 }  // namespace vilma_detail

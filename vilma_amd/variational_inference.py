@@ -473,13 +473,13 @@ class MultiPopVI(SweepDriver):
     """Fit the multi-population mixture-of-Gaussians VI scheme on MI355X.
 
     Keyword arguments are the reference's (variational_inference.py:96-142).  `form` selects
-    the LD storage ('auto' | 'dense' | 'eig'); `_engine_factory` lets tests inject a different
-    engine implementation (the default is the HIP engine and there is no CPU fallback)."""
+    the LD storage ('auto' | 'dense' | 'eig').  The engine is always the HIP engine
+    (vilma_amd.engine.HipEngine): there is no CPU fallback and no parameter to supply another."""
 
     def __init__(self, marginal_effects=None, std_errs=None, ld_mats=None, annotations=None,
                  mixture_covs=None, checkpoint=True, checkpoint_freq=5, scaled=False,
                  scale_se=False, output='vilma_output', gwas_N=None, init_hg=None,
-                 num_its=None, form='auto', _engine_factory=None, _comm=None):
+                 num_its=None, form='auto', _comm=None):
         # ---- argument checks, in the reference's order and with its exceptions ----
         if marginal_effects is not None and mixture_covs is not None:
             P_ = np.asarray(marginal_effects).shape[0]
@@ -562,10 +562,8 @@ class MultiPopVI(SweepDriver):
             # every rank computes the same plan, so every rank raises here, before any collective
             raise ValueError('rank(s) %s would receive no SNPs: fewer independent LD components '
                              'than GPUs (%d)' % (empty, self.comm.world))
-        if _engine_factory is None:
-            from .engine import HipEngine
-            _engine_factory = HipEngine
-        self.engine = _engine_factory(P, n_loc, M, self.num_annotations)
+        from . import engine as _engine
+        self.engine = _engine.HipEngine(P, n_loc, M, self.num_annotations)
 
         # ---- one-time constants (variational_inference.py:189-252) for this shard's blocks;
         # the per-SNP results are gathered across ranks ----
@@ -628,7 +626,11 @@ class MultiPopVI(SweepDriver):
         except ld_device.RidgeStalled as exc:
             # the reference's own per-block solve (matrix_structures.py:349-387) always returns a
             # starting point: fall back to it on the host (re-decomposing blocks that were dropped)
-            logging.warning('%s; falling back to the per-block ridge solve on the host', exc)
+            # (blocks the streaming loader dropped from host memory are decomposed again, on demand)
+            again = sum(1 for sub, _, _ in local_lds for m in sub.matrices
+                        if getattr(m, 'is_deferred', lambda: False)())
+            logging.warning('%s; falling back to the per-block ridge solve on the host '
+                            '(%d block(s) decomposed again)', exc, again)
             ridge = np.zeros((P, n_loc))
             for p, (sub, perm, n_ld) in enumerate(local_lds):
                 ridge[p] = sub.ridge_inverse_dot(rmle[p], reg[p])

@@ -137,7 +137,7 @@ def _make_simple(num_pops, num_components, mins, maxes):
     return covs
 
 
-def main(args, _engine_factory=None):
+def main(args):
     from .sharding import init_distributed_from_env
     init_distributed_from_env()          # torchrun --nproc-per-node G: one rank per GPU
     np.random.seed(args.seed)
@@ -217,7 +217,6 @@ def main(args, _engine_factory=None):
         checkpoint=(args.checkpoint_freq > 0), checkpoint_freq=args.checkpoint_freq,
         output=args.output, scaled=args.scaled, scale_se=args.scale_se, gwas_N=gwas_n,
         init_hg=init_hg, num_its=args.num_its, form=getattr(args, 'ld_form', 'auto'),
-        _engine_factory=_engine_factory,
     )
     checkpoint = np.load(args.load_checkpoint[0]) if args.load_checkpoint else None
     params = elbo.optimize(checkpoint)
