@@ -99,6 +99,32 @@ def test_c3_fit_invariants():
     eng.close()
 
 
+def test_c3k12_default_mixture_fit_invariants():
+    """C3's SNPs and LD under the mixture `vilma fit` builds by default for two cohorts (-K 12 ->
+    582 components, reference vi_options.py:17-20, 284-337) at FULL size: 29 GB of vi_mu, the
+    per-SNP passes dominate.  The sweeps run from the device's control block although the mixture
+    is far beyond the on-chip stash (lazy trials + the materialising sums pass); same invariants as
+    C3."""
+    sh, eng, drv = _setup('C3K12')
+    assert sh.M == 582 and sh.P == 2 and sh.N_global > 1_000_000
+    drv.initialize_from(sh.fake_mu)
+    state, elbo_prev = None, drv._objective
+    assert np.isfinite(elbo_prev)
+    for it in range(4):
+        state, stats = drv.sweep(state, lookahead=it < 3)
+        assert state['elbo'] >= elbo_prev - 25 * (1e-6 * abs(elbo_prev) + 1e-6)
+        assert np.all(state['L'] >= 1.0) and state['L'][1] == 1.0
+        assert np.all(np.isfinite(stats)) and stats[0] >= 0
+        elbo_prev = state['elbo']
+    assert drv.n_stages_ahead >= 3 and drv.n_stages_skipped == 0
+    mean, var = eng.get_moments()
+    assert np.all(np.isfinite(mean)) and np.all(var >= 0)
+    assert abs(drv._hyper.sum() - 1.0) < 1e-12 and np.all(drv._hyper >= 1e-100)
+    obj = _fresh_objective(drv)
+    assert abs(obj - drv._objective) <= 1e-12 * abs(obj)
+    eng.close()
+
+
 def test_c2_three_sweeps_against_oracle():
     from oracle.ldop import EigenBlock, BlockDiagonalLD
     from oracle.vi import MultiPopVIOracle
