@@ -28,6 +28,8 @@
 #include "decide.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #define NEG_INF (-__builtin_huge_val())
 
@@ -406,8 +408,15 @@ static __device__ __forceinline__ void sym_group_diag(const v2d (&v)[CS_ROWS],
 #ifndef LD_TRACE
 #define LD_TRACE 0
 #endif
+// -DSNP_TRACE=1 (profiles/snp_pass_timeline.py): every WAVE of snp_pass_kernel leaves a row of 12 in
+// the same buffer: seven core-clock stamps (entry, loop start, loop end, normaliser known, tile
+// sums written, hand-over done, exit), the XCC id, entry and exit on the 100 MHz clock the whole
+// chip shares, and HW_ID (which CU, SIMD and wave slot it ran in)
+#ifndef SNP_TRACE
+#define SNP_TRACE 0
+#endif
 
-#if LD_TRACE
+#if LD_TRACE || SNP_TRACE
 __device__ double *g_ld_trace = nullptr;
 __device__ long long g_ld_trace_cap = 0;
 int set_ld_trace(double *buf_dev, int64_t capacity_rows) {
@@ -1150,15 +1159,59 @@ void launch_repack_columns(const double *src, int n, int r, int64_t ldc, double 
 }
 
 // --------------------------------------------------------------------------------------------
+// exp and 1/sqrt of the per-SNP passes.  These passes are co-bound by the vector ALU (profiles/
+// r03o_c3_pmc_sq.txt: ~70 % busy), so what the library versions spend on inputs that cannot occur
+// here is worth removing: exp() selects its result for +-inf and out-of-range arguments (two
+// compares, three selects per call), rsqrt() tests the class of its seed (a compare, two selects).
+//   pass_exp(x): x = n ln 2 + r, |r| <= ln 2 / 2; e^r = 1 + r + r^2 q(r), q of degree 9 fitted at
+//     the Chebyshev nodes of the interval (truncation 1.6e-17 relative with the coefficients
+//     rounded to double); the result is scaled by 2^n with ldexp, which overflows to inf and
+//     underflows through the denormals to 0 by itself (n saturates in the conversion).  NaN in,
+//     NaN out; +-inf (never formed from finite logits) gives NaN, which the normaliser check of
+//     snp_pass_kernel treats like any other Z out of range.
+//   pass_rsqrt(x): the hardware seed (v_rsq_f64, ~2^-23) and one third-order step,
+//     y (1 + e/2 + 3 e^2/8) with e = 1 - x y^2: below 1 ulp for normal x > 0 (pivots of SPD
+//     matrices with entries of 1e0 .. 1e12).
+// --------------------------------------------------------------------------------------------
+// The coefficients are pinned to scalar registers once per kernel (exp_consts()): as
+// vector-register operands the compiler ties each to the accumulator of a two-address v_fmac and
+// copies it first -- one v_mov_b64 per Horner step.
+struct ExpConsts { double c[9]; };
+static __device__ __forceinline__ ExpConsts exp_consts() {
+    ExpConsts k = {{0x1.28918e390a71ep-22, 0x1.71de0da9d06acp-19, 0x1.a019b905bafb1p-16,
+                    0x1.a01a01a7c54aep-13, 0x1.6c16c1788dc33p-10, 0x1.11111111109b2p-7,
+                    0x1.5555555553d5ep-5, 0x1.5555555555556p-3, 0x1.0000000000001p-1}};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) asm("" : "+s"(k.c[j]));
+    return k;
+}
+static __device__ __forceinline__ double pass_exp(double x, const ExpConsts &k) {
+    const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(n, -0x1.62e42fefa39efp-1, x);
+    r = fma(n, -0x1.abc9e3b39803fp-56, r);
+    double t = 0x1.af38b4925be09p-26;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) t = fma(t, r, k.c[j]);
+    t = fma(t, r, 1.0);
+    t = fma(t, r, 1.0);
+    return __builtin_ldexp(t, (int)n);
+}
+static __device__ __forceinline__ double pass_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+// --------------------------------------------------------------------------------------------
 // small SPD helpers, fully unrolled so everything stays in registers
 // --------------------------------------------------------------------------------------------
 // det(lam)^(-1/2) of a symmetric positive definite matrix
 template <int P>
 static __device__ __forceinline__ double spd_rsqrt_det(const double (&lam)[P][P]) {
     if constexpr (P == 1) {
-        return rsqrt(lam[0][0]);
+        return pass_rsqrt(lam[0][0]);
     } else if constexpr (P == 2) {
-        return rsqrt(lam[0][0] * lam[1][1] - lam[0][1] * lam[1][0]);
+        return pass_rsqrt(lam[0][0] * lam[1][1] - lam[0][1] * lam[1][0]);
     } else {
         double G[P][P];
         double w = 1.0;
@@ -1167,7 +1220,7 @@ static __device__ __forceinline__ double spd_rsqrt_det(const double (&lam)[P][P]
             double s = lam[j][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= G[j][k] * G[j][k];
-            const double rj = rsqrt(s);
+            const double rj = pass_rsqrt(s);
             G[j][j] = s * rj;
             w *= rj;
 #pragma unroll
@@ -1186,13 +1239,13 @@ static __device__ __forceinline__ double spd_rsqrt_det(const double (&lam)[P][P]
 template <int P>
 static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], double (&sig)[P][P]) {
     if constexpr (P == 1) {
-        const double w = rsqrt(lam[0][0]);
+        const double w = pass_rsqrt(lam[0][0]);
         sig[0][0] = w * w;
         return w;
     } else if constexpr (P == 2) {
         // closed form of the reference's 2x2 helper (numerics.py:223-232); 1/det = w^2
         const double det = lam[0][0] * lam[1][1] - lam[0][1] * lam[1][0];
-        const double w = rsqrt(det);
+        const double w = pass_rsqrt(det);
         const double r = w * w;
         sig[0][0] = lam[1][1] * r;
         sig[1][1] = lam[0][0] * r;
@@ -1209,7 +1262,7 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
             double s = lam[j][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= G[j][k] * G[j][k];
-            const double rj = rsqrt(s);
+            const double rj = pass_rsqrt(s);
             G[j][j] = s * rj;
             Gi[j][j] = rj;
             w *= rj;
@@ -1282,6 +1335,11 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 #ifndef KU
 #define KU 2
 #endif
+// Few components per wave (M = 40: ten): measured and NOT adopted -- batches of 5, so that all of a
+// wave's vi_mu is requested up front.  The loop shrinks (6.0 k -> 4.7 k cycles) but the kernel
+// needs 129 - 166 registers instead of 92 - 128, fewer workgroups are in flight per CU and both
+// passes get slower (evaluation 0.155 -> 0.166 ms, two-step trial 0.474 -> 0.503 ms, one box:
+// profiles/r04e_snp_pass_timeline.txt).
 
 int snp_pass_grid(int64_t N) { return (int)((N + SNP_THREADS - 1) / SNP_THREADS); }
 // workgroups (= tiles) of launch_snp_pass = rows of its partials
@@ -1334,6 +1392,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     constexpr int NTP = (NT + 7) / 8 * 8;
     constexpr int NACC = 2 + 2 * P;
     constexpr int KB = P <= 2 ? KU : (KU > 2 ? 2 : KU);
+    constexpr int TB = KB < 2 ? KB : 2;            // components whose tables are fetched together
     extern __shared__ double lds[];
     PRED_EXIT(a.pred);
     // the buffers and step sizes: from the arguments, or -- for a sweep queued ahead of the
@@ -1361,6 +1420,15 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
 #pragma unroll
         for (int p = 0; p < P; ++p) q.tau[p] = a.tau.v[p];
     }
+#if SNP_TRACE
+    long long stamp[7];
+#define SNP_STAMP(j) stamp[j] = __builtin_readcyclecounter()
+    const long long real0 = (long long)__builtin_amdgcn_s_memrealtime();     // 100 MHz, one clock for the chip
+#else
+#define SNP_STAMP(j)
+#endif
+    SNP_STAMP(0);
+    const ExpConsts expk = exp_consts();
     const int N = a.N, M = a.M;
     const int64_t N64 = N;
     const int lane = threadIdx.x & 63;
@@ -1406,12 +1474,30 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         d[p] = sld[p] / q.tau[p];
         g[p] = 0.0;
     }
+    // Everything the END of the tile needs from memory is requested here, by the wave that will
+    // use it: a load issued after the main loop would wait (vmcnt is in order) for every vi_mu
+    // store of the loop to be acknowledged first -- microseconds, with the other three waves of
+    // the workgroup already gone (profiles/r04e_snp_pass_timeline.txt: the last stretch of wave 0
+    // was 24 - 27 % of the workgroup's life).
+    int pos[P];
+    double scal_t[P], snap_t[P];
+    const bool tail_wave = SNP_SPLIT != 4 || w == 0;
+    if (BLEND || tail_wave) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) pos[p] = a.invperm[p * N64 + ii];
+    }
+    if (!BLEND && a.diff && tail_wave) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            scal_t[p] = a.scal[p * N64 + ii];
+            snap_t[p] = q.snap_in[p * N64 + ii];
+        }
+    }
     if (BLEND) {
         // _nat_grad_beta (variational_inference.py:804-823); identical for every component k
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const int pos = a.invperm[p * N64 + ii];
-            const double linked = q.pool_cur[(int64_t)(P + p) * N64 + pos];
+            const double linked = q.pool_cur[(int64_t)(P + p) * N64 + pos[p]];
             const double m = q.m_cur[p * N64 + ii];
             g[p] = (adj[p] - (linked / se[p] - m * sld[p])) / q.tau[p];
             // a lazy trial leaves g instead of its candidates' vi_mu (one wave per tile writes it)
@@ -1440,7 +1526,11 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     // scalar registers), so the batch computes without a scalar-load stall per component
     constexpr bool TAB_AHEAD = P <= 2;
 
-    double shift[NS], Z[NS], Skl[NS], Sip[NS], amax[NS], Sm[NS][P], S2[NS][P];
+    // Running sums per candidate, e = the softmax term of a component: Z = sum e, Sq = sum e quad,
+    // Sm = sum e mu, Smm = sum e mu^2, Ssig = sum e Sig_pp.  Everything the objective needs is
+    // linear in these (see below the loop), so tr(Prec Sig) and mu^T Prec mu are never formed per
+    // component: 10 operations per (component, candidate) where the direct sums took 17.
+    double shift[NS], Z[NS], Sq[NS], amax[NS], Sm[NS][P], Smm[NS][P], Ssig[NS][P];
 #pragma unroll
     for (int c = 0; c < NS; ++c) shift[c] = s0;
 
@@ -1449,19 +1539,28 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     // stores and then loads waits for its own stores to reach HBM before it sees the loaded data;
     // with the next loads ahead of the stores it only ever waits for loads.  With several
     // annotations the log-weight row differs per lane: those (vector) loads travel with the batch.
-    auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0) {
-        double prt[TAB_AHEAD ? KB : 1][P][P], lht[TAB_AHEAD ? KB : 1];
+    // `maxonly`: form the logits a_k only and keep their maximum (the rare second look at a tile
+    // whose normaliser left the representable range, see below)
+    auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0, auto maxonly) {
+        constexpr bool MAXONLY = decltype(maxonly)::value;
+#pragma unroll
+        for (int t0 = 0; t0 < KB; t0 += TB) {
+        if (k0 + t0 >= kend) break;                    // wave-uniform
+        double prt[TAB_AHEAD ? TB : 1][P][P], lht[TAB_AHEAD ? TB : 1];
         if (TAB_AHEAD) {
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const int kc = min(k0 + kk, M - 1);
+            for (int tt = 0; tt < TB; ++tt) {
+                if (t0 + tt >= KB) break;
+                const int kc = min(k0 + t0 + tt, M - 1);
 #pragma unroll
-                for (int e = 0; e < P * P; ++e) prt[kk][e / P][e % P] = prec_tab[(int64_t)kc * P * P + e];
-                lht[kk] = ONE_ANNOT ? lh_tab[kc] : lhv[kk];
+                for (int e = 0; e < P * P; ++e) prt[tt][e / P][e % P] = prec_tab[(int64_t)kc * P * P + e];
+                lht[tt] = ONE_ANNOT ? lh_tab[kc] : lhv[t0 + tt];
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
+        for (int tt = 0; tt < TB; ++tt) {
+            const int kk = t0 + tt;
+            if (kk >= KB) break;
             const int k = k0 + kk;
             if (k >= kend) break;                      // wave-uniform
             double pr[P][P], lam[P][P], sig[P][P], told[P];
@@ -1469,12 +1568,12 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
             for (int p = 0; p < P; ++p) {
 #pragma unroll
                 for (int q = 0; q < P; ++q) {
-                    pr[p][q] = TAB_AHEAD ? prt[kk][p][q] : prec_tab[(int64_t)k * P * P + p * P + q];
+                    pr[p][q] = TAB_AHEAD ? prt[tt][p][q] : prec_tab[(int64_t)k * P * P + p * P + q];
                     lam[p][q] = pr[p][q];
                 }
                 lam[p][p] += d[p];
             }
-            const double lhk = TAB_AHEAD ? lht[kk] : (ONE_ANNOT ? lh_tab[k] : lhv[kk]);
+            const double lhk = TAB_AHEAD ? lht[tt] : (ONE_ANNOT ? lh_tab[k] : lhv[kk]);
             const double wk = spd_inverse<P>(lam, sig);
 #pragma unroll
             for (int p = 0; p < P; ++p) {              // Lam_k mu_k: the old natural parameter
@@ -1483,10 +1582,6 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                 for (int q = 0; q < P; ++q) t += lam[p][q] * mul[kk][q];
                 told[p] = t;
             }
-            // tr(Prec Sig) = tr(I) - tr(D Sig) = P - sum_p d_p Sig_pp: the same for every candidate
-            double tr = (double)P;
-#pragma unroll
-            for (int p = 0; p < P; ++p) tr = fma(-d[p], sig[p][p], tr);
 #pragma unroll
             for (int c = 0; c < NS; ++c) {
                 double nat[P], mun[P];
@@ -1501,7 +1596,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                         t = 0.0;
 #pragma unroll
                         for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
-                        if (!NOSTORE) {
+                        if (!NOSTORE && !MAXONLY) {
 #ifndef SNP_DIAG_NOSTORE                 // (diagnostic builds of profiles/microbench_snp.py only)
                             // no `if (live)`: a lane past the end works on a copy of SNP N-1 and
                             // stores the value that SNP's own lane stores, to the same place --
@@ -1514,90 +1609,112 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                     mun[p] = t;
                     quad += t * nat[p];
                 }
-                // mu^T Prec mu through Lam = Prec + D (D diagonal), Sig = Lam^-1:
-                //   mu^T Prec mu = mu^T Lam mu - sum_p d_p mu_p^2 = quad - sum_p d_p mu_p^2
-                // (2P+1 operations with tr above instead of 3P^2; the cancellation costs at most
-                // ~P eps absolute per (component, SNP) in terms that enter the ELBO additively
-                // next to O(1) neighbours)
-                double ip = quad;
-#pragma unroll
-                for (int p = 0; p < P; ++p) ip = fma(-d[p] * mun[p], mun[p], ip);
                 const double ak = 0.5 * quad + lhk;
-                amax[c] = fmax(amax[c], ak);
-                const double e = wk * exp(ak - shift[c]);
+                if (MAXONLY) {
+                    amax[c] = fmax(amax[c], ak);
+                    continue;
+                }
+                const double e = wk * pass_exp(ak - shift[c], expk);
                 Z[c] += e;
-                Skl[c] = fma(e, 0.5 * (quad + tr), Skl[c]);
-                Sip[c] = fma(e, ip, Sip[c]);
+                Sq[c] = fma(e, quad, Sq[c]);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     Sm[c][p] = fma(e, mun[p], Sm[c][p]);
-                    S2[c][p] = fma(e, sig[p][p] + mun[p] * mun[p], S2[c][p]);
+                    Smm[c][p] = fma(e, mun[p] * mun[p], Smm[c][p]);
+                    Ssig[c][p] = fma(e, sig[p][p], Ssig[c][p]);
                 }
                 if (STASH) stash[((k - kbeg) * NS + c) * SNP_THREADS + threadIdx.x] = e;
             }
         }
+        }
     };
 
+    const std::false_type all_sums{};
+    const std::true_type logit_max{};
     double invZ[NS], Zt[NS];
     for (int attempt = 0;; ++attempt) {
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
-            Z[c] = 0.0; Skl[c] = 0.0; Sip[c] = 0.0; amax[c] = NEG_INF;
+            Z[c] = 0.0; Sq[c] = 0.0;
 #pragma unroll
-            for (int p = 0; p < P; ++p) { Sm[c][p] = 0.0; S2[c][p] = 0.0; }
+            for (int p = 0; p < P; ++p) { Sm[c][p] = 0.0; Smm[c][p] = 0.0; Ssig[c][p] = 0.0; }
         }
         if (!FETCH_FIRST || attempt > 0) fetch(bufA, lhA, kbeg);
+        SNP_STAMP(1);
         for (int k0 = kbeg; k0 < kend; k0 += 2 * KB) {
             fetch(bufB, lhB, k0 + KB);         // past the end the clamped loads re-read component M-1
-            fold(bufA, lhA, k0);
+            fold(bufA, lhA, k0, all_sums);
             if (k0 + KB >= kend) break;        // wave-uniform
             fetch(bufA, lhA, k0 + 2 * KB);
-            fold(bufB, lhB, k0 + KB);
+            fold(bufB, lhB, k0 + KB, all_sums);
         }
-        // every wave publishes its part of the normaliser and its largest logit; every wave adds the
-        // four parts in wave order, so all of them hold the same Z and take the same decision
+        SNP_STAMP(2);
+        // every wave publishes its part of the normaliser; every wave adds the four parts in wave
+        // order, so all of them hold the same Z and take the same decision
         if (SNP_SPLIT == 4) {
 #pragma unroll
-            for (int c = 0; c < NS; ++c) {
-                zx_lds[((w * NS + c) * 2 + 0) * 64 + lane] = Z[c];
-                zx_lds[((w * NS + c) * 2 + 1) * 64 + lane] = amax[c];
-            }
+            for (int c = 0; c < NS; ++c) zx_lds[((w * NS + c) * 2 + 0) * 64 + lane] = Z[c];
             lds_barrier();
         }
         bool bad = false;
-        double amx[NS];
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
             double z = SNP_SPLIT == 4 ? zx_lds[((0 * NS + c) * 2 + 0) * 64 + lane] : Z[c];
-            double m = SNP_SPLIT == 4 ? zx_lds[((0 * NS + c) * 2 + 1) * 64 + lane] : amax[c];
 #pragma unroll
-            for (int ww = 1; ww < SNP_SPLIT; ++ww) {
-                z += zx_lds[((ww * NS + c) * 2 + 0) * 64 + lane];
-                m = fmax(m, zx_lds[((ww * NS + c) * 2 + 1) * 64 + lane]);
-            }
+            for (int ww = 1; ww < SNP_SPLIT; ++ww) z += zx_lds[((ww * NS + c) * 2 + 0) * 64 + lane];
             Zt[c] = z;
-            amx[c] = m;
-            const bool ok = z >= 1e-150 && z <= 1e150;               // false for NaN too
-            // a tile is redone at most once: with the exact maximum as the shift Z is in range
-            // unless the problem itself is not finite
-            bad = bad || (!ok && attempt == 0 && m > NEG_INF && m < -NEG_INF);
+            bad = bad || !(z >= 1e-150 && z <= 1e150);               // true for NaN too
         }
-        const bool retry = __builtin_amdgcn_ballot_w64(bad) != 0;     // the same in all four waves
+        // a tile is redone at most once: with the exact maximum as the shift Z is in range unless
+        // the problem itself is not finite
+        const bool retry = attempt == 0 && __builtin_amdgcn_ballot_w64(bad) != 0;   // the same in all four waves
         if (!retry) break;
-        if (SNP_SPLIT != 4) { // (experiment build: waves are independent)
+        // The largest logit of every candidate, from a pass over the tile that forms no exponentials
+        // and stores nothing (the running maximum used to ride along in the main loop: two
+        // operations per component and candidate for a tile in a million).
 #pragma unroll
-            for (int c = 0; c < NS; ++c) {
-                const bool ok = Zt[c] >= 1e-150 && Zt[c] <= 1e150;
-                if (!ok && amx[c] > NEG_INF && amx[c] < -NEG_INF) shift[c] = amx[c];
-            }
-            continue;
+        for (int c = 0; c < NS; ++c) amax[c] = NEG_INF;
+        fetch(bufA, lhA, kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * KB) {
+            fetch(bufB, lhB, k0 + KB);
+            fold(bufA, lhA, k0, logit_max);
+            if (k0 + KB >= kend) break;
+            fetch(bufA, lhA, k0 + 2 * KB);
+            fold(bufB, lhB, k0 + KB, logit_max);
+        }
+        if (SNP_SPLIT == 4) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) zx_lds[((w * NS + c) * 2 + 1) * 64 + lane] = amax[c];
+            lds_barrier();      // (also: every wave has read the Z parts, which the next round rewrites)
         }
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
+            double m = SNP_SPLIT == 4 ? zx_lds[((0 * NS + c) * 2 + 1) * 64 + lane] : amax[c];
+#pragma unroll
+            for (int ww = 1; ww < SNP_SPLIT; ++ww) m = fmax(m, zx_lds[((ww * NS + c) * 2 + 1) * 64 + lane]);
             const bool ok = Zt[c] >= 1e-150 && Zt[c] <= 1e150;
-            if (!ok && amx[c] > NEG_INF && amx[c] < -NEG_INF) shift[c] = amx[c];
+            if (!ok && m > NEG_INF && m < -NEG_INF) shift[c] = m;
         }
-        lds_barrier();                          // zx_lds and the stash are rewritten next round
+    }
+    SNP_STAMP(3);
+    // the sums the objective is written in, from the linear ones: with Lam = Prec + D (D diagonal)
+    // and Sig = Lam^-1,
+    //   sum e (quad + tr(Prec Sig)) / 2,  tr(Prec Sig) = P - sum_p d_p Sig_pp
+    //   sum e mu^T Prec mu,               mu^T Prec mu = quad - sum_p d_p mu_p^2
+    //   sum e (Sig_pp + mu_p^2)
+    // (the cancellations cost ~P eps of Z absolute, as they did term by term)
+    double Skl[NS], Sip[NS], S2[NS][P];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        double trs = (double)P * Z[c], ips = Sq[c];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            trs = fma(-d[p], Ssig[c][p], trs);
+            ips = fma(-d[p], Smm[c][p], ips);
+            S2[c][p] = Smm[c][p] + Ssig[c][p];
+        }
+        Skl[c] = 0.5 * (Sq[c] + trs);
+        Sip[c] = ips;
     }
 #pragma unroll
     for (int c = 0; c < NS; ++c) invZ[c] = 1.0 / Zt[c];
@@ -1641,6 +1758,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         }
         lds_barrier();                          // the stash is dead: it carries the hand-over now
     }
+    SNP_STAMP(4);
     // waves 1..3 hand their remaining sums to wave 0, which adds them in wave order
     if (SNP_SPLIT == 4 && w > 0) {
         double *dst = hand_lds + (w - 1) * NS * NACC * SNP_TILE + lane;
@@ -1656,6 +1774,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         }
     }
     if (SNP_SPLIT == 4) lds_barrier();
+    SNP_STAMP(5);
     if (SNP_SPLIT != 4 || w == 0) {
         // per-SNP results and the tile's contributions to the objective sums
         const bool owner = live;
@@ -1687,7 +1806,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                 if (owner) {
                     m_out[p * N64 + i] = m;
                     v_out[p * N64 + i] = v;
-                    pool_out[p * N64 + a.invperm[p * N64 + i]] = m / se[p];
+                    pool_out[p * N64 + pos[p]] = m / se[p];
                 }
                 vals[p] = owner ? m * adj[p] : 0.0;
                 vals[P + p] = owner ? sld[p] * v : 0.0;
@@ -1716,8 +1835,8 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
             if (owner) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    const double nw = mpost[p] * a.scal[p * N64 + i];
-                    const double od = q.snap_in[p * N64 + i];
+                    const double nw = mpost[p] * scal_t[p];
+                    const double od = snap_t[p];
                     const double df = fabs(nw - od);
                     dv[0] += (df <= 1e-6 + 1e-6 * fabs(od)) ? 0.0 : 1.0;
                     dv[1] += df;
@@ -1735,6 +1854,18 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
             }
         }
     }
+#if SNP_TRACE
+    SNP_STAMP(6);
+    if (lane == 0 && g_ld_trace != nullptr && (long long)blockIdx.x * 4 + w < g_ld_trace_cap) {
+        double *row = g_ld_trace + 12 * ((long long)blockIdx.x * 4 + w);
+        for (int j = 0; j < 7; ++j) row[j] = (double)stamp[j];
+        row[7] = (double)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xf);    // HW_REG_XCC_ID[3:0]
+        row[8] = (double)real0;
+        row[9] = (double)(long long)__builtin_amdgcn_s_memrealtime();
+        row[10] = (double)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));           // HW_REG_HW_ID
+        row[11] = 0.0;
+    }
+#endif
 }
 
 template <int P, bool BLEND, bool ONE_ANNOT, int NS>
@@ -1830,6 +1961,7 @@ template <int P, bool ONE_ANNOT, bool WRITE, int KS, bool MAT = false>
 __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     constexpr int SPW = 64 / KS;
     PRED_EXIT(a.pred);
+    const ExpConsts expk = exp_consts();
     const int N = a.N, M = a.M, A = a.A;
     const int64_t N64 = N;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1931,7 +2063,7 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
                 for (int q = 0; q < P; ++q) t += lam[p][q] * mu[u][q];
                 quad += mu[u][p] * t;
             }
-            delta[u] = fmax(wdet * exp(0.5 * quad + lhk - lse), 1e-100);
+            delta[u] = fmax(wdet * pass_exp(0.5 * quad + lhk - lse, expk), 1e-100);
         }
         if (WRITE) {
 #pragma unroll
