@@ -87,14 +87,16 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps, budget_s=150.0, scale_se=
     from threadpoolctl import threadpool_limits
     t_leg = time.perf_counter()
     cfg = dict(WORKLOADS[workload])
-    if cfg.get('kind', 'ar1') != 'ar1':
-        # the eigen-form synthetic workloads build their factors on the GPU; the baseline is
-        # quoted on the headline workload (C3) only
-        return {'value': None, 'unit': 'sweeps/s', 'cores': 0, 'kind': 'port',
-                'sample': 'not run: the CPU baseline is timed on AR(1) workloads (C2, C3, C5) only'}
+    lowrank = cfg.get('kind', 'ar1') != 'ar1'
     full = SyntheticShard(seed=seed, **cfg)
     n_blocks = max(1, min(len(full.sizes_all), int(round(block_frac * len(full.sizes_all)))))
-    sh = SyntheticShard(seed=seed, block_range=(0, n_blocks), **cfg).build(None)
+    # (the eigen-form workloads C4 / C4f build the sample's factors (U, s) on this process's GPU,
+    # as the timed run's loader did, and hand them to the CPU leg as host arrays: setup, not timed)
+    device = None
+    if lowrank:
+        import torch
+        device = torch.device('cuda', torch.cuda.current_device())
+    sh = SyntheticShard(seed=seed, block_range=(0, n_blocks), **cfg).build(device)
     P = sh.P
     # every core this process may USE: the affinity mask, cut by the cgroup's CPU quota (a GPU box
     # hands out one GPU's share of the host) and by the 64 threads this image's OpenBLAS was built
@@ -120,10 +122,15 @@ def cpu_baseline(workload, seed, block_frac, n_sweeps, budget_s=150.0, scale_se=
     threads = max(1, min(avail, quota or avail, 64))
     core_note = 'affinity mask %d, cgroup quota %s, OpenBLAS build limit 64' % (avail, quota or 'none')
     # setup (not timed): eigendecompose the sample's blocks, one LAPACK call per core
-    with threadpool_limits(limits=1), ThreadPoolExecutor(max_workers=threads) as pool:
-        ld = [BlockDiagonalLD(list(pool.map(lambda b: EigenBlock(ar1_numpy(b.n, b.rho[p]), 1.0),
-                                            sh.blocks)), perm=sh.perm, missing=sh.missing)
+    if lowrank:
+        ld = [BlockDiagonalLD([EigenBlock(u=U.cpu().numpy(), s=sv.cpu().numpy(), t=1.0)
+                               for U, sv in sh._eig[p]], perm=sh.perm, missing=sh.missing)
               for p in range(P)]
+    else:
+        with threadpool_limits(limits=1), ThreadPoolExecutor(max_workers=threads) as pool:
+            ld = [BlockDiagonalLD(list(pool.map(lambda b: EigenBlock(ar1_numpy(b.n, b.rho[p]), 1.0),
+                                                sh.blocks)), perm=sh.perm, missing=sh.missing)
+                  for p in range(P)]
     annotations = np.ones((sh.N, 1))
     vi = MultiPopVIOracle(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
                           annotations=annotations, mixture_covs=list(sh.covs), checkpoint=False,

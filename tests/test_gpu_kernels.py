@@ -244,7 +244,7 @@ def test_fused_eigen_product_ranks_and_two_right_hand_sides(rank_of):
     of the block and full: the operator against numpy, and a two-step trial (two right-hand sides
     in one pass over U) bit-identical to two one-step trials."""
     from vilma_amd.engine import HipEngine
-    sizes = [37, 400, 530, 1100, 2100]
+    sizes = [37, 400, 530, 1100, 2100, 3500]      # (3 500: the tall class, 512-thread workgroups)
     rng = np.random.default_rng(7)
     n_ld = sum(sizes)
     N, P, M = n_ld + 11, 2, 3
@@ -295,9 +295,11 @@ def test_fused_eigen_product_ranks_and_two_right_hand_sides(rank_of):
 @pytest.mark.parametrize('sizes', [[1, 2, 3], [127, 128, 129], [255, 256, 257], [300, 64, 700],
                                    [1000, 17], [511, 513, 512], [2431],
                                    # the fused eigen-form product holds 2, 4, 8 or 12 rows per
-                                   # thread (blocks up to 512, 1024, 2048, 3072 rows); taller
-                                   # blocks keep the two-pass kernels
-                                   [512, 513, 9], [1024, 1025], [2048, 2049], [3072, 5], [3073, 70]])
+                                   # thread (blocks up to 512, 1024, 2048, 3072 rows; up to 6 144
+                                   # with workgroups of 512 threads); taller blocks keep the
+                                   # two-pass kernels
+                                   [512, 513, 9], [1024, 1025], [2048, 2049], [3072, 5], [3073, 70],
+                                   [6144, 3], [6145, 4100]])
 def test_ld_matvec_block_sizes(sizes):
     """The symmetric (lower-triangle) dense kernel and the eigen-form kernels across slab
     boundaries: block sizes around multiples of 128, odd sizes, ragged mixes, perm + missing."""

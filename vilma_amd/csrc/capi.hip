@@ -10,7 +10,7 @@ namespace {
 
 void free_items(ItemSet &it) {
     dev_free(it.sym); dev_free(it.comb); dev_free(it.a); dev_free(it.row); dev_free(it.rcomb);
-    for (int k = 0; k < 4; ++k) dev_free(it.eig[k]);
+    for (int k = 0; k < 5; ++k) dev_free(it.eig[k]);
     dev_free(it.eig_all);
     dev_free(it.fcomb);
     it = ItemSet();
@@ -35,7 +35,7 @@ struct HostItems {
     std::vector<RowCombItem> rcomb;
     std::vector<EigenGroup> groups;
     int64_t group_bytes = 0;          // U bytes in the group being filled
-    std::vector<EigItem> eig[4];
+    std::vector<EigItem> eig[5];
     std::vector<RowCombItem> fcomb;
 };
 
@@ -183,9 +183,10 @@ int upload_items(vilma_ctx *c, HostItems &H, ItemSet &out) {
     sort_items(H, c->ld_order);
     out.groups = H.groups;
     std::vector<EigItem> eig_all;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 5; ++k) {
         if (upload_vec(c, H.eig[k], &out.eig[k], &out.n_eig[k])) return 1;
-        eig_all.insert(eig_all.end(), H.eig[k].begin(), H.eig[k].end());
+        // (the tall class needs workgroups of 512 threads: always a launch of its own)
+        if (k < 4) eig_all.insert(eig_all.end(), H.eig[k].begin(), H.eig[k].end());
     }
     std::stable_sort(eig_all.begin(), eig_all.end(), [](const EigItem &x, const EigItem &y) {
         return (int64_t)x.n * x.ncols > (int64_t)y.n * y.ncols;
@@ -333,6 +334,7 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
                     launch_ld_eig_fused(it.eig[k], it.n_eig[k], eig_class_rows(k), pl, pl2,
                                         c->sym_scratch, c->s_stride, s);
             }
+        launch_ld_eig_tall(it.eig[4], it.n_eig[4], pl, pl2, c->sym_scratch, c->s_stride, s);
         launch_ld_rowsum_combine(it.fcomb, it.n_fcomb, pl, pl2, c->sym_scratch, c->s_stride,
                                  c->dot_partials, c->dot_stride, s);
         for (const EigenGroup &g : it.groups) {

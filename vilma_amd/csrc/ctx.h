@@ -55,15 +55,15 @@ struct ItemSet {
     std::vector<EigenGroup> groups;
     // fused eigen-form product: one list per block-height class (rows per thread 2, 4, 8, 12) and
     // the combine items of all fused blocks
-    EigItem *eig[4] = {nullptr, nullptr, nullptr, nullptr};
-    int n_eig[4] = {0, 0, 0, 0};
+    EigItem *eig[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // by block-height class
+    int n_eig[5] = {0, 0, 0, 0, 0};
     EigItem *eig_all = nullptr;      // the same items in one list (largest first), for the
     int n_eig_all = 0;               // single-launch variant small shards use
     RowCombItem *fcomb = nullptr;
     int n_fcomb = 0;
 };
-inline int eig_class(int R) { return R == 2 ? 0 : R == 4 ? 1 : R == 8 ? 2 : 3; }
-inline int eig_class_rows(int k) { return k == 0 ? 2 : k == 1 ? 4 : k == 2 ? 8 : 12; }
+inline int eig_class(int R) { return R == 2 ? 0 : R == 4 ? 1 : R == 8 ? 2 : R == 12 ? 3 : 4; }
+inline int eig_class_rows(int k) { return k == 0 ? 2 : k == 1 ? 4 : k == 2 ? 8 : k == 3 ? 12 : 24; }
 inline int pad2(int n) { return (n + 1) & ~1; }
 // columns of U one workgroup of the fused product takes (a whole number of batches): about
 // g_eig_slab_elems elements (default 96 k = 768 KB) of U per workgroup, at most EIG_SLAB_MAX_COLS

@@ -248,6 +248,7 @@ void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *poo
                               int dot_stride, hipStream_t s);
 
 // Fused eigen-form product on column-major U (see EigItem).  eig_rows_per_thread(n): 2, 4, 8, 12,
+// 24 (= 12 rows per thread of a 512-thread workgroup: blocks of 3 073 .. 6 144 rows, launch_ld_eig_tall)
 // or 0 = block too tall (two-pass kernels); columns are taken eig_batch_cols(R) at a time.
 int eig_rows_per_thread(int n);
 int eig_batch_cols(int R);
@@ -255,6 +256,8 @@ int eig_batch_cols(int R);
 void launch_ld_eig_fused(const EigItem *items, int n_items, int R, const double *pool0,
                          const double *pool1, double *scratch, int64_t s_stride, hipStream_t s);
 // the class of blocks of up to 512 rows (R = 2): one WAVE per slab of columns, no barrier
+void launch_ld_eig_tall(const EigItem *items, int n_items, const double *pool0, const double *pool1,
+                        double *scratch, int64_t s_stride, hipStream_t s);
 void launch_ld_eig_wave(const EigItem *items, int n_items, const double *pool0, const double *pool1,
                         double *scratch, int64_t s_stride, hipStream_t s);
 // the items of every class in one launch (small shards: one ramp and tail instead of four)

@@ -798,27 +798,31 @@ void launch_ld_rowsum_combine(const RowCombItem *items, int n_items, double *poo
 // in order.  Workgroups never wait for each other; summation orders are fixed.
 // --------------------------------------------------------------------------------------------
 #define EIG_THREADS 256
-#define EIG_MAX_ROWS (EIG_THREADS * 12)     // tallest block the fused kernel takes (R = 12)
+#define EIG_TALL_THREADS 512                // blocks of 3 073 .. 6 144 rows: twice the threads, R = 12
+#define EIG_MAX_ROWS (EIG_TALL_THREADS * 12)     // tallest block the fused kernels take
 
-int eig_rows_per_thread(int n) {            // 2, 4, 8, 12, or 0: too tall, two-pass kernels
+// rows per thread: 2, 4, 8, 12 (256 threads); 24 = the tall class (12 rows per thread of 512); or
+// 0: too tall, two-pass kernels
+int eig_rows_per_thread(int n) {
     if (n <= 2 * EIG_THREADS) return 2;
     if (n <= 4 * EIG_THREADS) return 4;
     if (n <= 8 * EIG_THREADS) return 8;
-    if (n <= EIG_MAX_ROWS) return 12;
+    if (n <= 12 * EIG_THREADS) return 12;
+    if (n <= EIG_MAX_ROWS) return 24;
     return 0;
 }
 int eig_batch_cols(int R) { return R <= 2 ? 8 : (R <= 4 ? 4 : 2); }
 
 #define EIG_RED_SLOTS 16                      // values per batch, at most (R = 2, two right-hand sides)
-template <int R, int NR>
+template <int R, int NR, int T = EIG_THREADS>
 static __device__ __forceinline__ void eig_fused_body(
     const EigItem &it, const PoolPair &pools, double *__restrict__ scratch, int64_t s_stride,
-    double (&red)[2][EIG_THREADS / 64][EIG_RED_SLOTS]) {
+    double (&red)[2][T / 64][EIG_RED_SLOTS]) {
     constexpr int H = R / 2;                       // 16-byte loads per column per thread
     constexpr int C = R <= 2 ? 8 : (R <= 4 ? 4 : 2);   // columns per batch: <= 12 loads in flight
     constexpr int V = C * NR;                      // values reduced per batch
     constexpr int G = (V + 7) / 8;                 // butterflies per batch
-    constexpr int NW = EIG_THREADS / 64;
+    constexpr int NW = T / 64;
     const int n = it.n, ncols = it.ncols;
     const int64_t ldc = it.ldc;
     const int lane = threadIdx.x & 63;
@@ -830,7 +834,7 @@ static __device__ __forceinline__ void eig_fused_body(
         const double *xg = pools.p[r] + it.x_off;
 #pragma unroll
         for (int i = 0; i < H; ++i) {
-            const int row = row0 + 512 * i;
+            const int row = row0 + 2 * T * i;
             x[r][2 * i] = row < n ? xg[row] : 0.0;
             x[r][2 * i + 1] = row + 1 < n ? xg[row + 1] : 0.0;
             y[r][2 * i] = y[r][2 * i + 1] = 0.0;
@@ -844,7 +848,7 @@ static __device__ __forceinline__ void eig_fused_body(
     // vmcnt(0) -- for the NEXT batch too -- before it touches this one.
     int roff[H];
 #pragma unroll
-    for (int i = 0; i < H; ++i) roff[i] = min(row0 + 512 * i, (int)ldc - 2);
+    for (int i = 0; i < H; ++i) roff[i] = min(row0 + 2 * T * i, (int)ldc - 2);
     // eigenvalue factors: wave-uniform, written at load time only -> scalar loads.  As vector loads
     // they share vmcnt with the stream, and waiting for one of them is waiting for the next batch.
     const const_tab scale_tab = as_table(it.scale);
@@ -913,7 +917,7 @@ static __device__ __forceinline__ void eig_fused_body(
         double *so = scratch + r * s_stride + it.s_off;
 #pragma unroll
         for (int i = 0; i < H; ++i) {
-            const int row = row0 + 512 * i;
+            const int row = row0 + 2 * T * i;
             // (write-through, like ld_sym_kernel's partial sums: see LD_PARTIAL_STORE; row is even
             // and so is the record's offset)
             if (row + 1 < n) LD_PARTIAL_STORE2(&so[row], y[r][2 * i], y[r][2 * i + 1]);
@@ -1068,6 +1072,36 @@ __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_kernel(
     if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const EigItem it = items[blockIdx.x];
     eig_fused_body<R, NR>(it, pools, scratch, s_stride, red);
+}
+
+// The tall class (3 073 .. 6 144 rows): the same body with 512 threads, 12 rows each, so U is read
+// once here too (228 registers with two right-hand sides: two waves per SIMD, which 512 threads
+// are).  Taller blocks still take the two-pass kernels.
+template <int NR>
+__global__ __launch_bounds__(EIG_TALL_THREADS) void ld_eig_tall_kernel(
+    const EigItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
+    int64_t s_stride, const int *pred, const PhasePtrs *pp) {
+    __shared__ double red[2][EIG_TALL_THREADS / 64][EIG_RED_SLOTS];
+    PRED_EXIT(pred);
+    PoolPair pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
+    const EigItem it = items[blockIdx.x];
+    eig_fused_body<12, NR, EIG_TALL_THREADS>(it, pools, scratch, s_stride, red);
+}
+
+void launch_ld_eig_tall(const EigItem *items, int n_items, const double *pool0, const double *pool1,
+                        double *scratch, int64_t s_stride, hipStream_t s) {
+    if (n_items <= 0) return;
+    PoolPair pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    const dim3 grid(n_items), block(EIG_TALL_THREADS);
+    if (pool1)
+        hipLaunchKernelGGL((ld_eig_tall_kernel<2>), grid, block, 0, s, items, pp, scratch, s_stride,
+                           g_pred, g_phase);
+    else
+        hipLaunchKernelGGL((ld_eig_tall_kernel<1>), grid, block, 0, s, items, pp, scratch, s_stride,
+                           g_pred, g_phase);
 }
 
 // All classes in one launch: the item says how many rows per thread its block needs.  Every class

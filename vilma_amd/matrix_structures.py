@@ -85,7 +85,7 @@ def dense_bytes_moved(n):
 # fused kernel runs at ~0.85 of the dense kernel's rate (workload C4, one right-hand side: 5.2-5.8
 # TB/s per block-height class against 6.2 TB/s; r02q: all-eigen 432 sweeps/s, all-dense 331).
 EIGEN_FORM_PENALTY = 1.2
-EIGEN_FUSED_MAX_ROWS = 3072          # csrc/kernels.hip EIG_MAX_ROWS
+EIGEN_FUSED_MAX_ROWS = 6144          # csrc/kernels.hip EIG_MAX_ROWS (512 threads x 12 rows)
 
 
 def _eigen_passes(n):
