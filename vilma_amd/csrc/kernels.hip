@@ -811,6 +811,10 @@ int eig_rows_per_thread(int n) {
     if (n <= EIG_MAX_ROWS) return 24;
     return 0;
 }
+// (Measured and not adopted, round 4: batches of 4 / 4 / 2 / 1 columns with a register budget of
+// three workgroups per CU for the one-launch kernel -- 126 / 168 registers instead of 174 / 230:
+// C4 0.572 / 0.566 ms per product against 0.603 / 0.567, C4f 0.521 / 0.551 against 0.517 / 0.526,
+// alternating on one box: inside the spread between processes.  gpurun_out/r04w.)
 int eig_batch_cols(int R) { return R <= 2 ? 8 : (R <= 4 ? 4 : 2); }
 
 #define EIG_RED_SLOTS 16                      // values per batch, at most (R = 2, two right-hand sides)
