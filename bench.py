@@ -53,14 +53,16 @@ def parse():
                          'runs whenever a sweep gains less than EM_TOL); the config string says so')
     ap.add_argument('--cpu-frac', type=float, default=None,
                     help='fraction of the workload\'s LD blocks in the CPU-baseline sample '
-                         '(default: 0.25; 0.02 for C5, whose sweep is ~25x C3\'s on the CPU)')
-    ap.add_argument('--cpu-sweeps', type=int, default=8,
+                         '(default: 0.10 -- about 10 s of timed CPU sweeps at C3 after ~40 - 70 s of '
+                         'untimed setup, eigendecompositions and the ridge start of the sample; '
+                         '0.02 for C5, whose sweep is ~25x C3\'s on the CPU)')
+    ap.add_argument('--cpu-sweeps', type=int, default=12,
                     help='sweeps of the CPU baseline (fewer if --cpu-budget runs out first)')
     ap.add_argument('--cpu-budget', type=float, default=150.0,
                     help='seconds the whole CPU-baseline leg may take (sample setup included): '
-                         'the timed loop stops after the sweep during which the budget runs out '
-                         '(at least 2 sweeps) and the in-run GPU-vs-CPU comparison of the sample '
-                         'is skipped when less than a fifth of it is left')
+                         'the timed loop stops after the sweep during which 60 %% of the budget is '
+                         'gone (at least 2 sweeps) and the in-run GPU-vs-CPU comparison of the '
+                         'sample is skipped when less than a fifth of it is left')
     ap.add_argument('--prof-every', type=int, default=0,
                     help='bracket every k-th LD product with HIP events (roofline.avg_launch_ms); '
                          'default: every product on 1 GPU, every 8th on a sharded run, where the '
@@ -515,7 +517,7 @@ def main():
             'algorithmic_bytes_per_launch': r['ld_algorithmic_bytes']}
     if world == 1 and not args.no_cpu_baseline and not rehearsal:
         try:
-            frac = args.cpu_frac if args.cpu_frac is not None else (0.02 if args.workload == 'C5' else 0.25)
+            frac = args.cpu_frac if args.cpu_frac is not None else (0.02 if args.workload == 'C5' else 0.10)
             out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, frac, args.cpu_sweeps,
                                                args.cpu_budget, args.learn_scaling)
         except Exception as exc:      # the GPU number stands on its own
