@@ -99,7 +99,7 @@ int vilma_ld_begin(vilma_ctx *ctx, int cohort, int n_blocks, int64_t n_ld, const
 /* Element counts to use in total_elems (rows are padded to a multiple of 16 doubles = 128 B so
  * that every 1-KiB wave load covers whole cache lines; dense blocks keep the lower triangle; an
  * eigen-form block keeps U once -- column-major with the column length rounded up to even for the
- * fused product, row-major for blocks of more than 3 072 SNPs -- and s:
+ * fused product, row-major for blocks of more than 6 144 SNPs -- and s:
  * pad2(n) * pad16(r) + pad16(r)). */
 int64_t vilma_ld_dense_elems(int n);
 int64_t vilma_ld_lowrank_elems(int n, int r);
@@ -112,7 +112,7 @@ int vilma_ld_add_dense(vilma_ctx *ctx, int cohort, int n, const double *R);
 
 /* Add the next block in eigen form: U [n*r] row-major (host or device), s [r];
  * dot = U (s * (U^T x)) (LowRankMatrix.dot, matrix_structures.py:148-152).  Only U and s are
- * stored.  Blocks of up to 3 072 SNPs keep U column-major and a product reads it ONCE (the fused
+ * stored.  Blocks of up to 6 144 SNPs keep U column-major and a product reads it ONCE (the fused
  * kernel holds a slab of columns in registers between the two uses); taller blocks keep it
  * row-major and read it twice (column sums, then row sums).  The call repacks; the caller's
  * layout is always row-major. */
@@ -330,9 +330,20 @@ typedef struct {
 } vilma_sweep_stats;
 
 #define VILMA_SWEEP_DIFF 1        /* fuse the convergence statistics into the sweep's last evaluation */
-#define VILMA_SWEEP_LOOKAHEAD 2   /* the caller promises to call vilma_sweep again: the next sweep
-                                     may be queued (and decided on the device) before this call
-                                     returns */
+#define VILMA_SWEEP_LOOKAHEAD 2   /* the caller promises to call vilma_sweep again: the sweep loop --
+                                     inner beta loop and its break rule, line-search retries, the
+                                     M-step, with scale_se the error-scaling update and its
+                                     re-evaluation -- is then decided by a kernel from a control
+                                     block on the device, for every mixture size, and work beyond
+                                     the state this call reports (at most ONE beta trial) may
+                                     already be on `stream` when it returns.  Results are the bits
+                                     of the same call without the flag.  The host replays every
+                                     decision with the same source and returns an error if the
+                                     two differ.  Ignored with VILMA_SWEEP_VERBOSE (per-update
+                                     events need the host in the loop) and with VILMA_LOOKAHEAD=0
+                                     in the environment.  A later call on a DIFFERENT stream first
+                                     waits for the queued work and restores the reported state
+                                     (as vilma_sweep_drain does) */
 #define VILMA_SWEEP_VETO 4        /* the sweep queued ahead by this call must not proceed if no
                                      posterior mean moved in THIS sweep (optimize() stops then,
                                      variational_inference.py:374-382): checked on the device */
@@ -375,7 +386,8 @@ int vilma_sweep_drain(vilma_ctx *ctx);
  * milliseconds and number of bracketed launches since the last reset (arrays of VILMA_PROF_KINDS). */
 #define VILMA_PROF_LD_SYM 0      /* ld_sym_kernel: symmetric dense blocks, lower triangle read once */
 #define VILMA_PROF_LD_EIG 1      /* ld_eig_fused_kernel: one product of the eigen-form blocks (the fused
-                                  * launches, the two-pass kernels of blocks over 3 072 SNPs, combine) */
+                                  * launches incl. the 512-thread one for 3 073 .. 6 144 SNPs, the
+                                  * two-pass kernels of taller blocks, combine) */
 #define VILMA_PROF_LD_SYM2 2     /* ld_sym_kernel with two right-hand sides (vilma_trial_beta2): one pass
                                   * over the store, two products */
 #define VILMA_PROF_SNP_EVAL 3    /* snp_pass_kernel of a plain evaluation */
