@@ -42,7 +42,7 @@ def test_mid_size_trajectory_with_inner_loops(lookahead):
         assert vi.n_stages_ahead >= 15 and vi.n_stages_skipped == 0
 
 
-@pytest.mark.parametrize('sums', ['stash', 'pass', 'lazy'])
+@pytest.mark.parametrize('sums', ['stash', 'pass', 'lazy', 'lazy-one-step'])
 def test_inner_loops_on_the_device_equal_host_decided_bit_for_bit(monkeypatch, sums):
     """The mid-size problem's 16 sweeps (inner beta loops of up to eight updates, rejected steps, a
     trial with both candidates rejected) decided on the device against the same fit with every
@@ -51,12 +51,15 @@ def test_inner_loops_on_the_device_equal_host_decided_bit_for_bit(monkeypatch, s
     candidate's responsibility sums: from the trial pass's on-chip stash (what M = 20 takes by
     itself); from a pass over the accepted candidate behind the decision (what mixtures beyond the
     stash take: forced here); and that pass behind LAZY trials, which store no vi_mu at all -- the
-    pass re-derives the accepted candidate from the trial's natural gradient and stores it."""
+    pass re-derives the accepted candidate from the trial's natural gradient and stores it (also
+    with one candidate per trial, VILMA_TWO_STEP=0: what more than two cohorts take)."""
     g = golden('traj_p2_mid.npz')
     # (the stash is switched off for the host-decided run too: the two ways of summing the same
     # responsibilities differ in the last bit, and that is not what is compared here)
     monkeypatch.setenv('VILMA_TILE_SUMS', '1' if sums == 'stash' else '0')
-    monkeypatch.setenv('VILMA_PIPE_LAZY', '1' if sums == 'lazy' else '0')
+    monkeypatch.setenv('VILMA_PIPE_LAZY', '1' if sums.startswith('lazy') else '0')
+    if sums == 'lazy-one-step':
+        monkeypatch.setenv('VILMA_TWO_STEP', '0')
 
     def run(lookahead):
         monkeypatch.setenv('VILMA_LOOKAHEAD', '1' if lookahead else '0')
