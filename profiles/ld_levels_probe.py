@@ -64,6 +64,33 @@ def time_ld(eng, x, y, iters):
     return ms / max(n, 1)
 
 
+def time_ld_two_rhs(eng, P, N, M, iters):
+    """ld_sym_kernel with two right-hand sides (the product of a two-step trial), by the library's
+    events; a small mixture keeps the per-SNP pass beside it short."""
+    import torch
+    from vilma_amd.synthetic import mixture_covs
+    rng = np.random.default_rng(1)
+    se = rng.uniform(0.005, 0.02, size=(P, N))
+    eng.set_snp_data(rng.normal(size=(P, N)) / se, se, 1.0 / se ** 2, np.ones((P, N)),
+                     np.zeros(N, dtype=np.int64))
+    covs = mixture_covs(P, M)
+    eng.set_mixture(np.linalg.inv(covs), np.linalg.slogdet(covs)[1])
+    eng.set_hyper(np.full((1, M), 1.0 / M))
+    eng.set_mu(rng.normal(size=(M, P, N)) * 1e-4)
+    eng.eval(); eng.accept(False)
+    for _ in range(3):
+        eng.trial2(1e-3, 5e-4)
+    torch.cuda.synchronize()
+    eng.prof_enable(True)
+    eng.prof_read(reset=True)
+    for _ in range(iters):
+        eng.trial2(1e-3, 5e-4)
+    torch.cuda.synchronize()
+    ms, n = eng.prof_read()['ld_sym_kernel_two_rhs']
+    eng.prof_enable(False)
+    return ms / max(n, 1)
+
+
 def analyse_trace(rows, label):
     """rows [n, 5]: start, end (100 MHz ticks), XCC id, bytes, core-clock cycles start to end."""
     rows = rows[rows[:, 1] > 0]
@@ -116,6 +143,8 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--workload', default='C3')
     ap.add_argument('--shard', type=int, default=1)
+    ap.add_argument('--two-rhs', action='store_true',
+                    help='only time the product with one and with two right-hand sides (any build)')
     ap.add_argument('--build-variants', action='store_true',
                     help='only build the diagnostic variants of the library next to it and exit: '
                          'libvilma_hip_trace.so (-DLD_TRACE=1) and the LD_STORE_MODE builds of '
@@ -138,6 +167,13 @@ def main():
         return
     import torch
     eng, x, y = build_engine(args.workload, args.shard)
+    if args.two_rhs:
+        one = time_ld(eng, x, y, args.iters)
+        two = time_ld_two_rhs(eng, x.shape[0], x.shape[1], 4, args.iters)
+        sms, sbytes = eng.stream_store(5)
+        print('library %s: ld_sym_kernel one right-hand side %.4f ms, two %.4f ms (ratio %.3f); bare read of '
+              'the store %.4f ms' % (os.environ.get('VILMA_HIP_LIB', 'default'), one, two, two / one, sms))
+        return
     alg, stored = eng.ld_bytes()
     print('store %.3f GB (algorithmic %.3f GB symmetric-half basis %.3f GB), library %s'
           % (stored / 1e9, alg / 1e9, alg / 2e9, os.environ.get('VILMA_HIP_LIB', 'default')))
