@@ -1407,12 +1407,13 @@ static __device__ __forceinline__ double tile_sum8(const double (&p)[8], int lan
     return sym_rowsum8(p, lane, row);
 }
 
-// Register budget: three waves per SIMD for up to two cohorts (168 VGPRs; the two-step trial with
-// the stash then spills 6 registers and still gains: C3 trial pass 0.54 -> 0.48 ms,
-// profiles/r03c_ab_snp_pass.txt); with the Cholesky of three or four cohorts that budget spills
-// dozens, so those keep two.
+// Register budget: three waves per SIMD up to four cohorts.  For up to two that is what the kernels
+// need anyway (92 - 128 VGPRs since round 4).  With the Cholesky of four cohorts the budget of 168
+// spills 10 - 16 registers (round 3: dozens, and two waves were better; after round 4's cheaper
+// arithmetic three are: C5 evaluation 3.34 -> 3.23 ms, trial 7.55 - 7.70 -> 7.26 - 7.40 ms, alternating
+// on one box, gpurun_out/r04G).
 #ifndef SNP_MIN_WAVES
-#define SNP_MIN_WAVES(P) ((P) <= 2 ? 3 : (P) <= 4 ? 2 : 1)
+#define SNP_MIN_WAVES(P) ((P) <= 4 ? 3 : 1)
 #endif
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
 // store of the wave to be acknowledged (vmcnt(0)): with the pass's vi_mu stores in flight that is
