@@ -7,15 +7,20 @@
 //                      matrix_structures.py:389-408).  HBM-streaming, 16-byte coalesced loads.
 //   ld_eig_fused_kernel  eigen-form blocks, y = U (s * (U^T x)) with U read once: a slab of columns
 //                      of the column-major U stays in registers between its two uses --
-//                      LowRankMatrix.dot (matrix_structures.py:148-152).  ld_colsum_kernel +
-//                      ld_rowsum_kernel: the same product in two passes over a row-major U, for
-//                      blocks too tall for the fused kernel (> 3 072 SNPs).
+//                      LowRankMatrix.dot (matrix_structures.py:148-152); ld_eig_wave_kernel
+//                      (blocks up to 512 SNPs, a wave per slab) and ld_eig_tall_kernel (3 073 ..
+//                      6 144 SNPs, 512 threads) are the same product.  ld_colsum_kernel +
+//                      ld_rowsum_kernel: two passes over a row-major U, for blocks too tall for
+//                      the fused kernels (> 6 144 SNPs).
 //   snp_pass_kernel    fused per-SNP pass: natural-gradient blend, new_mu, mixture
-//                      responsibilities (online softmax), posterior moments, KL and likelihood
-//                      partial sums -- replaces numerics.py:11-146, 179-213 and
-//                      variational_inference.py:762-823, 873-885 for one candidate point.
+//                      responsibilities (softmax against a fixed shift), posterior moments, KL and
+//                      likelihood partial sums, the M-step's responsibility sums -- replaces
+//                      numerics.py:11-146, 179-213 and variational_inference.py:762-823, 873-885
+//                      for one or two candidate points.
 //   delta_kernel       responsibilities of a state reduced per annotation (numerics.py:118-129)
-//                      or written out;  mstep_kernel: the M-step table from those sums.
+//                      or written out; with MAT the accepted candidate of a lazy trial re-derived
+//                      and stored on the way.  mstep_kernel: the M-step table from those sums.
+//   sweep_decide_kernel  the decisions of the sweep loop on the device (decide.h).
 //   finalize / reduce / mean_diff   deterministic fixed-order reductions of per-workgroup
 //                      partials and the convergence statistics.  No atomics anywhere.
 //
