@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Seeded random problems across the kernel template space, each fitted twice -- every decision of
+the sweep loop on the device (the default when sweeps are promised ahead) and on the host side of the
+library (VILMA_LOOKAHEAD=0) -- and compared after every sweep: ELBO, L, error_scaling bit for bit,
+convergence statistics bit for bit (to rounding with --learn-scaling: two summation orders), the
+final vi_mu and hyper_delta bit for bit.  The library itself raises if a device decision ever
+differs from the host's replay of it.
+
+    python profiles/fuzz_device_vs_host.py [--seeds 120] [--first 0] [--sweeps 12]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seeds', type=int, default=120)
+    ap.add_argument('--first', type=int, default=0)
+    ap.add_argument('--sweeps', type=int, default=12)
+    args = ap.parse_args()
+    from test_gpu_edge_cases import _problem, _build
+    pool = [1, 2, 5, 31, 64, 127, 128, 129, 200, 255, 256, 257, 300, 513]
+    bad, handed, t0 = 0, 0, time.time()
+    for seed in range(args.first, args.first + args.seeds):
+        rng = np.random.default_rng(77000 + seed)
+        P = int(rng.choice([1, 2, 2, 3, 4, 5]))
+        M = int(rng.choice([2, 3, 7, 12, 33, 70, 130, 582] if P <= 2 else [2, 3, 7, 12, 33, 81]))
+        A = int(rng.integers(1, 4))
+        sizes = [[int(v) for v in rng.choice(pool, size=int(rng.integers(1, 5)))] for _ in range(P)]
+        N = max(sum(s) for s in sizes) + int(rng.integers(0, 9))
+        scale_se, scaled = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        pr = _problem(rng, P, sizes, N=N, M=M, A=A, ldthresh=float(rng.choice([1.0, 0.7])),
+                      empty_annot=bool(rng.integers(0, 2)))
+        label = 'seed %d: P=%d M=%d A=%d N=%d scaled=%d learn_scaling=%d' % (seed, P, M, A, N, scaled, scale_se)
+
+        def run(lookahead):
+            os.environ['VILMA_LOOKAHEAD'] = '1' if lookahead else '0'
+            vi = _build(pr, 'product', scale_se=scale_se, scaled=scaled)
+            np.random.seed(3)
+            vi._initialize()
+            state, trace = None, []
+            for k in range(args.sweeps):
+                state, stats = vi.sweep(state, lookahead=k + 1 < args.sweeps)
+                trace.append((state['elbo'], tuple(state['L']), tuple(stats), tuple(vi.error_scaling)))
+            params = vi._params()
+            out = (trace, params[0].copy(), params[2].copy(), vi.n_trials, vi.n_stages_ahead,
+                   vi.n_stages_skipped)
+            vi.engine.close()
+            return out
+        try:
+            host, dev = run(False), run(True)
+            ok = True
+            for d, h in zip(dev[0], host[0]):
+                ok &= d[0] == h[0] and d[1] == h[1] and d[3] == h[3] and d[2][0] == h[2][0]
+                ok &= bool(np.allclose(d[2], h[2], rtol=1e-12, atol=0)) if scale_se else d[2] == h[2]
+            ok &= np.array_equal(dev[1], host[1]) and np.array_equal(dev[2], host[2]) and dev[3] == host[3]
+            handed += dev[5]
+            if not ok:
+                bad += 1
+                print('MISMATCH', label, flush=True)
+            elif seed % 10 == 0:
+                print('ok', label, 'decided on the device:', dev[4], 'handed back:', dev[5],
+                      '(%.0f s)' % (time.time() - t0), flush=True)
+        except Exception as exc:
+            bad += 1
+            print('ERROR', label, repr(exc)[:300], flush=True)
+    print('%d problems, %d mismatches or errors, %d stages handed back to the host, %.0f s'
+          % (args.seeds, bad, handed, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
