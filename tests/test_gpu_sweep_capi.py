@@ -136,9 +136,12 @@ def test_vilma_sweep_reproduces_the_reference_trajectories(name):
     fit.close()
 
 
-def test_line_search_failure_is_the_reference_error():
+@pytest.mark.parametrize('flags', [0, 2], ids=['host-decided', 'queued-ahead'])
+def test_line_search_failure_is_the_reference_error(flags):
     """A NaN objective makes every comparison false: the search backs off until L > L_MAX and
-    reports the reference's message (variational_inference.py:790-799)."""
+    reports the reference's message (variational_inference.py:790-799) -- also when the sweep was
+    promised ahead (VILMA_SWEEP_LOOKAHEAD): the device rejects step after step, gives up beyond
+    L_MAX, and the host's line search, taking over where the device stood, raises the error."""
     from vilma_amd import _lib
     g = golden('traj_p1_dense.npz')
     fit = CFit(g)
@@ -154,7 +157,7 @@ def test_line_search_failure_is_the_reference_error():
     assert not np.isfinite(obj.value)
     L = np.ones(5)
     elbo, running = C.c_double(obj.value), C.c_double(float('nan'))
-    rc = lib.vilma_sweep(ctx, None, _p(L), C.byref(elbo), C.byref(running), 2.0, 0, None)
+    rc = lib.vilma_sweep(ctx, None, _p(L), C.byref(elbo), C.byref(running), 2.0, flags, None)
     assert rc != 0
     assert b'Encountered a numerical error.' in lib.vilma_last_error(ctx)
     fit.close()
