@@ -194,7 +194,8 @@ int vilma_trial_beta(vilma_ctx *ctx, void *stream, double step, double *totals_d
  * right-hand side rides in the same loads), so a rejected first step no longer costs a second
  * pass over the LD store.  Each candidate's sums are bit-identical to vilma_trial_beta's at its
  * step.  Candidate A is held as the trial state exactly as after vilma_trial_beta(step_a);
- * candidate B is accepted with vilma_accept(ctx, 2). */
+ * candidate B is accepted with vilma_accept(ctx, 2).  Up to four cohorts (the per-SNP kernels of
+ * five to eight evaluate one candidate per pass): an error beyond. */
 int vilma_trial_beta2(vilma_ctx *ctx, void *stream, double step_a, double step_b,
                       double *totals_a_dev, double *totals_b_dev);
 

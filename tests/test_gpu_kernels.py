@@ -229,6 +229,19 @@ def test_errors_are_loud():
     from vilma_amd.engine import HipEngine
     with pytest.raises(_lib.VilmaHipError):
         HipEngine(9, 10, 3, 1)              # more than 8 cohorts: unsupported
+    eng = HipEngine(5, 8, 3, 1)             # five cohorts: one candidate per trial only
+    eng.set_snp_data(np.ones((5, 8)), np.ones((5, 8)), np.ones((5, 8)), np.ones((5, 8)),
+                     np.zeros(8, dtype=np.int32))
+    eng.set_mixture(np.stack([np.eye(5), 2 * np.eye(5), 3 * np.eye(5)]), np.zeros(3))
+    eng.set_hyper(np.full((1, 3), 1 / 3))
+    for p in range(5):
+        eng.load_ld(p, [('dense', np.eye(8))], np.arange(8, dtype=np.int64), 8)
+    eng.set_mu(np.zeros((3, 5, 8)))
+    eng.eval(); eng.accept(False)
+    eng.trial(0.5)
+    with pytest.raises(_lib.VilmaHipError, match='up to four cohorts'):
+        eng.trial2(0.5, 0.25)
+    eng.close()
     eng = HipEngine(1, 10, 3, 1)
     with pytest.raises(_lib.VilmaHipError):
         eng.eval()                          # LD not loaded

@@ -413,6 +413,9 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     if (blend && !queued && !c->have_moments)
         return fail(c, "vilma_trial_beta needs an accepted evaluation of the current state");
     const bool two = blend && totals2_dev != nullptr;
+    if (two && c->P > 4)
+        return fail(c, "two candidates per beta trial are built for up to four cohorts (the kernels of "
+                       "five to eight evaluate one)");
     SnpKernelArgs a;
     fill_snp_args(c, a, step);
     a.step2 = step2;

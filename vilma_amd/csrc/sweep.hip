@@ -212,7 +212,8 @@ SweepState *sweep_state(vilma_ctx *c) {
     const char *two = std::getenv("VILMA_TWO_STEP");
     // Two steps per beta trial pay where the LD product dominates a trial (P <= 2); at P = 4 the
     // second candidate's per-SNP work outweighs the saved products (profiles/r02h_ab_twostep.txt)
-    s->two_step = (two && (two[0] == '0' || two[0] == '1')) ? two[0] == '1' : c->P <= 2;
+    // (VILMA_TWO_STEP=1 is honoured up to four cohorts: beyond that the kernels evaluate one candidate)
+    s->two_step = (two && (two[0] == '0' || two[0] == '1')) ? (two[0] == '1' && c->P <= 4) : c->P <= 2;
     c->sw = s;
     return s;
 }
