@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0   # measured copy ceiling on MI355X (same guide, HBM section)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50,
@@ -72,7 +72,7 @@ def parse():
                          '(no collectives; NOT a valid bench line)')
     ap.add_argument('--emulate-rank', type=int, default=0,
                     help='with --emulate-shard K: which rank\'s shard to time (default 0)')
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def cpu_baseline(workload, seed, block_frac, n_sweeps, budget_s=150.0, scale_se=False):
@@ -250,8 +250,12 @@ def relaunch_under_torchrun(args):
     raise SystemExit(subprocess.call(cmd))
 
 
-def main():
-    args = parse()
+def main(argv=None, engine_factory=None):
+    """`engine_factory` is for tests/bench_rehearsal.py only: a CPU test engine with HipEngine's
+    interface, to rehearse N ranks' protocol and the fields of the JSON line without a GPU (over
+    gloo).  Such a line says REHEARSAL in `metric` and measures nothing.  No environment variable
+    or flag of this program selects an engine: run as `python bench.py`, it is always HipEngine."""
+    args = parse(argv)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(args)
     import torch
@@ -266,12 +270,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    # rehearsal knobs (tests only): several ranks on one GPU over gloo; or -- VILMA_BENCH_ENGINE=
-    # "module:Class" -- the whole launch line without any GPU on a CPU test engine with HipEngine's
-    # interface (tests/oracle_engine.py), to rehearse N ranks' protocol and the fields of the JSON
-    # line on the CPU.  Such a line says REHEARSAL in `metric` and measures nothing.
-    engine_spec = os.environ.get('VILMA_BENCH_ENGINE')
-    rehearsal = bool(engine_spec)
+    # rehearsal knobs (tests only): several ranks on one GPU over gloo
+    rehearsal = engine_factory is not None
+    engine_spec = getattr(engine_factory, '__name__', 'test engine') if rehearsal else None
     if os.environ.get('VILMA_BENCH_SAME_DEVICE') == '1':
         local_rank = 0
     backend = os.environ.get('VILMA_BENCH_BACKEND', 'gloo' if rehearsal else 'nccl')
@@ -311,10 +312,7 @@ def main():
     shard.finish_init(inv_se2)
 
     if rehearsal:
-        import importlib
-        sys.path.insert(0, os.path.join(ROOT, 'tests'))
-        mod, cls = engine_spec.split(':')
-        engine = getattr(importlib.import_module(mod), cls)(P, shard.N, M, 1)
+        engine = engine_factory(P, shard.N, M, 1)
     else:
         engine = HipEngine(P, shard.N, M, 1)
     engine.set_snp_data(shard.adj, shard.se, shard.sld, shard.scalings, shard.annot)
@@ -406,9 +404,44 @@ def main():
                            for form, n, r in (shard.block_specs(args.ld_form, p)
                                               if shard.kind == 'lowrank' else shard.block_specs()))
     survey_launch = float(shard.ld_bytes)                # 8 n^2 dense, 8 n r eigen
+    specs_all = [sp for p in range(P) for sp in (shard.block_specs(args.ld_form, p)
+                                                  if shard.kind == 'lowrank' else shard.block_specs())]
+    alg_dense = 8.0 * sum(n * (n + 1) / 2 for form, n, r in specs_all if form == 'dense')
+    alg_eig = 8.0 * sum(n * r for form, n, r in specs_all if form != 'dense')
     avg_ms = kernel_ms / max(launches, 1)
     achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     state_bytes = 8.0 * shard.N * (2 * M * P)            # per-SNP pass: read mu, write mu'
+
+    # Every hot kernel of the sweep with its own algorithmic bytes and fraction of the HBM peak
+    # (an LD launch reads its store once whatever the number of right-hand
+    # sides; a per-SNP pass reads vi_mu [M][P][N] once and writes one array per candidate it stores;
+    # the sums pass behind a lazy trial reads it and writes the accepted candidate).  All kinds are
+    # bracketed on the same sampling tick, so launches_k / sampled products = launches of kind k
+    # per LD product, and the sweep's algorithmic bytes follow from the exact product count.
+    mp_bytes = 8.0 * shard.N * M * P
+    kinds = [('ld_sym_kernel<1>', 'ld_sym_kernel', alg_dense),
+             ('ld_sym_kernel<2>', 'ld_sym_kernel_two_rhs', alg_dense),
+             ('ld_eig_fused_kernel', 'ld_eig_fused_kernel', alg_eig),
+             ('snp_pass_eval', 'snp_pass_eval', mp_bytes),
+             ('snp_pass_trial', 'snp_pass_trial', 2 * mp_bytes),
+             ('snp_pass_trial2', 'snp_pass_trial2', 3 * mp_bytes),
+             ('snp_pass_trial_lazy', 'snp_pass_trial_lazy', mp_bytes),
+             ('snp_pass_trial2_lazy', 'snp_pass_trial2_lazy', mp_bytes),
+             ('delta_kernel (sums pass)', 'sums_pass', mp_bytes),
+             ('delta_kernel<MAT> (re-derive + store + sums)', 'sums_pass_store', 2 * mp_bytes)]
+    kernel_rows = []
+    for name, key, nbytes in kinds:
+        ms_k, n_k = prof.get(key, (0.0, 0))
+        if not n_k:
+            continue
+        gbps = nbytes / (ms_k / n_k * 1e-3) / 1e9
+        kernel_rows.append({'name': name, 'algorithmic_bytes': nbytes, 'avg_ms': ms_k / n_k,
+                            'launches': int(n_k), 'GBps': gbps, 'frac': gbps / HBM_PEAK_GBS})
+    sampled_products = sum(prof[k][1] for k in ('ld_sym_kernel', 'ld_sym_kernel_two_rhs')) or \
+        prof['ld_eig_fused_kernel'][1]
+    per_product = (sum(r['algorithmic_bytes'] * r['launches'] for r in kernel_rows) / sampled_products
+                   if sampled_products else 0.0)
+    sweep_bytes = per_product * n_prod / max(args.steps, 1)
 
     # HBM traffic of the dominant kernel: NOT measured in this run (PMC counters need their own
     # rocprofv3 passes); replayed from the committed PMC summary when it was taken on this very
@@ -491,9 +524,17 @@ def main():
             'avg_launch_ms_two_rhs': sym2[0] / sym2[1] if sym2[1] else None,
             'launches_two_rhs': int(sym2[1]),
             'sweep_algorithmic_GBps': (n_prod * (alg_launch + state_bytes)) / elapsed / 1e9,
+            # every hot kernel on its own algorithmic bytes; the whole sweep on the sum of what its
+            # kernels need (exact product count x the sampled mix of launches per product)
+            'kernels': kernel_rows,
+            'sweep_algorithmic_bytes': sweep_bytes,
+            'sweep_frac': (sweep_bytes / (elapsed / max(args.steps, 1)) / 1e9 / HBM_PEAK_GBS
+                           if elapsed > 0 else None),
             # the per-SNP passes, bracketed the same way
             'snp_pass_avg_ms': {k: prof[k][0] / prof[k][1] for k in
-                                ('snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2') if prof[k][1]},
+                                ('snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2',
+                                 'snp_pass_trial_lazy', 'snp_pass_trial2_lazy', 'sums_pass',
+                                 'sums_pass_store') if prof.get(k, (0, 0))[1]},
         },
     }
     out['collective'] = engine.collective

@@ -394,7 +394,13 @@ int vilma_sweep_drain(vilma_ctx *ctx);
 #define VILMA_PROF_SNP_EVAL 3    /* snp_pass_kernel of a plain evaluation */
 #define VILMA_PROF_SNP_TRIAL 4   /* ... of a one-step beta trial */
 #define VILMA_PROF_SNP_TRIAL2 5  /* ... of a two-step beta trial */
-#define VILMA_PROF_KINDS 6
+#define VILMA_PROF_SUMS 6        /* delta_kernel + its column reduction: the responsibility sums of the
+                                  * accepted candidate, for mixtures beyond the on-chip stash */
+#define VILMA_PROF_SUMS_MAT 7    /* the same pass behind a lazy trial: it also re-derives and stores the
+                                  * accepted candidate's vi_mu (read + write) */
+#define VILMA_PROF_SNP_TRIAL_LAZY 8   /* one-step beta trial that stores no candidate (lazy) */
+#define VILMA_PROF_SNP_TRIAL2_LAZY 9  /* two-step beta trial that stores no candidate (lazy) */
+#define VILMA_PROF_KINDS 10
 int vilma_prof_enable(vilma_ctx *ctx, int enable);
 int vilma_prof_read(vilma_ctx *ctx, double *ms_total, int64_t *launches, int reset);
 

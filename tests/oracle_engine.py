@@ -237,9 +237,10 @@ class OracleEngine:
         pass
 
     # ---- measurement hooks of HipEngine: nothing to measure here (bench.py's CPU rehearsal of
-    # the multi-rank launch line, VILMA_BENCH_ENGINE, still walks through them)
+    # the multi-rank launch line, tests/bench_rehearsal.py, still walks through them)
     PROF_KINDS = ('ld_sym_kernel', 'ld_eig_fused_kernel', 'ld_sym_kernel_two_rhs',
-                  'snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2')
+                  'snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2',
+                  'sums_pass', 'sums_pass_store', 'snp_pass_trial_lazy', 'snp_pass_trial2_lazy')
 
     def prof_enable(self, on=True, every=1):
         pass

@@ -434,7 +434,9 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
         c->prof_now = c->prof > 0 && (c->prof_tick % c->prof) == 0;
         prof_begin(c, s, e0);
         launch_snp_pass(a, blend, ns, s);
-        prof_end(c, s, e0, !blend ? VILMA_PROF_SNP_EVAL : two ? VILMA_PROF_SNP_TRIAL2 : VILMA_PROF_SNP_TRIAL);
+        prof_end(c, s, e0, !blend ? VILMA_PROF_SNP_EVAL
+                           : a.no_store ? (two ? VILMA_PROF_SNP_TRIAL2_LAZY : VILMA_PROF_SNP_TRIAL_LAZY)
+                           : two ? VILMA_PROF_SNP_TRIAL2 : VILMA_PROF_SNP_TRIAL);
     }
     // (a queued sweep puts nothing on the side stream: its sums are part of the finalize launch,
     // and an event between the pass and the LD product costs microseconds of stream time)
@@ -488,7 +490,14 @@ int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev
     fill_delta_args(c, a, c->delta_partials);
     a.mat = c->lazy_trial ? 1 : 0;       // behind a lazy trial the pass also stores the candidate
     set_launch_phase(&c->ctl->phase[VILMA_PHASE_SUMS]);
-    launch_delta_sums(a, sums_dev, s);
+    {
+        // bracketed on the tick of the LD product that follows, like the per-SNP pass
+        hipEvent_t e0;
+        c->prof_now = c->prof > 0 && (c->prof_tick % c->prof) == 0;
+        prof_begin(c, s, e0);
+        launch_delta_sums(a, sums_dev, s);
+        prof_end(c, s, e0, a.mat ? VILMA_PROF_SUMS_MAT : VILMA_PROF_SUMS);
+    }
     set_launch_phase(nullptr);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -634,7 +643,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     rc |= dev_alloc(c, &c->lh, (int64_t)A * M);
     rc |= dev_alloc(c, &c->counts, A);
     for (int s = 0; s < 3 && !rc; ++s) {
-        rc |= dev_alloc(c, &c->mu[s], (int64_t)M * PN);
+        rc |= dev_alloc(c, &c->mu[s], mu_buffer_elems(N, M, P));
         rc |= dev_alloc(c, &c->m[s], PN); rc |= dev_alloc(c, &c->v[s], PN);
         rc |= dev_alloc(c, &c->lse[s], N);
     }
@@ -930,12 +939,43 @@ int vilma_ld_matvec(vilma_ctx *c, void *stream, int cohort, const double *x, dou
     return 0;
 }
 
+// The vi_mu buffers may be laid out tile by tile (kernels.hip, MU_TILED); the caller's array is the
+// reference's [M][P][N].  Rows of it travel through a staging chunk on the device (a few rows of N
+// at a time: no buffer of the context is used as scratch, so a pending trial survives).
+static int mu_convert(vilma_ctx *c, double *buf, double *host, bool to_device) {
+    const int MP = c->M * c->P;
+    const int R = (int)std::max<int64_t>(1, std::min<int64_t>(MP, ((int64_t)8 << 20) / std::max<int64_t>(c->N, 1)));
+    double *stage = nullptr;
+    HIPCHK(c, hipMalloc((void **)&stage, (size_t)R * c->N * sizeof(double)));
+    int rc = 0;
+    for (int r0 = 0; r0 < MP && !rc; r0 += R) {
+        const int rows = std::min(R, MP - r0);
+        const size_t bytes = (size_t)rows * c->N * sizeof(double);
+        if (to_device) {
+            if (hipMemcpy(stage, host + (size_t)r0 * c->N, bytes, hipMemcpyDefault) != hipSuccess) { rc = 1; break; }
+            launch_mu_tile(buf, stage, c->N, MP, r0, rows, true, nullptr);
+            if (hipDeviceSynchronize() != hipSuccess) rc = 1;
+        } else {
+            launch_mu_tile(buf, stage, c->N, MP, r0, rows, false, nullptr);
+            if (hipDeviceSynchronize() != hipSuccess) { rc = 1; break; }
+            if (hipMemcpy(host + (size_t)r0 * c->N, stage, bytes, hipMemcpyDefault) != hipSuccess) rc = 1;
+        }
+    }
+    (void)hipFree(stage);
+    if (rc) return fail(c, "vi_mu layout conversion failed");
+    return 0;
+}
+
 int vilma_set_mu(vilma_ctx *c, const double *vi_mu) {
     if (!c) return 1;
     if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(c->mu[c->mu_cur], vi_mu, (size_t)c->M * c->P * c->N * sizeof(double),
-                        hipMemcpyDefault));
+    if (mu_is_tiled()) {
+        if (mu_convert(c, c->mu[c->mu_cur], const_cast<double *>(vi_mu), true)) return 1;
+    } else {
+        HIPCHK(c, hipMemcpy(c->mu[c->mu_cur], vi_mu, (size_t)c->M * c->P * c->N * sizeof(double),
+                            hipMemcpyDefault));
+    }
     c->have_moments = false;
     return 0;
 }
@@ -944,8 +984,12 @@ int vilma_get_mu(vilma_ctx *c, double *vi_mu) {
     if (!c) return 1;
     if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(vi_mu, c->mu[c->mu_cur], (size_t)c->M * c->P * c->N * sizeof(double),
-                        hipMemcpyDefault));
+    if (mu_is_tiled()) {
+        if (mu_convert(c, c->mu[c->mu_cur], vi_mu, false)) return 1;
+    } else {
+        HIPCHK(c, hipMemcpy(vi_mu, c->mu[c->mu_cur], (size_t)c->M * c->P * c->N * sizeof(double),
+                            hipMemcpyDefault));
+    }
     return 0;
 }
 

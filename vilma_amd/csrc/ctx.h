@@ -206,8 +206,8 @@ struct vilma_ctx {
                                     // the brackets of queued launches that turned out empty)
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[VILMA_PROF_KINDS] = {0, 0, 0, 0, 0, 0};
-    int64_t prof_launches[VILMA_PROF_KINDS] = {0, 0, 0, 0, 0, 0};
+    double prof_ms[VILMA_PROF_KINDS] = {};
+    int64_t prof_launches[VILMA_PROF_KINDS] = {};
 };
 
 namespace vilma_detail {

@@ -225,6 +225,11 @@ void set_launch_predicate(const int *flag);
 
 // ns = 2: a beta trial at the two step sizes a.step / a.step2, second candidate into the *2 outputs
 void launch_snp_pass(const SnpKernelArgs &a, bool blend, int ns, hipStream_t s);
+// The vi_mu buffers' layout in HBM (kernels.hip, MU_TILED): elements to allocate per buffer (>= M*P*N),
+// and the conversion between the reference's [M*P][N] array and that layout
+int64_t mu_buffer_elems(int64_t N, int M, int P);
+bool mu_is_tiled();
+void launch_mu_tile(double *buf, double *nat, int64_t N, int MP, int r0, int R, bool to_tiled, hipStream_t s);
 int snp_pass_grid(int64_t N);       // workgroups of the thread-per-SNP kernels (256 SNPs each)
 int snp_tile_grid(int64_t N);       // workgroups of launch_snp_pass (each loops over tiles of 64 SNPs) = rows of its partials
 // can launch_snp_pass deliver the responsibility sums of ns candidates (LDS stash fits)?

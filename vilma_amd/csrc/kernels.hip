@@ -148,6 +148,52 @@ static __device__ __forceinline__ void ld_store2_wt(double *p, double a, double 
 #else
 #define MU_STORE(p, v) (*(p) = (v))
 #endif
+// Layout of the vi_mu buffers in HBM.  The reference's array is [M][P][N] (SNP axis contiguous):
+// a wave that walks the components of its 64 SNPs then touches M*P rows 8 N bytes apart, 512 B in
+// each -- M*P DRAM pages and address translations per tile.  MU_TILED stores the same numbers tile
+// by tile, [ceil(N/64)][M][P][64]: the M*P pieces of a tile are one contiguous run of M*P*512 bytes,
+// every wave of the per-SNP kernels reads (and writes) a linear stream.  vilma_set_mu / vilma_get_mu
+// convert at the boundary (mu_tile_kernel), so nothing outside the kernels sees the difference.
+#ifndef MU_TILED
+#define MU_TILED 0
+#endif
+#define MU_TILE 64
+// elements between the same (SNP, cohort) of consecutive components / cohorts of one component
+#if MU_TILED
+#define MU_BASE(ii, M, P, N64) ((int64_t)((ii) >> 6) * ((int64_t)(M) * (P) * MU_TILE) + ((ii) & 63))
+#define MU_ROW(r, N64) ((int64_t)(r) * MU_TILE)
+#else
+#define MU_BASE(ii, M, P, N64) ((int64_t)(ii))
+#define MU_ROW(r, N64) ((int64_t)(r) * (N64))
+#endif
+// element (k, p) of SNP ii, given base = MU_BASE(ii, ...): base + MU_ROW(k * P + p, N64)
+int64_t mu_buffer_elems(int64_t N, int M, int P) {
+#if MU_TILED
+    return (N + MU_TILE - 1) / MU_TILE * MU_TILE * (int64_t)M * P;
+#else
+    return N * (int64_t)M * P;
+#endif
+}
+// rows [r0, r0 + R) of the natural [M*P][N] array (`nat`: a staging chunk [R][N]) <-> the buffer's
+// layout; to_tiled: nat -> buf (lanes past N fill the last tile with zeros), else buf -> nat
+__global__ __launch_bounds__(256) void mu_tile_kernel(double *__restrict__ buf, double *__restrict__ nat,
+                                                       int64_t N, int MP, int r0, int R, bool to_tiled) {
+    const int64_t npad = (N + MU_TILE - 1) / MU_TILE * MU_TILE;
+    const int64_t total = npad * R;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int rr = (int)(o / npad);
+        const int64_t i = o % npad;
+        double *b = buf + MU_BASE(i, MP, 1, N) + MU_ROW(r0 + rr, N);
+        if (to_tiled) *b = i < N ? nat[(int64_t)rr * N + i] : 0.0;
+        else if (i < N) nat[(int64_t)rr * N + i] = *b;
+    }
+}
+bool mu_is_tiled() { return MU_TILED != 0; }
+void launch_mu_tile(double *buf, double *nat, int64_t N, int MP, int r0, int R, bool to_tiled, hipStream_t s) {
+    const int64_t total = (N + MU_TILE - 1) / MU_TILE * MU_TILE * R;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(mu_tile_kernel, dim3(grid), dim3(256), 0, s, buf, nat, N, MP, r0, R, to_tiled);
+}
 // Predicated launches: when the host queues work ahead of a decision that a device kernel takes
 // (decide_kernel), every kernel of that work starts by reading the decision's flag and exits if
 // it is 0 -- mis-speculated work costs a few microseconds of empty launches and touches nothing.
@@ -1490,6 +1536,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     const int i = SNP_SPLIT == 4 ? blockIdx.x * 64 + lane : blockIdx.x * 256 + threadIdx.x;
     const bool live = i < N;
     const int ii = live ? i : N - 1;
+    const int64_t mu_base = MU_BASE(ii, M, P, N64);
 
     // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
     // buffered (see below).  A plain evaluation requests its first batch before anything else, so
@@ -1501,7 +1548,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
         for (int kk = 0; kk < KB; ++kk) {
             const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
 #pragma unroll
-            for (int p = 0; p < P; ++p) dst[kk][p] = MU_LOAD(&q.mu_in[((int64_t)kc * P + p) * N64 + ii]);
+            for (int p = 0; p < P; ++p) dst[kk][p] = MU_LOAD(&q.mu_in[mu_base + MU_ROW(kc * P + p, N64)]);
         }
     };
     double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
@@ -1646,7 +1693,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                             // stores the value that SNP's own lane stores, to the same place --
                             // cheaper than four exec-mask branches per component (C3 trial pass
                             // 0.48 -> 0.44 ms)
-                            MU_STORE(&mu_out[c][((int64_t)k * P + p) * N64 + ii], t);
+                            MU_STORE(&mu_out[c][mu_base + MU_ROW(k * P + p, N64)], t);
 #endif
                         }
                     }
@@ -2013,6 +2060,7 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     const int i = (blockIdx.x * (SNP_THREADS / 64) + w) * SPW + (lane % SPW);
     const bool live = i < N;
     const int ii = live ? i : N - 1;
+    const int64_t mu_base = MU_BASE(ii, M, P, N64);
     // the state: from the arguments, or -- behind a queued sweep's decision -- the one its EVAL
     // phase starts from (the candidate the decision accepted)
     const double *mu_state = a.mu, *lse_state = a.lse;
@@ -2057,7 +2105,7 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
         for (int u = 0; u < KD; ++u) {
             const int kc = min(k0 + u * KS, M - 1);       // unconditional loads; extras ignored
 #pragma unroll
-            for (int p = 0; p < P; ++p) dst[u][p] = MU_LOAD(&mu_state[((int64_t)kc * P + p) * N64 + ii]);
+            for (int p = 0; p < P; ++p) dst[u][p] = MU_LOAD(&mu_state[mu_base + MU_ROW(kc * P + p, N64)]);
         }
     };
     auto work = [&](double (&mu)[KD][P], int k0) {
@@ -2094,7 +2142,7 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
 #pragma unroll
                     for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
                     mu[u][p] = t;
-                    MU_STORE(&mu_mat[((int64_t)k * P + p) * N64 + ii], t);
+                    MU_STORE(&mu_mat[mu_base + MU_ROW(k * P + p, N64)], t);
                 }
             } else {
                 wdet = spd_rsqrt_det<P>(lam);
@@ -2394,7 +2442,7 @@ __global__ __launch_bounds__(SNP_THREADS) void init_state_kernel(const InitArgs 
             double t = 0.0;
 #pragma unroll
             for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
-            if (live) a.mu_out[((int64_t)k * P + p) * N64 + i] = t;
+            if (live) a.mu_out[MU_BASE(i, M, P, N64) + MU_ROW(k * P + p, N64)] = t;
         }
         if (ONE_ANNOT) {
             const double s = wave_sum(live ? delta : 0.0);
@@ -2481,7 +2529,7 @@ __global__ __launch_bounds__(SNP_THREADS) void snp_given_delta_kernel(const SnpK
                 lam[p][q] = pr[p][q];
             }
             lam[p][p] += d[p];
-            mu[p] = a.mu_in[((int64_t)k * P + p) * N64 + ii];
+            mu[p] = a.mu_in[MU_BASE(ii, a.M, P, N64) + MU_ROW(k * P + p, N64)];
         }
         const double wk = spd_inverse<P>(lam, sig);            // det(lam)^-1/2
         const double dl = delta_km[(int64_t)k * N64 + ii];

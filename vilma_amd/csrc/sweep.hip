@@ -607,8 +607,8 @@ int queue_decision(vilma_ctx *c, SweepState *s, hipStream_t st, int mode, bool v
 // group behind an arming -- the evaluation in front of it was the host's, its sums are reduced.
 int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fresh) {
     const bool two = s->two_step, stash = stash_sums(c, s);
-    // profiling brackets of this group: 4 tag (trial), 4 tag + 1 (sums, M-step, evaluation),
-    // 4 tag + 2 (re-evaluation)
+    // profiling brackets of this group: 4 tag (trial), 4 tag + 1 (M-step, evaluation),
+    // 4 tag + 2 (re-evaluation), 4 tag + 3 (sums pass)
     const int64_t tag = ++s->group_serial;
     int rc = 0;
     c->prof_tag = 4 * tag;
@@ -630,7 +630,9 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     if (!rc && !stash) {
         // (behind a lazy trial the pass runs on every accept: it is what stores the candidate)
         set_launch_predicate(&c->ctl->run_sums);
+        c->prof_tag = 4 * tag + 3;
         rc = queue_sums_phase(c, st, s->results + s->o_sa);
+        c->prof_tag = 4 * tag + 1;
         set_launch_predicate(nullptr);
         if (!rc && s->comm_kind) rc = comm_allreduce(c, s, st, s->results + s->o_sa, s->am, 0);
         set_launch_predicate(&c->ctl->run_eval);
@@ -958,6 +960,8 @@ int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, doubl
             if (rep.outcome == VILMA_OUT_ACCEPT_CONTINUE || rep.outcome == VILMA_OUT_REJECTED) {
                 prof_drop_tag(c, 4 * q.tag + 1);
                 prof_drop_tag(c, 4 * q.tag + 2);
+                // (the sums pass runs behind every accepted lazy trial: it is what stores the candidate)
+                if (rep.outcome == VILMA_OUT_REJECTED || !q.args.lazy) prof_drop_tag(c, 4 * q.tag + 3);
             }
         } else if (q.args.mode == VILMA_DECIDE_EVAL && q.tag && rep.outcome != VILMA_OUT_TAU_UPDATED) {
             prof_drop_tag(c, 4 * q.tag + 2);        // the re-evaluation's launches exit at once

@@ -495,7 +495,8 @@ class HipEngine:
         self._check(self.lib.vilma_prof_enable(self.ctx, max(1, int(every)) if on else 0))
 
     PROF_KINDS = ('ld_sym_kernel', 'ld_eig_fused_kernel', 'ld_sym_kernel_two_rhs',
-                  'snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2')
+                  'snp_pass_eval', 'snp_pass_trial', 'snp_pass_trial2',
+                  'sums_pass', 'sums_pass_store', 'snp_pass_trial_lazy', 'snp_pass_trial2_lazy')
 
     def prof_read(self, reset=True):
         """{kernel: (milliseconds, launches)} accumulated by the library's HIP events."""

@@ -22,6 +22,8 @@ WORKLOADS = {
     'C2': dict(P=1, n_ld=100_000, B=500, M=25, fixed=200, missing_frac=0.0),
     'C3': dict(P=2, n_ld=1_000_000, B=1700, M=40, fixed=None, missing_frac=0.05),
     'tiny': dict(P=2, n_ld=6_000, B=12, M=12, fixed=None, missing_frac=0.05),
+    # (enough blocks for every rank of an 8-way sharding to hold some)
+    'tiny8': dict(P=2, n_ld=8_000, B=40, M=12, fixed=None, missing_frac=0.05),
     # C4: as C3 but eigen-truncated LD (what --ldthresh 0.8 leaves: kept rank ~0.28 n)
     'C4': dict(P=2, n_ld=1_000_000, B=1700, M=40, fixed=None, missing_frac=0.05,
                kind='lowrank', rank_frac=0.28),
@@ -167,6 +169,9 @@ class SyntheticShard:
             block_range = shard_ranges(self.sizes_all, self.miss_all, world,
                                        per_snp_cost=8.0 * 3 * M * P)[rank]
         self.b0, self.b1 = block_range
+        if self.b1 <= self.b0:
+            raise ValueError('rank %d of %d would hold no LD block of this workload (%d blocks)'
+                             % (rank, world, len(self.sizes_all)))
         self.sizes = self.sizes_all[self.b0:self.b1]
         self.miss = self.miss_all[self.b0:self.b1]
         self.blocks = [BlockData(seed, self.b0 + i, n, m, P)
