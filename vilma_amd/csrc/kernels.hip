@@ -150,25 +150,51 @@ static __device__ __forceinline__ void ld_store2_wt(double *p, double a, double 
 #endif
 // Layout of the vi_mu buffers in HBM.  The reference's array is [M][P][N] (SNP axis contiguous):
 // a wave that walks the components of its 64 SNPs then touches M*P rows 8 N bytes apart, 512 B in
-// each -- M*P DRAM pages and address translations per tile.  MU_TILED stores the same numbers tile
-// by tile, [ceil(N/64)][M][P][64]: the M*P pieces of a tile are one contiguous run of M*P*512 bytes,
-// every wave of the per-SNP kernels reads (and writes) a linear stream.  vilma_set_mu / vilma_get_mu
-// convert at the boundary (mu_tile_kernel), so nothing outside the kernels sees the difference.
+// each -- M*P DRAM pages and address translations per tile.  The buffers hold the same numbers tile
+// by tile instead, so that the M*P pieces of a tile of 64 SNPs are one contiguous run and every wave
+// of the per-SNP kernels reads (and writes) a linear stream:
+//   MU_TILED 1   [ceil(N/64)][M*P][64]            8 bytes per lane and row (r05a)
+//   MU_TILED 2   [ceil(N/64)][ceil(M*P/2)][64][2]  rows r = k P + p in PAIRS (2j, 2j+1): a lane holds
+//                both rows of a pair side by side, so one global_load_dwordx4 / global_store_dwordx4
+//                moves 16 bytes per lane, 1 KiB per wave -- half the memory instructions
+//   MU_TILED 0   the reference's layout (diagnostic builds)
+// vilma_set_mu / vilma_get_mu convert at the boundary (mu_tile_kernel), so nothing outside the
+// kernels sees the difference.
 #ifndef MU_TILED
-#define MU_TILED 0
+#define MU_TILED 2
 #endif
 #define MU_TILE 64
-// elements between the same (SNP, cohort) of consecutive components / cohorts of one component
-#if MU_TILED
+// element (row r = k P + p) of SNP ii: base + MU_ROW(r), base = MU_BASE(ii, M, P, N)
+#if MU_TILED == 2
+#define MU_PAIRS(M, P) (((int64_t)(M) * (P) + 1) / 2)
+#define MU_BASE(ii, M, P, N64) ((int64_t)((ii) >> 6) * (MU_PAIRS(M, P) * 2 * MU_TILE) + 2 * ((ii) & 63))
+#define MU_ROW(r, N64) ((int64_t)((r) >> 1) * (2 * MU_TILE) + ((r) & 1))
+// pair j (rows 2j, 2j+1) of the SNP whose base is `base`: a 16-byte aligned v2d
+#define MU_PAIR(j) ((int64_t)(j) * (2 * MU_TILE))
+#elif MU_TILED == 1
 #define MU_BASE(ii, M, P, N64) ((int64_t)((ii) >> 6) * ((int64_t)(M) * (P) * MU_TILE) + ((ii) & 63))
 #define MU_ROW(r, N64) ((int64_t)(r) * MU_TILE)
 #else
 #define MU_BASE(ii, M, P, N64) ((int64_t)(ii))
 #define MU_ROW(r, N64) ((int64_t)(r) * (N64))
 #endif
-// element (k, p) of SNP ii, given base = MU_BASE(ii, ...): base + MU_ROW(k * P + p, N64)
+#define MU_PAIRED (MU_TILED == 2)
+#if MU_PAIRED
+#if MU_NT
+#define MU_LOAD2(p) __builtin_nontemporal_load((const v2d *)(p))
+#else
+#define MU_LOAD2(p) (*(const v2d *)(p))
+#endif
+#if MUOUT_NT
+#define MU_STORE2(p, a, b) __builtin_nontemporal_store(v2d{(a), (b)}, (v2d *)(p))
+#else
+#define MU_STORE2(p, a, b) (*(v2d *)(p) = v2d{(a), (b)})
+#endif
+#endif
 int64_t mu_buffer_elems(int64_t N, int M, int P) {
-#if MU_TILED
+#if MU_TILED == 2
+    return (N + MU_TILE - 1) / MU_TILE * MU_TILE * 2 * MU_PAIRS(M, P);
+#elif MU_TILED == 1
     return (N + MU_TILE - 1) / MU_TILE * MU_TILE * (int64_t)M * P;
 #else
     return N * (int64_t)M * P;
@@ -184,8 +210,12 @@ __global__ __launch_bounds__(256) void mu_tile_kernel(double *__restrict__ buf, 
         const int rr = (int)(o / npad);
         const int64_t i = o % npad;
         double *b = buf + MU_BASE(i, MP, 1, N) + MU_ROW(r0 + rr, N);
-        if (to_tiled) *b = i < N ? nat[(int64_t)rr * N + i] : 0.0;
-        else if (i < N) nat[(int64_t)rr * N + i] = *b;
+        if (to_tiled) {
+            *b = i < N ? nat[(int64_t)rr * N + i] : 0.0;
+#if MU_PAIRED
+            if (r0 + rr == MP - 1 && (MP & 1)) b[1] = 0.0;       // the unpaired last row's partner
+#endif
+        } else if (i < N) nat[(int64_t)rr * N + i] = *b;
     }
 }
 bool mu_is_tiled() { return MU_TILED != 0; }
@@ -1436,13 +1466,19 @@ int snp_tile_grid(int64_t N) { return (int)((N + 63) / 64); }
 int snp_sum_rows(int64_t N, int A) { (void)A; return snp_tile_grid(N); }
 
 // components per wave = stash slots per wave
-static inline int snp_slots(int M) { return (M + 3) / 4; }
+// (with vi_mu in row pairs, an odd number of cohorts pairs rows of two components: every wave's range
+// then starts at an even component)
+static __host__ __device__ inline int snp_wave_comps(int M, int P) {
+    const int q = (M + 3) / 4;
+    return (MU_PAIRED && (P & 1)) ? (q + 1) / 2 * 2 : q;
+}
+static inline int snp_slots(int M, int P) { return snp_wave_comps(M, P); }
 // accumulators a wave hands to wave 0 per candidate: Skl, Sip, Sm[P], S2[P]
 static inline int snp_nacc(int P) { return 2 + 2 * P; }
 size_t snp_pass_lds_bytes(int M, int P, int ns, bool stash) {
     const size_t zx = (size_t)4 * ns * 2 * SNP_TILE * sizeof(double);         // every wave's Z, max a
     const size_t hand = (size_t)3 * ns * snp_nacc(P) * SNP_TILE * sizeof(double);   // waves 1..3 -> 0
-    const size_t st = stash ? (size_t)snp_slots(M) * ns * SNP_THREADS * sizeof(double) : 0;
+    const size_t st = stash ? (size_t)snp_slots(M, P) * ns * SNP_THREADS * sizeof(double) : 0;
     return zx + std::max(hand, st);      // the hand-over reuses the stash once the sums are formed
 }
 // The stash is used when it leaves room for at least two workgroups in a CU's 160 KB of LDS (one
@@ -1524,7 +1560,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // this wave's components
-    const int Q = SNP_SPLIT == 4 ? (M + 3) / 4 : M;
+    const int Q = SNP_SPLIT == 4 ? snp_wave_comps(M, P) : M;
     const int kbeg = SNP_SPLIT == 4 ? w * Q : 0, kend = min(M, kbeg + Q);
     const int rowid = SNP_SPLIT == 4 ? blockIdx.x : blockIdx.x * 4 + w;     // row of the partials
     const int nrows = SNP_SPLIT == 4 ? gridDim.x : (N + 63) / 64;
@@ -1544,12 +1580,24 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     // (C3: 0.207 -> 0.198 ms).  A trial does not: the same move costs it 0.02 ms
     // (gpurun_out/ab23.txt of round 3; it is bound by its stores, not by latency).
     auto fetch_mu = [&](double (&dst)[KB][P], int k0) {
+#if MU_PAIRED
+        // the batch's KB P rows are KB P / 2 row pairs: 16 bytes per lane and load (k0 P is even)
+        static_assert(KB % 2 == 0, "row pairs of an odd number of cohorts span two components");
+        const int j0 = (k0 * P) >> 1, jmax = (int)MU_PAIRS(M, P) - 1;
+#pragma unroll
+        for (int t = 0; t < KB * P / 2; ++t) {
+            const v2d v = MU_LOAD2(&q.mu_in[mu_base + MU_PAIR(min(j0 + t, jmax))]);   // unconditional; extras ignored
+            dst[(2 * t) / P][(2 * t) % P] = v.x;
+            dst[(2 * t + 1) / P][(2 * t + 1) % P] = v.y;
+        }
+#else
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
             const int kc = min(k0 + kk, M - 1);       // unconditional loads; extras are ignored
 #pragma unroll
             for (int p = 0; p < P; ++p) dst[kk][p] = MU_LOAD(&q.mu_in[mu_base + MU_ROW(kc * P + p, N64)]);
         }
+#endif
     };
     double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
     constexpr bool FETCH_FIRST = !BLEND;
@@ -1634,6 +1682,8 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
     // whose normaliser left the representable range, see below)
     auto fold = [&](const double (&mul)[KB][P], const double (&lhv)[KB], int k0, auto maxonly) {
         constexpr bool MAXONLY = decltype(maxonly)::value;
+        double carry[NS][P];        // (odd P, paired rows: the even component of a pair waiting to be stored)
+        (void)carry;
 #pragma unroll
         for (int t0 = 0; t0 < KB; t0 += TB) {
         if (k0 + t0 >= kend) break;                    // wave-uniform
@@ -1687,6 +1737,7 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                         t = 0.0;
 #pragma unroll
                         for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+#if !MU_PAIRED
                         if (!NOSTORE && !MAXONLY) {
 #ifndef SNP_DIAG_NOSTORE                 // (diagnostic builds of profiles/microbench_snp.py only)
                             // no `if (live)`: a lane past the end works on a copy of SNP N-1 and
@@ -1696,10 +1747,40 @@ __global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel
                             MU_STORE(&mu_out[c][mu_base + MU_ROW(k * P + p, N64)], t);
 #endif
                         }
+#endif
                     }
                     mun[p] = t;
                     quad += t * nat[p];
                 }
+#if MU_PAIRED && !defined(SNP_DIAG_NOSTORE)
+                if (BLEND && !NOSTORE && !MAXONLY) {
+                    // 16 bytes per lane and store: a component's rows in pairs (no `if (live)`, as above)
+                    if constexpr (P % 2 == 0) {
+#pragma unroll
+                        for (int t = 0; t < P / 2; ++t)
+                            MU_STORE2(&mu_out[c][mu_base + MU_PAIR(((k * P) >> 1) + t)], mun[2 * t], mun[2 * t + 1]);
+                    } else if ((kk & 1) == 0) {
+                        // an odd number of cohorts: the rows of components (k, k + 1), k even, pair up;
+                        // the even one waits for its partner -- or, as the mixture's last component, goes
+                        // out with the buffer's padding row
+#pragma unroll
+                        for (int p = 0; p < P; ++p) carry[c][p] = mun[p];
+                        if (k + 1 >= kend) {                  // wave-uniform; then k + 1 == M
+#pragma unroll
+                            for (int t = 0; t < (P + 1) / 2; ++t)
+                                MU_STORE2(&mu_out[c][mu_base + MU_PAIR(((k * P) >> 1) + t)], carry[c][2 * t],
+                                          2 * t + 1 < P ? carry[c][(2 * t + 1) % P] : 0.0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < P; ++t) {
+                            const double lo = 2 * t < P ? carry[c][(2 * t) % P] : mun[(2 * t - P) % P];
+                            const double hi = 2 * t + 1 < P ? carry[c][(2 * t + 1) % P] : mun[(2 * t + 1 - P) % P];
+                            MU_STORE2(&mu_out[c][mu_base + MU_PAIR((((k - 1) * P) >> 1) + t)], lo, hi);
+                        }
+                    }
+                }
+#endif
                 const double ak = 0.5 * quad + lhk;
                 if (MAXONLY) {
                     amax[c] = fmax(amax[c], ak);
@@ -2100,7 +2181,36 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     // Double buffering as in snp_pass_kernel: the loads of the next batch are issued BEFORE this
     // batch's stores (on gfx9 loads and stores retire through one in-order counter, so a wave that
     // stores and then loads waits for its own stores to reach memory before it sees the loaded data)
+    // vi_mu in row pairs (MU_TILED 2): 16 bytes per lane and access where the rows a lane works on are
+    // whole pairs -- a batch of KD consecutive components (KS == 1: k0 is a multiple of KD), or the
+    // rows of one component with an even number of cohorts
+    constexpr bool PAIR_BATCH = MU_PAIRED && KS == 1 && (KD * P) % 2 == 0 && KD % 2 == 0;
+    constexpr bool PAIR_COMP = MU_PAIRED && !PAIR_BATCH && P % 2 == 0;
     auto fetch = [&](double (&dst)[KD][P], int k0) {
+#if MU_PAIRED
+        if constexpr (PAIR_BATCH) {
+            const int j0 = (k0 * P) >> 1, jmax = (int)MU_PAIRS(M, P) - 1;
+#pragma unroll
+            for (int t = 0; t < KD * P / 2; ++t) {
+                const v2d v = MU_LOAD2(&mu_state[mu_base + MU_PAIR(min(j0 + t, jmax))]);
+                dst[(2 * t) / P][(2 * t) % P] = v.x;
+                dst[(2 * t + 1) / P][(2 * t + 1) % P] = v.y;
+            }
+            return;
+        } else if constexpr (PAIR_COMP) {
+#pragma unroll
+            for (int u = 0; u < KD; ++u) {
+                const int kc = min(k0 + u * KS, M - 1);
+#pragma unroll
+                for (int t = 0; t < P / 2; ++t) {
+                    const v2d v = MU_LOAD2(&mu_state[mu_base + MU_PAIR(((kc * P) >> 1) + t)]);
+                    dst[u][2 * t] = v.x;
+                    dst[u][2 * t + 1] = v.y;
+                }
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < KD; ++u) {
             const int kc = min(k0 + u * KS, M - 1);       // unconditional loads; extras ignored
@@ -2142,8 +2252,15 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
 #pragma unroll
                     for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
                     mu[u][p] = t;
-                    MU_STORE(&mu_mat[mu_base + MU_ROW(k * P + p, N64)], t);
+                    if constexpr (!PAIR_BATCH && !PAIR_COMP) MU_STORE(&mu_mat[mu_base + MU_ROW(k * P + p, N64)], t);
                 }
+#if MU_PAIRED
+                if constexpr (PAIR_COMP) {
+#pragma unroll
+                    for (int t = 0; t < P / 2; ++t)
+                        MU_STORE2(&mu_mat[mu_base + MU_PAIR(((k * P) >> 1) + t)], mu[u][2 * t], mu[u][2 * t + 1]);
+                }
+#endif
             } else {
                 wdet = spd_rsqrt_det<P>(lam);
             }
@@ -2157,6 +2274,20 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
             }
             delta[u] = fmax(wdet * pass_exp(0.5 * quad + lhk - lse, expk), 1e-100);
         }
+#if MU_PAIRED
+        if constexpr (MAT && PAIR_BATCH) {
+            // the batch's new rows, pair by pair (a pair whose first row lies beyond the mixture was
+            // computed from a clamped load: not stored; one that ends in the padding row stores zero there)
+            const int j0 = (k0 * P) >> 1, MP = M * P;
+#pragma unroll
+            for (int t = 0; t < KD * P / 2; ++t) {
+                if (2 * (j0 + t) >= MP) break;              // uniform over the launch
+                const double lo = mu[(2 * t) / P][(2 * t) % P];
+                const double hi = 2 * (j0 + t) + 1 < MP ? mu[(2 * t + 1) / P][(2 * t + 1) % P] : 0.0;
+                MU_STORE2(&mu_mat[mu_base + MU_PAIR(j0 + t)], lo, hi);
+            }
+        }
+#endif
         if (WRITE) {
 #pragma unroll
             for (int u = 0; u < KD; ++u) {
