@@ -354,7 +354,10 @@ def main(argv=None, engine_factory=None):
 
     # an event pair costs ~10 us of stream time: every 3rd product on one GPU (<1 % of a C3 sweep;
     # an odd stride, so one- and two-right-hand-side launches are both sampled), every 9th on a shard
-    prof_every = args.prof_every or (3 if (world == 1 and args.emulate_shard <= 1) else 9)
+    # (with --learn-scaling a group is trial + evaluation + re-evaluation: a stride of 3 would bracket
+    # the same phase every time)
+    prof_every = args.prof_every or ((4 if args.learn_scaling else 3)
+                                     if (world == 1 and args.emulate_shard <= 1) else 9)
     engine.prof_enable(True, every=prof_every)
     engine.prof_read(reset=True)
     ev0, tr0, ah0 = driver.n_evaluations, driver.n_trials, driver.n_stages_ahead
@@ -365,9 +368,15 @@ def main(argv=None, engine_factory=None):
     sync()
     t0 = time.perf_counter()
     elbos = []
+    tau_start = np.array(np.atleast_1d(driver.error_scaling), dtype=np.float64)
+    tau_prev, tau_updates = tau_start, 0
     for k in range(args.steps):
         state, _ = driver.sweep(state, lookahead=k + 1 < args.steps)
         elbos.append(state['elbo'])
+        if args.learn_scaling:      # (a host-side comparison of what the sweep reported: no sync)
+            tau_now = np.array(np.atleast_1d(driver.error_scaling), dtype=np.float64)
+            tau_updates += int(np.any(tau_now != tau_prev))
+            tau_prev = tau_now
     sync()
     if world > 1:
         dist.barrier()
@@ -494,6 +503,11 @@ def main(argv=None, engine_factory=None):
             'stages_queued_ahead_then_skipped': driver.n_stages_skipped - sk0,
             'elbo_start': elbo0, 'elbo_end': elbos[-1] if elbos else elbo0,
             'error_scaling_end': [float(t) for t in np.atleast_1d(driver.error_scaling)],
+            # --learn-scaling: the error scaling at the start of the timed region and in how many of
+            # the timed sweeps the EM update moved it (it only acts once a sweep gains < EM_TOL:
+            # ~158 sweeps into C3, so `--warmup 160` puts it inside the timed region)
+            'error_scaling_start': [float(t) for t in tau_start],
+            'sweeps_that_updated_error_scaling': tau_updates if args.learn_scaling else None,
             'setup_seconds': setup_s,
         },
         'roofline': {

@@ -439,6 +439,16 @@ int vilma_prof_stream_pattern(vilma_ctx *ctx, void *stream, int passes, int chun
 int vilma_prof_ld_order(vilma_ctx *ctx, int order);
 int vilma_prof_ld_trace(vilma_ctx *ctx, double *buf_dev, int64_t capacity_rows);
 
+/* Debug poison.  With VILMA_DEBUG_POISON=1 in the environment when vilma_create runs, every beta trial
+ * (host-decided or queued ahead) first fills what it is about to produce with NaN: the result slots
+ * of candidates A and B (totals and responsibility sums) and the vi_mu buffers its candidates are
+ * stored into.  A slot a kernel leaves unwritten, or one a decision reads although no candidate
+ * produced it, then gives a non-finite objective at once (the line search ends in the reference's
+ * "Encountered a numerical error.") instead of whatever the memory held.  Results of a correct
+ * library are unchanged to the bit.  vilma_debug_result_slot copies the context's result slot of
+ * candidate A (which = 0) or B (1) of the LAST trial, n <= 3 P + 2 doubles, to `out` (host). */
+int vilma_debug_result_slot(vilma_ctx *ctx, int which, double *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

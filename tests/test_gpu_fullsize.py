@@ -11,7 +11,7 @@ from scipy.signal import lfilter
 pytestmark = pytest.mark.gpu
 
 
-def _setup(workload, seed=0, form='auto', block_range=None):
+def _setup(workload, seed=0, form='auto', block_range=None, scale_se=False):
     import torch
     from vilma_amd.synthetic import SyntheticShard, WORKLOADS
     from vilma_amd.engine import HipEngine
@@ -33,7 +33,7 @@ def _setup(workload, seed=0, form='auto', block_range=None):
                         specs=sh.block_specs())
     drv = SweepDriver()
     drv._setup_driver(eng, Comm(), sh.P, sh.M, 1, sh.chi_local, sh.rank_local, [sh.N_global],
-                      log_det, scale_se=False, num_its=100)
+                      log_det, scale_se=scale_se, num_its=100)
     return sh, eng, drv
 
 
@@ -97,6 +97,37 @@ def test_c3_fit_invariants():
     obj = _fresh_objective(drv)
     assert abs(obj - drv._objective) <= 1e-12 * abs(obj)
     eng.close()
+
+
+def test_c3_learn_scaling_acts_at_full_size_device_decided_equals_host_decided():
+    """--learn-scaling at the headline size, run until it ACTS: from the standard start the full
+    C3 problem first gains less than EM_TOL in a sweep after ~158 sweeps (profiles/
+    r05c_learn_scaling_where_it_acts.txt); from then on the EVAL decision updates tau
+    (_update_error_scaling, reference variational_inference.py:472-486) and re-evaluates.  200
+    sweeps decided on the device against 200 decided by the host: ELBO, L and tau equal to the
+    bit in every sweep; tau moves; every sweep passes the reference's acceptance bound; the cached
+    objective equals a fresh evaluation at the final tau."""
+    runs = []
+    for ahead in (True, False):
+        sh, eng, drv = _setup('C3', scale_se=True)
+        drv.initialize_from(sh.fake_mu)
+        state, elbo_prev, rows = None, drv._objective, []
+        for it in range(200):
+            state, stats = drv.sweep(state, lookahead=ahead and it < 199)
+            assert state['elbo'] >= elbo_prev - 25 * (1e-6 * abs(elbo_prev) + 1e-6)
+            elbo_prev = state['elbo']
+            rows.append((state['elbo'], tuple(state['L']), tuple(drv.error_scaling)))
+        if ahead:
+            assert drv.n_stages_ahead >= 190 and drv.n_stages_skipped == 0
+        taus = np.array([r[2] for r in rows])
+        assert np.all(taus[:100] == 1.0)                    # nothing to learn while sweeps gain > EM_TOL
+        n_moves = int(np.sum(np.any(np.diff(taus, axis=0) != 0.0, axis=1)))
+        assert n_moves >= 3 and np.all(np.abs(taus[-1] - 1.0) > 1e-4), (n_moves, taus[-1])
+        obj = _fresh_objective(drv)
+        assert abs(obj - drv._objective) <= 1e-12 * abs(obj)
+        runs.append(rows)
+        eng.close()
+    assert runs[0] == runs[1]
 
 
 def test_c3k12_default_mixture_fit_invariants():
@@ -278,17 +309,21 @@ def test_c5_operator_and_fit_invariants():
     eng.close()
 
 
-def _sample_against_oracle(workload, block_range, n_sweeps, form='auto'):
+def _sample_against_oracle(workload, block_range, n_sweeps, form='auto', scale_se=False, warm_sweeps=0):
     """A contiguous run of a full-size workload's LD blocks (its SNPs, LD, sumstats and mixture
     exactly as in the full problem) fitted on the GPU -- sweeps queued ahead and decided on the
     device -- and by the oracle from the same starting point: ELBO 1e-9 per sweep, the L
-    trajectory to the bit, posterior means 1e-7 (north star: 1e-5)."""
+    trajectory to the bit, posterior means 1e-7 (north star: 1e-5).  warm_sweeps: the GPU first
+    runs that many sweeps alone and the comparison starts from the state it reached (its vi_mu,
+    hyper_delta, L, running ELBO change handed to the oracle) -- how --learn-scaling is reached
+    where it acts: tau only moves once a sweep gains less than EM_TOL.  Returns the error scaling
+    after every compared sweep."""
     import os
     from oracle.ldop import EigenBlock, BlockDiagonalLD
     from oracle.vi import MultiPopVIOracle
     from oracle import native, numerics as nm
     from vilma_amd.synthetic import ar1_numpy
-    sh, eng, drv = _setup(workload, form=form, block_range=block_range)
+    sh, eng, drv = _setup(workload, form=form, block_range=block_range, scale_se=scale_se)
     assert len(sh.blocks) == block_range[1] - block_range[0]
     assert len(sh.blocks) >= 0.1 * len(sh.sizes_all)
     if sh.kind == 'lowrank':
@@ -300,23 +335,33 @@ def _sample_against_oracle(workload, block_range, n_sweeps, form='auto'):
                               perm=sh.perm, missing=sh.missing) for p in range(sh.P)]
     ovi = MultiPopVIOracle(marginal_effects=sh.betahat, std_errs=sh.se, ld_mats=ld,
                            annotations=np.ones((sh.N, 1)), mixture_covs=list(sh.covs),
-                           checkpoint=False, checkpoint_freq=-1, scaled=False, scale_se=False,
+                           checkpoint=False, checkpoint_freq=-1, scaled=False, scale_se=scale_se,
                            gwas_N=sh.gwas_N, init_hg=sh.init_hg, num_its=n_sweeps)
     # (the sample's constants use its own sum of 1/se^2, on both sides)
     np.testing.assert_allclose(ovi.adj_marginal_effects, sh.adj, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(ovi.chi_stat, sh.chi_local, rtol=1e-8)
     # one starting point for both: the device's _initialize on the shard's own jittered start
     drv.initialize_from(sh.fake_mu)
-    vi_mu0, hyper0 = eng.get_mu(), drv._hyper
+    state = None
+    for it in range(warm_sweeps):
+        state, _ = drv.sweep(state, lookahead=True)
+    vi_mu0, hyper0 = eng.get_mu(), drv._hyper       # (reading the state takes back what was queued ahead)
+    if warm_sweeps:
+        assert np.all(drv.error_scaling == 1.0), 'tau moved during the warm-up: start the comparison earlier'
     ovi.nat_grad_vi_delta = nm.fast_vi_delta_grad(hyper0, ovi.log_det, ovi.annotations)
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))
     native.enable(threads=threads)          # the oracle's per-SNP passes as compiled C loops
+    taus = []
     try:
         _, d0, _ = ovi._nat_to_not_vi_delta((vi_mu0, None, hyper0))
         oparams = (vi_mu0, d0, hyper0)
         oelbo = ovi.elbo(oparams)
         assert abs(drv._objective - oelbo) < 1e-9 * abs(oelbo)
-        state, oL, ored = None, np.ones(5), None
+        oL, ored = np.ones(5), None
+        if state is not None:
+            # the oracle continues the GPU's run: same L, same running change; its ELBO carries on
+            # from the GPU's accumulated value, as optimize() would carry it
+            oL, ored, oelbo = state['L'].copy(), state['running'], state['elbo']
         ahead = 0
         for it in range(n_sweeps):
             oparams, oL, oelbo, ored = ovi._optimize_step(oparams, oL, oelbo, 2., ored)
@@ -326,6 +371,9 @@ def _sample_against_oracle(workload, block_range, n_sweeps, form='auto'):
             assert abs(state['elbo'] - oelbo) < 1e-9 * abs(oelbo), (it, state['elbo'], oelbo)
             assert np.array_equal(state['L'], oL), (it, state['L'], oL)
             assert abs(state['running'] - ored) <= 1e-9 * abs(ored)
+            if scale_se:
+                np.testing.assert_allclose(drv.error_scaling, ovi.error_scaling, rtol=1e-9)
+            taus.append(np.array(drv.error_scaling))
         assert ahead >= n_sweeps - 2            # the sweeps did run from the device's control block
         mean, var = eng.get_moments()
         omean = ovi._posterior_mean(*oparams)
@@ -336,11 +384,25 @@ def _sample_against_oracle(workload, block_range, n_sweeps, form='auto'):
     finally:
         native.disable()
         eng.close()
+    return taus
 
 
 def test_c3_block_sample_four_sweeps_against_the_oracle():
     """170 consecutive blocks of C3's 1700 (10 %, ~100 k SNPs x 2 cohorts, M = 40), four sweeps."""
     _sample_against_oracle('C3', (700, 870), 4)
+
+
+def test_c3_block_sample_learn_scaling_where_tau_moves_against_the_oracle():
+    """--learn-scaling where it acts (reference variational_inference.py:441-448, 472-486, 712-738):
+    the error scaling only moves in a sweep that gained less than EM_TOL = 10, which this sample of
+    C3 reaches after ~50 sweeps (profiles/r05c_learn_scaling_where_it_acts.txt; the full problem
+    after ~158).  The GPU runs 46 sweeps with scale_se on its own, hands its state to the oracle,
+    and both run 8 more: in those the EVAL decision of the device's stage machine takes the tau
+    update and the re-evaluation behind it -- tau 1e-9, ELBO 1e-9, L to the bit, every sweep."""
+    taus = _sample_against_oracle('C3', (700, 870), 8, scale_se=True, warm_sweeps=46)
+    moved = [t for t in taus if np.any(t != 1.0)]
+    assert len(moved) >= 2, taus                 # tau did move, in more than one sweep
+    assert not np.array_equal(moved[0], moved[-1])
 
 
 def test_c4f_block_sample_three_sweeps_against_the_oracle():

@@ -91,8 +91,7 @@ class CFit:
         self.lib.vilma_destroy(self.ctx)
 
 
-@pytest.mark.parametrize('name', TRAJ_NAMES)
-def test_vilma_sweep_reproduces_the_reference_trajectories(name):
+def _reproduce_trajectory(name, extra_flags=0):
     from vilma_amd import _lib
     g = golden('traj_%s.npz' % name)
     fit = CFit(g, form='eig' if name.endswith('lowrank') or name.endswith('_lr') else 'dense')
@@ -111,7 +110,7 @@ def test_vilma_sweep_reproduces_the_reference_trajectories(name):
     n = len(g['elbo'])
     for it in range(n):
         fit.ok(lib.vilma_sweep(ctx, None, _p(L), C.byref(elbo), C.byref(running), 2.0,
-                               _lib.SWEEP_DIFF, C.byref(stats)))
+                               _lib.SWEEP_DIFF | (extra_flags if it + 1 < n else 0), C.byref(stats)))
         assert abs(elbo.value - g['elbo'][it]) < 1e-9 * abs(elbo.value), (it, elbo.value)
         assert np.array_equal(L, g['L'][it]), (it, L, g['L'][it])
         assert stats.n_evaluations <= int(g['objs_per_sweep'][it])
@@ -133,6 +132,46 @@ def test_vilma_sweep_reproduces_the_reference_trajectories(name):
     # vilma_set_state with what vilma_get_state returned is the same state: same ELBO
     fit.ok(lib.vilma_set_state(ctx, None, _p(mu), _p(hyper), _p(tau), C.byref(obj)))
     assert abs(obj.value - elbo.value) < 1e-9 * abs(obj.value)
+    fit.close()
+
+
+
+@pytest.mark.parametrize('name', TRAJ_NAMES)
+def test_vilma_sweep_reproduces_the_reference_trajectories(name):
+    _reproduce_trajectory(name)
+
+
+@pytest.mark.parametrize('flags', [0, 2], ids=['host-decided', 'queued-ahead'])
+@pytest.mark.parametrize('name', ['p1_dense', 'p2_scale_se', 'p4_m81', 'p2_bigblock_lr'])
+def test_debug_poison_changes_no_trajectory(name, flags, monkeypatch):
+    """VILMA_DEBUG_POISON=1 (read by vilma_create): the result slots of both candidates and the
+    candidates' vi_mu buffers are filled with NaN before every beta trial.  Whatever a trial is
+    defined to produce it must then have written, and nothing may be read that was not produced:
+    the reference's trajectories come out unchanged, L to the bit."""
+    monkeypatch.setenv('VILMA_DEBUG_POISON', '1')
+    _reproduce_trajectory(name, extra_flags=flags)
+
+
+def test_debug_poison_reaches_an_unwritten_slot(monkeypatch):
+    """The other half: with the switch on, candidate B's result slot after a ONE-step trial is NaN
+    (nothing produced it), so a decision that read it would fail loudly."""
+    from vilma_amd import _lib
+    monkeypatch.setenv('VILMA_DEBUG_POISON', '1')
+    monkeypatch.setenv('VILMA_TWO_STEP', '0')
+    g = golden('traj_p1_dense.npz')
+    fit = CFit(g)
+    lib, ctx = fit.lib, fit.ctx
+    obj = C.c_double()
+    fit.ok(lib.vilma_initialize(ctx, None, _p(fit.fake_mu()), C.byref(obj)))
+    L = np.ones(5)
+    elbo, running = C.c_double(obj.value), C.c_double(float('nan'))
+    stats = _lib.SweepStats()
+    fit.ok(lib.vilma_sweep(ctx, None, _p(L), C.byref(elbo), C.byref(running), 2.0, 0, C.byref(stats)))
+    assert abs(elbo.value - g['elbo'][0]) < 1e-9 * abs(elbo.value)      # the sweep itself is sound
+    nt = 3 * fit.P + 2
+    slot_b = np.zeros(nt)
+    fit.ok(lib.vilma_debug_result_slot(ctx, 1, _p(slot_b), nt))
+    assert np.all(np.isnan(slot_b)), slot_b
     fit.close()
 
 

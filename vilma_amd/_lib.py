@@ -128,6 +128,7 @@ def load():
         'vilma_prof_enable': (C.c_int, [vp, C.c_int]),
         'vilma_prof_read': (C.c_int, [vp, _c_double_p, _c_i64_p, C.c_int]),
         'vilma_prof_stream_store': (C.c_int, [vp, vp, C.c_int, vp, vp]),
+        'vilma_debug_result_slot': (C.c_int, [vp, C.c_int, vp, C.c_int]),
         'vilma_prof_stream_pattern': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
         'vilma_prof_ld_order': (C.c_int, [vp, C.c_int]),
         'vilma_prof_ld_trace': (C.c_int, [vp, vp, C.c_int64]),

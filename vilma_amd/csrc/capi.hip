@@ -428,6 +428,11 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     if (sums_a_dev && !stash) return fail(c, "this trial cannot deliver the responsibility sums");
     if (!queued) c->tile_sums_ns = stash ? ns : 0;
     if (queued) set_launch_phase(&c->ctl->phase[phase]);
+    if (c->poison && blend && !a.no_store) {
+        const int64_t nmu = mu_buffer_elems(c->N, c->M, c->P);
+        launch_poison(a.mu_out, nmu, queued ? 1 : 0, s);
+        if (two) launch_poison(a.mu_out2, nmu, queued ? 2 : 0, s);
+    }
     {
         // bracketed with the LD product that follows (same sampling tick)
         hipEvent_t e0;
@@ -687,6 +692,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         if (v >= 128) c->chunk_rows = std::min((v + 31) / 32 * 32, 512);    // LD_MAX_CHUNK_ROWS (kernels.hip)
     }
     // VILMA_OVERLAP=0 keeps everything on the caller's stream (A/B measurements)
+    if (const char *po = std::getenv("VILMA_DEBUG_POISON")) c->poison = po[0] != '0' && po[0] != 0;
     const char *ov = std::getenv("VILMA_OVERLAP");
     c->overlap = !(ov && ov[0] == '0');
     // The side stream is created at HIGH priority: HIP maps streams onto a small pool of hardware

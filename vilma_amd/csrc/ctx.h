@@ -154,6 +154,7 @@ struct vilma_ctx {
     double *snap[2] = {nullptr, nullptr};
     int snap_cur = 0;
     double *gbuf = nullptr;         // [P][N]: the natural gradient a lazy trial leaves (kernels.h)
+    bool poison = false;            // VILMA_DEBUG_POISON=1: NaN into what a trial is about to write
     bool lazy_trial = false;        // the trials being queued store no vi_mu (set by sweep.hip)
     double *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;

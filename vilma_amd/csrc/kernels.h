@@ -229,6 +229,9 @@ void launch_snp_pass(const SnpKernelArgs &a, bool blend, int ns, hipStream_t s);
 // and the conversion between the reference's [M*P][N] array and that layout
 int64_t mu_buffer_elems(int64_t N, int M, int P);
 bool mu_is_tiled();
+// debug poison (VILMA_DEBUG_POISON): NaN into p[0, n) -- which = 1 / 2: into the vi_mu buffer the current
+// launch phase assigns to candidate A / B instead of p; honours the launch predicate
+void launch_poison(double *p, int64_t n, int which, hipStream_t s);
 void launch_mu_tile(double *buf, double *nat, int64_t N, int MP, int r0, int R, bool to_tiled, hipStream_t s);
 int snp_pass_grid(int64_t N);       // workgroups of the thread-per-SNP kernels (256 SNPs each)
 int snp_tile_grid(int64_t N);       // workgroups of launch_snp_pass (each loops over tiles of 64 SNPs) = rows of its partials

@@ -242,6 +242,26 @@ typedef const PhasePtrs __attribute__((address_space(4))) *phase_tab;
 #define PHASE(pp) ((phase_tab)(pp))
 #define PRED_EXIT(pred) do { if ((pred) != nullptr && *(pred) == 0) return; } while (0)
 
+// VILMA_DEBUG_POISON=1 (read by vilma_create): what a beta trial is about to write -- its result slots,
+// its candidates' vi_mu -- is filled with NaN first, so that anything a kernel leaves unwritten, or a
+// decision reads without its having been produced, surfaces at once as a non-finite objective ("Encountered
+// a numerical error.") instead of as whatever the buffer held before.  which = 1 / 2: the vi_mu buffer
+// the launch phase assigns to candidate A / B (roles of a sweep queued ahead live on the device).
+__global__ __launch_bounds__(256) void poison_kernel(double *p, int64_t n, const int *pred,
+                                                      const PhasePtrs *pp, int which) {
+    PRED_EXIT(pred);
+    if (pp != nullptr && which == 1) p = PHASE(pp)->mu_out;
+    if (pp != nullptr && which == 2) p = PHASE(pp)->mu_out2;
+    if (p == nullptr) return;
+    const double nan = __builtin_nan("");
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) p[o] = nan;
+}
+void launch_poison(double *p, int64_t n, int which, hipStream_t s) {
+    if (n <= 0) return;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 1 << 14);
+    hipLaunchKernelGGL(poison_kernel, dim3(grid), dim3(256), 0, s, p, n, g_pred, which ? g_phase : nullptr, which);
+}
+
 typedef const double __attribute__((address_space(4))) *const_tab;
 static __device__ __forceinline__ const_tab as_table(const double *p) { return (const_tab)p; }
 
@@ -1502,6 +1522,10 @@ static __device__ __forceinline__ double tile_sum8(const double (&p)[8], int lan
 #ifndef SNP_MIN_WAVES
 #define SNP_MIN_WAVES(P) ((P) <= 4 ? 3 : 1)
 #endif
+// (a plain evaluation is a chain of HBM round trips per tile: what it has in flight is waves x batch)
+#ifndef SNP_EVAL_WAVES
+#define SNP_EVAL_WAVES(P) SNP_MIN_WAVES(P)
+#endif
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
 // store of the wave to be acknowledged (vmcnt(0)): with the pass's vi_mu stores in flight that is
 // microseconds per barrier, and a tile has three.  Nothing in this kernel is handed between
@@ -1511,7 +1535,7 @@ static __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH, bool NOSTORE = false>
-__global__ __launch_bounds__(SNP_THREADS, SNP_MIN_WAVES(P)) void snp_pass_kernel(const SnpKernelArgs a) {
+__global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WAVES(P)) void snp_pass_kernel(const SnpKernelArgs a) {
     static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
     static_assert(!NOSTORE || (BLEND && !STASH), "lazy trials are the no-stash trials");
     constexpr int NT = 2 * P + 2;

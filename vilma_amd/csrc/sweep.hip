@@ -317,6 +317,7 @@ int trial(vilma_ctx *c, SweepState *s, hipStream_t st, double step, double next_
     s->alt_valid = false;
     s->cur_sums = -1;                   // the trial's sums overwrite the device copy
     const bool two = s->two_step;
+    if (c->poison) launch_poison(s->results + s->o_ta, s->o_sb + s->am - s->o_ta, 0, st);
     if (two) {
         if (vilma_trial_beta2(c, (void *)st, step, next_step, s->results + s->o_ta, s->results + s->o_tb))
             return 1;
@@ -614,6 +615,7 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     c->prof_tag = 4 * tag;
     c->lazy_trial = lazy_trials(c, s);
     set_launch_predicate(&c->ctl->alive);
+    if (c->poison) launch_poison(s->results + s->o_ta, s->o_sb + s->am - s->o_ta, 0, st);
     rc = queue_trial_phase(c, st, two, s->results + s->o_ta, s->results + s->o_tb,
                            stash ? s->results + s->o_sa : nullptr,
                            (stash && two) ? s->results + s->o_sb : nullptr);
@@ -1213,6 +1215,17 @@ int vilma_update_error_scaling(vilma_ctx *c, void *stream, double *orig_obj, dou
     if (update_error_scaling(c, s, (hipStream_t)stream, &nw)) return 1;
     if (orig_obj) *orig_obj = orig;
     if (new_obj) *new_obj = nw;
+    return 0;
+}
+
+int vilma_debug_result_slot(vilma_ctx *c, int which, double *out, int n) {
+    if (!c || !out) return 1;
+    SweepState *s = sweep_state(c);
+    if (!s) return 1;
+    if (which < 0 || which > 1 || n < 0 || n > s->nt) return fail(c, "vilma_debug_result_slot: bad slot or length");
+    if (vilma_sweep_drain(c)) return 1;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, s->results + (which ? s->o_tb : s->o_ta), (size_t)n * sizeof(double), hipMemcpyDefault));
     return 0;
 }
 
