@@ -494,3 +494,30 @@ def test_two_step_and_lookahead_change_no_bit(monkeypatch):
             assert c[2] < c0[2]                          # ... in fewer passes over the LD store
         if lookahead:
             assert c[3] > 0
+
+
+@pytest.mark.parametrize('name', ['p1_dense', 'p2_scale_se', 'p1_scaled', 'p4_general'])
+def test_output_arrays_formed_on_the_device(name):
+    """The arrays `vilma fit` writes besides vi_mu (reference vi_options.py:263-265): vi_sigma
+    [M,P,P,N] from vilma_get_vi_sigma against the host's closed forms (one and two cohorts: the
+    same IEEE operations, equal to the bit; more: Cholesky against numpy's inverse, 1e-12) at an
+    error scaling that has moved; vi_delta [N,M] (transposed on the device) is compared with the
+    reference's fixed point of the same vi_mu in test_fit_trajectory (here: its layout and normalisation)."""
+    g = golden('traj_%s.npz' % name)
+    vi, _ = product_vi_from_traj(g)
+    np.random.seed(int(g['seed']))
+    params = vi._initialize()
+    L, elbo, red = np.ones(5), vi.elbo(params), None
+    for it in range(3):
+        params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
+    if bool(g['scale_se']):
+        vi.error_scaling = vi.error_scaling * np.linspace(1.1, 0.9, vi.num_pops)    # off 1 either way
+    dev, host = vi.vi_sigma, vi._vi_sigma_host()
+    assert dev.shape == host.shape == (vi.num_mix, vi.num_pops, vi.num_pops, vi.num_loci)
+    if vi.num_pops <= 2:
+        assert np.array_equal(dev, host)
+    else:
+        np.testing.assert_allclose(dev, host, rtol=1e-12, atol=1e-300)
+    vi_delta = params[1]
+    assert vi_delta.shape == (vi.num_loci, vi.num_mix) and vi_delta.flags.c_contiguous
+    np.testing.assert_allclose(vi_delta.sum(axis=1), 1.0, rtol=1e-12)

@@ -1010,10 +1010,38 @@ int vilma_get_delta(vilma_ctx *c, double *vi_delta) {
     fill_delta_args(c, a, scratch);
     launch_delta_write(a, nullptr);
     HIPCHK(c, hipDeviceSynchronize());
-    std::vector<double> km((size_t)c->M * c->N);
-    HIPCHK(c, hipMemcpy(km.data(), scratch, km.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < c->N; ++i)
-        for (int k = 0; k < c->M; ++k) vi_delta[i * c->M + k] = km[(size_t)k * c->N + i];
+    // transposed on the device, a slice of SNPs at a time through a staging buffer (the host loop
+    // over [M][N] took 2 s at 1 M SNPs x 582 components)
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(c->N, ((int64_t)32 << 20) / std::max(c->M, 1)));
+    double *stage = nullptr;
+    HIPCHK(c, hipMalloc((void **)&stage, (size_t)chunk * c->M * sizeof(double)));
+    int rc = 0;
+    for (int64_t i0 = 0; i0 < c->N && !rc; i0 += chunk) {
+        const int n = (int)std::min<int64_t>(chunk, c->N - i0);
+        launch_transpose_km(scratch, stage, c->N, c->M, i0, n, nullptr);
+        if (hipMemcpy(vi_delta + (size_t)i0 * c->M, stage, (size_t)n * c->M * sizeof(double),
+                      hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+    }
+    (void)hipFree(stage);
+    if (rc) return fail(c, "vilma_get_delta: device to host copy failed");
+    return 0;
+}
+
+int vilma_get_vi_sigma(vilma_ctx *c, double *vi_sigma) {
+    if (!c || !vi_sigma) return 1;
+    if (vilma_sweep_drain(c)) return 1;      // the staging buffer is a trial buffer: nothing may be queued
+    HIPCHK(c, hipDeviceSynchronize());
+    double *stage = c->mu[c->mu_ta];         // M P N doubles: M / P components of [P][P][N] at a time
+    const int nk_max = std::max(1, c->M / c->P);
+    TauArg tau;
+    for (int p = 0; p < VILMA_MAX_P; ++p) tau.v[p] = p < c->P ? c->tau[p] : 1.0;
+    const size_t per_k = (size_t)c->P * c->P * c->N;
+    for (int k0 = 0; k0 < c->M; k0 += nk_max) {
+        const int nk = std::min(nk_max, c->M - k0);
+        launch_vi_sigma(c->P, c->prec, c->sld, tau, c->N, k0, nk, stage, nullptr);
+        HIPCHK(c, hipMemcpy(vi_sigma + (size_t)k0 * per_k, stage, (size_t)nk * per_k * sizeof(double),
+                            hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

@@ -323,6 +323,11 @@ struct DeltaArgs {
 };
 void launch_delta_sums(const DeltaArgs &a, double *sums_out /*[A*M]*/, hipStream_t s);
 void launch_delta_write(const DeltaArgs &a, hipStream_t s);
+// out [n][M] <- rows i0 .. i0 + n of the transpose of in [M][N] (vilma_get_delta)
+void launch_transpose_km(const double *in, double *out, int64_t N, int M, int64_t i0, int n, hipStream_t s);
+// vi_sigma of components [k0, k0 + nk) into out [nk][P][P][N] (vilma_get_vi_sigma)
+void launch_vi_sigma(int P, const double *prec, const double *sld, const TauArg &tau, int64_t N, int k0, int nk,
+                     double *out, hipStream_t s);
 int delta_grid(int64_t N);
 // rows ([A*M] doubles each) of the partials buffer launch_delta_sums needs: one per wave plus the
 // scratch rows of its multi-pass column reduction

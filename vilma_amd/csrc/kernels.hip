@@ -224,6 +224,135 @@ void launch_mu_tile(double *buf, double *nat, int64_t N, int MP, int r0, int R, 
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 1 << 16);
     hipLaunchKernelGGL(mu_tile_kernel, dim3(grid), dim3(256), 0, s, buf, nat, N, MP, r0, R, to_tiled);
 }
+// (Prec + D)^-1 by Cholesky with IEEE sqrt and divide -- for outputs (vi_sigma_kernel), where the
+// per-SNP passes' fast reciprocal square root (pass_rsqrt, ~2 ulp) has no business
+template <int P>
+static __device__ __forceinline__ void spd_inverse_exact(const double (&lam)[P][P], double (&sig)[P][P]) {
+    double G[P][P], Gi[P][P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        double s = lam[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= G[j][k] * G[j][k];
+        G[j][j] = sqrt(s);
+        Gi[j][j] = 1.0 / G[j][j];
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+            double t = lam[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= G[i][k] * G[j][k];
+            G[i][j] = t * Gi[j][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) t += G[i][k] * Gi[k][j];
+            Gi[i][j] = -t * Gi[i][i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = a; k < P; ++k) t += Gi[k][a] * Gi[k][b];
+            sig[a][b] = t;
+            sig[b][a] = t;
+        }
+    }
+}
+
+// out[(i - i0) * M + k] = in[k * N + i] for i in [i0, i0 + n): the [M][N] responsibilities the delta
+// pass writes, turned into the reference's [N][M] rows for the host (32 x 32 tiles through LDS, both
+// sides coalesced)
+__global__ __launch_bounds__(256) void transpose_km_kernel(const double *__restrict__ in, double *__restrict__ out,
+                                                            int64_t N, int M, int64_t i0, int n) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+    const int64_t ib = (int64_t)blockIdx.x * 32;
+    const int kb = blockIdx.y * 32;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int k = kb + ty + r;
+        const int64_t i = ib + tx;
+        tile[ty + r][tx] = (k < M && i < n) ? in[(int64_t)k * N + i0 + i] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int64_t i = ib + ty + r;
+        const int k = kb + tx;
+        if (i < n && k < M) out[i * M + k] = tile[tx][ty + r];
+    }
+}
+void launch_transpose_km(const double *in, double *out, int64_t N, int M, int64_t i0, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(transpose_km_kernel, dim3((n + 31) / 32, (M + 31) / 32), dim3(256), 0, s, in, out, N, M, i0, n);
+}
+
+// vi_sigma [M][P][P][N] for the outputs (`vilma fit` writes it into the .npz; reference
+// variational_inference.py:712-724, numerics.py:216-290): Sig_ki = (Prec_k + diag(sld_i / tau))^-1 for
+// components [k0, k0 + nk) into out [nk][P][P][N].  Off the sweep path.  One and two cohorts use the
+// reference's closed forms in plain IEEE operations (no contraction): the same bits numpy gives.
+template <int P>
+__global__ __launch_bounds__(256) void vi_sigma_kernel(const double *__restrict__ prec, const double *__restrict__ sld,
+                                                        const TauArg tau, int64_t N, int k0, double *__restrict__ out) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int kk = blockIdx.y, k = k0 + kk;
+    double lam[P][P], sig[P][P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) lam[p][q] = prec[((int64_t)k * P + p) * P + q];
+        const double d = sld[p * N + i] / tau.v[p];
+        lam[p][p] = d + lam[p][p];
+    }
+    if constexpr (P == 1) {
+        sig[0][0] = 1.0 / lam[0][0];
+    } else if constexpr (P == 2) {
+        const double ad = lam[0][0] * lam[1][1];
+        const double bc = lam[0][1] * lam[1][0];
+        const double r = 1.0 / (ad - bc);
+        sig[0][0] = lam[1][1] * r;
+        sig[1][1] = lam[0][0] * r;
+        sig[1][0] = -lam[1][0] * r;
+        sig[0][1] = sig[1][0];
+    } else {
+        spd_inverse_exact<P>(lam, sig);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < P; ++q) out[(((int64_t)kk * P + p) * P + q) * N + i] = sig[p][q];
+}
+template <int P>
+static void launch_vi_sigma_p(const double *prec, const double *sld, const TauArg &tau, int64_t N, int k0, int nk,
+                              double *out, hipStream_t s) {
+    hipLaunchKernelGGL(vi_sigma_kernel<P>, dim3((unsigned)((N + 255) / 256), nk), dim3(256), 0, s, prec, sld, tau, N, k0, out);
+}
+void launch_vi_sigma(int P, const double *prec, const double *sld, const TauArg &tau, int64_t N, int k0, int nk,
+                     double *out, hipStream_t s) {
+    if (nk <= 0) return;
+    switch (P) {
+        case 1: launch_vi_sigma_p<1>(prec, sld, tau, N, k0, nk, out, s); break;
+        case 2: launch_vi_sigma_p<2>(prec, sld, tau, N, k0, nk, out, s); break;
+        case 3: launch_vi_sigma_p<3>(prec, sld, tau, N, k0, nk, out, s); break;
+        case 4: launch_vi_sigma_p<4>(prec, sld, tau, N, k0, nk, out, s); break;
+        case 5: launch_vi_sigma_p<5>(prec, sld, tau, N, k0, nk, out, s); break;
+        case 6: launch_vi_sigma_p<6>(prec, sld, tau, N, k0, nk, out, s); break;
+        case 7: launch_vi_sigma_p<7>(prec, sld, tau, N, k0, nk, out, s); break;
+        case 8: launch_vi_sigma_p<8>(prec, sld, tau, N, k0, nk, out, s); break;
+        default: break;
+    }
+}
+
 // Predicated launches: when the host queues work ahead of a decision that a device kernel takes
 // (decide_kernel), every kernel of that work starts by reading the decision's flag and exits if
 // it is 0 -- mis-speculated work costs a few microseconds of empty launches and touches nothing.

@@ -238,6 +238,12 @@ class HipEngine:
         self._check(self.lib.vilma_get_delta(self.ctx, _ptr(out)))
         return out
 
+    def get_vi_sigma(self):
+        """[M, P, P, N] at the current error scaling, formed on the device (outputs only)."""
+        out = np.empty((self.M, self.P, self.P, self.N))
+        self._check(self.lib.vilma_get_vi_sigma(self.ctx, _ptr(out)))
+        return out
+
     def get_moments(self):
         mean, var = np.empty((self.P, self.N)), np.empty((self.P, self.N))
         self._check(self.lib.vilma_get_moments(self.ctx, _ptr(mean), _ptr(var)))

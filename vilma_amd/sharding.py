@@ -66,6 +66,12 @@ def agree_on_rccl(comm, make_id, init_rccl):
     return False, err or 'another rank failed', failed
 
 
+def _is_identity(index, n):
+    index = np.asarray(index)
+    return index.shape == (n,) and (n == 0 or (index[0] == 0 and index[-1] == n - 1
+                                               and bool(np.all(index[1:] - index[:-1] == 1))))
+
+
 class Comm:
     """Thin wrapper over torch.distributed; a no-op for a single process."""
 
@@ -150,6 +156,8 @@ class Comm:
         axis: the temporaries stay below GATHER_CHUNK_BYTES x world."""
         local = np.ascontiguousarray(local, dtype=np.float64)
         if self.world == 1:
+            if local.shape[-1] == n_global and _is_identity(snp_index, n_global):
+                return local            # one rank holding every SNP in order: nothing to move
             out = np.empty(local.shape[:-1] + (n_global,))
             out[..., snp_index] = local
             return out
