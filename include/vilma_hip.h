@@ -140,12 +140,12 @@ int vilma_set_mu(vilma_ctx *ctx, const double *vi_mu);
 int vilma_get_mu(vilma_ctx *ctx, double *vi_mu);
 /* vi_delta [N*M] (reference layout) of the current state. */
 int vilma_get_delta(vilma_ctx *ctx, double *vi_delta);
-/* vi_sigma [M*P*P*N] (reference layout [M][P][P][N]) at the current error scaling: Sig_ki =
+/* vi_sigma [M*P*P*N] (reference layout [M][P][P][N]) at `error_scaling` [P] (NULL: the context's): Sig_ki =
  * (mixture_prec_k + diag(scaled_ld_diags_i / tau))^-1, what _set_vi_sigma keeps as an array
  * (variational_inference.py:712-724; numerics.py:216-290) and `vilma fit` writes into its .npz.  The
  * library never stores it; this forms it on the device for the output (closed forms for one and two
  * cohorts in plain IEEE operations, Cholesky beyond). */
-int vilma_get_vi_sigma(vilma_ctx *ctx, double *vi_sigma);
+int vilma_get_vi_sigma(vilma_ctx *ctx, const double *error_scaling, double *vi_sigma);
 /* posterior mean / marginal variance [P*N] of the current state, without scalings
  * (_posterior_mean, _posterior_marginal_variance, variational_inference.py:753-760). */
 int vilma_get_moments(vilma_ctx *ctx, double *mean, double *var);

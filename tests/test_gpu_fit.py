@@ -510,6 +510,7 @@ def test_output_arrays_formed_on_the_device(name):
     L, elbo, red = np.ones(5), vi.elbo(params), None
     for it in range(3):
         params, L, elbo, red = vi._optimize_step(params, L, elbo, 2., red)
+    vi_delta = params[1]                       # (downloaded at the fit's own error scaling)
     if bool(g['scale_se']):
         vi.error_scaling = vi.error_scaling * np.linspace(1.1, 0.9, vi.num_pops)    # off 1 either way
     dev, host = vi.vi_sigma, vi._vi_sigma_host()
@@ -518,6 +519,5 @@ def test_output_arrays_formed_on_the_device(name):
         assert np.array_equal(dev, host)
     else:
         np.testing.assert_allclose(dev, host, rtol=1e-12, atol=1e-300)
-    vi_delta = params[1]
     assert vi_delta.shape == (vi.num_loci, vi.num_mix) and vi_delta.flags.c_contiguous
     np.testing.assert_allclose(vi_delta.sum(axis=1), 1.0, rtol=1e-12)

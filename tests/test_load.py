@@ -221,3 +221,31 @@ def test_gpu_eigh_plan_and_stacks(monkeypatch):
     assert ld_device.plan_gpu_eigh(sizes, [False] * len(sizes), 16) == set()
     monkeypatch.setenv('VILMA_GPU_EIGH', '0')
     assert ld_device.plan_gpu_eigh(sizes, [True] * len(sizes), 16) == set()
+
+
+@pytest.mark.parametrize('body', [
+    'rs1 1 100 0.0 A C\nrs2 1 200 0.0 G T\n',                        # plain
+    'rs1\t1\t100\t0.0\tA\tC\n\n  rs2 1 200 0.0 G T  \n',             # tabs, a blank line, padding
+    '1:100_A_C 1 100 0.0 A C\n2 1 200 0.0 G T\n',                    # one numeric-looking ID among strings
+    '101 1 100 0.0 A C\n202 1 200 0.0 G T\n',                        # all-numeric IDs (pandas: int64)
+    'rs1 1 100 0.0 NA C\nrs2 1 200 0.0 G T\n',                       # an NA spelling (pandas: NaN)
+    'NA 1 100 0.0 A C\nrs2 1 200 0.0 G T\n',
+    '"rs 1" 1 100 0.0 A C\nrs2 1 200 0.0 G T\n',                     # quotes
+    'rs1 1 100 0.0 TRUE FALSE\nrs2 1 200 0.0 TRUE TRUE\n',           # boolean-looking alleles
+    'rs1 1 100 0.0 A\nrs2 1 200 0.0 G T\n',                          # a short line (pandas: NaN)
+])
+def test_var_files_read_as_pandas_reads_them(tmp_path, body):
+    """load._read_var_file splits plain .var files itself; whatever pandas.read_csv would treat
+    specially must come out exactly as pandas gives it (reference load.py:262-263), since the
+    SNP -> block assignment is decided by equality of these values."""
+    import pandas as pd
+    from vilma_amd import load
+    path = tmp_path / 'block.var'
+    path.write_text(body)
+    want = pd.read_csv(path, header=None, sep=r'\s+', names=['ID', 'CHROM', 'BP', 'CM', 'A1', 'A2'])
+    got = load._read_var_file(path)
+    for have, col in zip(got, ('ID', 'A1', 'A2')):
+        ref = want[col].to_numpy()
+        assert len(have) == len(ref)
+        for x, y in zip(have, ref):
+            assert (x == y and type(x) is type(y)) or (x != x and y != y), (col, x, y)

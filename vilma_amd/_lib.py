@@ -92,7 +92,7 @@ def load():
         'vilma_set_mu': (C.c_int, [vp, vp]),
         'vilma_get_mu': (C.c_int, [vp, vp]),
         'vilma_get_delta': (C.c_int, [vp, vp]),
-        'vilma_get_vi_sigma': (C.c_int, [vp, vp]),
+        'vilma_get_vi_sigma': (C.c_int, [vp, vp, vp]),
         'vilma_get_moments': (C.c_int, [vp, vp, vp]),
         'vilma_eval': (C.c_int, [vp, vp, vp]),
         'vilma_eval_diff': (C.c_int, [vp, vp, vp, vp, vp]),

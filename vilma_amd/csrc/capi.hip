@@ -1027,14 +1027,18 @@ int vilma_get_delta(vilma_ctx *c, double *vi_delta) {
     return 0;
 }
 
-int vilma_get_vi_sigma(vilma_ctx *c, double *vi_sigma) {
+int vilma_get_vi_sigma(vilma_ctx *c, const double *error_scaling, double *vi_sigma) {
     if (!c || !vi_sigma) return 1;
+    if (error_scaling)
+        for (int p = 0; p < c->P; ++p)
+            if (!(error_scaling[p] > 0.0) || !std::isfinite(error_scaling[p]))
+                return fail(c, "error_scaling must be positive");
     if (vilma_sweep_drain(c)) return 1;      // the staging buffer is a trial buffer: nothing may be queued
     HIPCHK(c, hipDeviceSynchronize());
     double *stage = c->mu[c->mu_ta];         // M P N doubles: M / P components of [P][P][N] at a time
     const int nk_max = std::max(1, c->M / c->P);
     TauArg tau;
-    for (int p = 0; p < VILMA_MAX_P; ++p) tau.v[p] = p < c->P ? c->tau[p] : 1.0;
+    for (int p = 0; p < VILMA_MAX_P; ++p) tau.v[p] = p < c->P ? (error_scaling ? error_scaling[p] : c->tau[p]) : 1.0;
     const size_t per_k = (size_t)c->P * c->P * c->N;
     for (int k0 = 0; k0 < c->M; k0 += nk_max) {
         const int nk = std::min(nk_max, c->M - k0);

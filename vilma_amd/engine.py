@@ -238,10 +238,11 @@ class HipEngine:
         self._check(self.lib.vilma_get_delta(self.ctx, _ptr(out)))
         return out
 
-    def get_vi_sigma(self):
-        """[M, P, P, N] at the current error scaling, formed on the device (outputs only)."""
+    def get_vi_sigma(self, error_scaling=None):
+        """[M, P, P, N] at `error_scaling` (None: the context's), formed on the device (outputs only)."""
         out = np.empty((self.M, self.P, self.P, self.N))
-        self._check(self.lib.vilma_get_vi_sigma(self.ctx, _ptr(out)))
+        tau = None if error_scaling is None else _f64(error_scaling)
+        self._check(self.lib.vilma_get_vi_sigma(self.ctx, None if tau is None else _ptr(tau), _ptr(out)))
         return out
 
     def get_moments(self):

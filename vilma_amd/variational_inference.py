@@ -713,8 +713,7 @@ class MultiPopVI(SweepDriver):
         if (self.comm.world == 1 and hasattr(self.engine, 'get_vi_sigma')
                 and len(self._snps) == self.num_loci
                 and np.array_equal(self._snps, np.arange(self.num_loci))):
-            self.engine.set_tau(self.error_scaling)
-            return self.engine.get_vi_sigma()
+            return self.engine.get_vi_sigma(self.error_scaling)
         return self._vi_sigma_host()
 
     def _vi_sigma_host(self):
