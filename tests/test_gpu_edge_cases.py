@@ -186,7 +186,8 @@ def test_device_resident_sweeps_equal_host_decided_sweeps(shape, monkeypatch):
     (_update_error_scaling, reference variational_inference.py:441-448, 472-486) and the
     re-evaluation behind it are decided and run on the device too.
     ELBO, L, error_scaling, convergence statistics after every sweep and the final state: bit for
-    bit; and the device handed no decision back to the host."""
+    bit (to rounding where the trials store no vi_mu, see below); and the device handed no decision
+    back to the host."""
     rng = np.random.default_rng({'p1': 1, 'p2_a2': 2, 'p3': 3, 'p4_m81': 4, 'p2_m130': 5,
                                  'p2_scale_se': 6, 'p1_scale_se': 7, 'p3_scale_se': 8, 'p5': 9}[shape])
     pr = {'p1': lambda: _problem(rng, 1, [[60, 45, 70, 30]], N=215, M=9),
@@ -219,7 +220,22 @@ def test_device_resident_sweeps_equal_host_decided_sweeps(shape, monkeypatch):
     dev = run(True)
     if scale_se:
         assert any(t[3] != (1.0,) * pr['P'] for t in host[0])      # tau did get updated
-    if scale_se:
+    lazy = shape in ('p2_m130', 'p5', 'p1_scale_se')
+    if lazy:
+        # Mixtures beyond the stash: the queued sweeps' trials store no vi_mu and carry the beta loop's
+        # state as mu_k = a mu_k^stored + Sig_k c (round 5), written out once when the loop ends; the
+        # host-decided sweeps store every accepted candidate and blend the stored array again.  The
+        # same fit up to the rounding of those intermediate arrays: every decision the same (L to
+        # the bit, the same number of trials), values to 1e-12.
+        for d, h in zip(dev[0], host[0]):
+            assert d[1] == h[1]
+            assert abs(d[0] - h[0]) <= 1e-12 * abs(h[0])
+            assert d[2][0] == h[2][0]
+            np.testing.assert_allclose(d[2], h[2], rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(d[3], h[3], rtol=1e-12)
+        np.testing.assert_allclose(dev[1], host[1], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(dev[2], host[2], rtol=1e-10, atol=1e-300)
+    elif scale_se:
         # with --learn-scaling the host-decided path forms the convergence statistics in a pass of
         # its own (vilma_mean_diff), the queued path inside the sweep's last evaluation: two
         # summation orders.  The count of moved means is exact either way; the rest to rounding.
@@ -229,7 +245,8 @@ def test_device_resident_sweeps_equal_host_decided_sweeps(shape, monkeypatch):
             np.testing.assert_allclose(d[2], h[2], rtol=1e-12)
     else:
         assert dev[0] == host[0]
-    assert np.array_equal(dev[1], host[1]) and np.array_equal(dev[2], host[2])
+    if not lazy:
+        assert np.array_equal(dev[1], host[1]) and np.array_equal(dev[2], host[2])
     assert dev[3] == host[3] and host[4] == 0
     # sweeps did run from the control block -- p2_m130 too: a mixture beyond the on-chip stash gets
     # its responsibility sums from a pass behind the decision, not from the host

@@ -51,8 +51,9 @@ def test_inner_loops_on_the_device_equal_host_decided_bit_for_bit(monkeypatch, s
     candidate's responsibility sums: from the trial pass's on-chip stash (what M = 20 takes by
     itself); from a pass over the accepted candidate behind the decision (what mixtures beyond the
     stash take: forced here); and that pass behind LAZY trials, which store no vi_mu at all -- the
-    pass re-derives the accepted candidate from the trial's natural gradient and stores it (also
-    with one candidate per trial, VILMA_TWO_STEP=0: what more than two cohorts take)."""
+    state of the beta loop is carried as two numbers per SNP and written out when the loop ends (also
+    with one candidate per trial, VILMA_TWO_STEP=0: what more than two cohorts take; these two
+    variants are compared to rounding, see below)."""
     g = golden('traj_p2_mid.npz')
     # (the stash is switched off for the host-decided run too: the two ways of summing the same
     # responsibilities differ in the last bit, and that is not what is compared here)
@@ -75,8 +76,20 @@ def test_inner_loops_on_the_device_equal_host_decided_bit_for_bit(monkeypatch, s
         vi.engine.close()
         return out
     host, dev = run(False), run(True)
-    assert dev[0] == host[0]
-    assert np.array_equal(dev[1], host[1])
+    if sums.startswith('lazy'):
+        # Round 5: between two stored states lazy trials carry the beta loop's state as (a, c) --
+        # mu_k = a mu_k^stored + Sig_k c -- and write it out once, when the loop ends; the host's line
+        # search stores every accepted candidate and blends the stored (rounded) array again.  The
+        # same numbers up to the rounding of the intermediate vi_mu arrays: every decision the same
+        # (L to the bit, same trials, same points), values to 1e-12.
+        for (e_d, L_d, r_d, st_d), (e_h, L_h, r_h, st_h) in zip(dev[0], host[0]):
+            assert L_d == L_h
+            assert abs(e_d - e_h) <= 1e-12 * abs(e_h) and abs(r_d - r_h) <= 1e-9 * abs(r_h)
+            np.testing.assert_allclose(st_d, st_h, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(dev[1], host[1], rtol=1e-10, atol=1e-14)
+    else:
+        assert dev[0] == host[0]
+        assert np.array_equal(dev[1], host[1])
     assert dev[2] == host[2] and dev[3] == host[3]
     assert host[4] == 0 and dev[4] >= 15 and dev[5] == 0
 

@@ -365,7 +365,7 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
     a.pool_out = c->pool[tr]; a.m_out = c->m[tr]; a.v_out = c->v[tr]; a.lse_out = c->lse[tr];
     a.partials = c->snp_partials;
     a.pp = nullptr;
-    a.g_out = c->gbuf; a.no_store = 0;
+    a.no_store = 0;
     a.lse_ref = c->have_moments ? c->lse[cur] : nullptr;
     a.sum_partials = nullptr;
     a.scal = c->scal; a.snapshot = c->snap[c->snap_cur]; a.snapshot_out = c->snap[c->snap_cur];
@@ -378,7 +378,7 @@ void fill_snp_args(vilma_ctx *c, SnpKernelArgs &a, double step) {
 void fill_delta_args(vilma_ctx *c, DeltaArgs &a, double *out, int trial_mu = 0, int trial_mom = 0) {
     a.N = (int32_t)c->N; a.M = c->M; a.A = c->A; a.P = c->P;
     a.pp = nullptr;
-    a.mat = 0; a.mu_mat = nullptr; a.g = nullptr; a.step = 0.0;
+    a.mat = 0; a.mu_mat = nullptr; a.cvec = nullptr; a.acoef = 1.0;
     a.mu = c->mu[trial_mu == 2 ? c->mu_tb : trial_mu == 1 ? c->mu_ta : c->mu_cur];
     a.sld = c->sld; a.annot = c->annot;
     a.prec = c->prec; a.log_det = c->log_det; a.lh = c->lh;
@@ -504,6 +504,24 @@ int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev
         prof_end(c, s, e0, a.mat ? VILMA_PROF_SUMS_MAT : VILMA_PROF_SUMS);
     }
     set_launch_phase(nullptr);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+// The state lazy trials reached, a * mu[mu_from] + Sig cvec[mom] (PhasePtrs), written out into
+// mu[mu_to] by the host's own launch (a device-resident sweep handed back in the middle of a beta
+// loop: the host's line search works on stored vi_mu).  Its responsibility sums go to sums_dev.
+int vilma_detail::materialise_deferred(vilma_ctx *c, hipStream_t s, int mu_from, int mu_to, int mom,
+                                       double a_def, const double *tau, double *sums_dev) {
+    DeltaArgs a;
+    fill_delta_args(c, a, c->delta_partials);
+    a.mat = 1;
+    a.mu = c->mu[mu_from];
+    a.mu_mat = c->mu[mu_to];
+    a.cvec = c->cvec[mom];
+    a.acoef = a_def;
+    a.lse = c->lse[mom];
+    for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? tau[p] : 1.0;
+    launch_delta_sums(a, sums_dev, s);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -652,7 +670,7 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
         rc |= dev_alloc(c, &c->m[s], PN); rc |= dev_alloc(c, &c->v[s], PN);
         rc |= dev_alloc(c, &c->lse[s], N);
     }
-    rc |= dev_alloc(c, &c->gbuf, PN);
+    for (int s = 0; s < 3 && !rc; ++s) rc |= dev_alloc(c, &c->cvec[s], PN);
     rc |= dev_alloc(c, &c->snap[0], PN);
     rc |= dev_alloc(c, &c->snap[1], PN);
     rc |= dev_alloc(c, &c->snp_partials, (int64_t)snp_tile_grid(N) * (2 * (2 * P + 2) + 6));
@@ -730,7 +748,7 @@ void vilma_destroy(vilma_ctx *c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     void *ptrs[] = {c->adj, c->se, c->sld, c->scal, c->annot, c->invperm, c->prec, c->log_det,
                     c->lh, c->counts, c->sum_partials, c->mu[0], c->mu[1], c->mu[2], c->m[0], c->m[1], c->m[2], c->v[0],
-                    c->v[1], c->v[2], c->lse[0], c->lse[1], c->lse[2], c->snap[0], c->snap[1], c->gbuf, c->snp_partials, c->delta_partials, c->diff_partials};
+                    c->v[1], c->v[2], c->lse[0], c->lse[1], c->lse[2], c->snap[0], c->snap[1], c->cvec[0], c->cvec[1], c->cvec[2], c->snp_partials, c->delta_partials, c->diff_partials};
     for (void *p : ptrs) dev_free(p);
     delete c;
 }

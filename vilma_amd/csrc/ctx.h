@@ -153,7 +153,8 @@ struct vilma_ctx {
     // (an error-scaling re-evaluation in the same sweep must compare with the same old means)
     double *snap[2] = {nullptr, nullptr};
     int snap_cur = 0;
-    double *gbuf = nullptr;         // [P][N]: the natural gradient a lazy trial leaves (kernels.h)
+    double *cvec[3] = {nullptr, nullptr, nullptr};  // [P][N] beside each set of moments: the vector c of a
+                                    // state lazy trials reached (PhasePtrs, kernels.h)
     bool poison = false;            // VILMA_DEBUG_POISON=1: NaN into what a trial is about to write
     bool lazy_trial = false;        // the trials being queued store no vi_mu (set by sweep.hip)
     double *snp_partials = nullptr, *dot_partials = nullptr;
@@ -248,6 +249,9 @@ int queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, double *dsum, 
 // accepted), for mixtures too large for the trial pass's on-chip stash; and the M-step from them
 int queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev);
 int queue_mstep(vilma_ctx *c, hipStream_t s, const double *sums_dev, double *hyper_dev);
+// a * mu[mu_from] + Sig cvec[mom] -> mu[mu_to] (the state lazy trials reached, written out by the host)
+int materialise_deferred(vilma_ctx *c, hipStream_t s, int mu_from, int mu_to, int mom, double a_def,
+                         const double *tau, double *sums_dev);
 // HIP-event brackets recorded with vilma_ctx::prof_tag == tag / >= tag are forgotten (launches of
 // a queued phase that did not happen exit at once: their microseconds are not kernel times)
 void prof_drop_tag(vilma_ctx *c, int64_t tag);

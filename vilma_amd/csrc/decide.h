@@ -63,8 +63,8 @@ static __host__ __device__ inline void decide_set_phases(const SweepDecideArgs &
     const double s2 = 1.0 / Lt2;
     phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_EVAL, 0.0, 0.0, ctl->phase[0]);
     phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_TRIAL, s1, s2, ctl->phase[1]);
-    set_phase_extras(a.bases, ctl->snap_cur, a.two_snapshots != 0, ctl->tau, ctl->phase[0]);
-    set_phase_extras(a.bases, ctl->snap_cur, a.two_snapshots != 0, ctl->tau, ctl->phase[1]);
+    set_phase_extras(a.bases, ctl->snap_cur, a.two_snapshots != 0, ctl->tau, ctl->a_def, ctl->c_zero, ctl->phase[0]);
+    set_phase_extras(a.bases, ctl->snap_cur, a.two_snapshots != 0, ctl->tau, ctl->a_def, ctl->c_zero, ctl->phase[1]);
     // the sums pass works on the state the evaluation starts from (a lazy accept overrides this)
     ctl->phase[VILMA_PHASE_SUMS] = ctl->phase[VILMA_PHASE_EVAL];
 }
@@ -151,8 +151,8 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
         ctl->run_eval2 = 0;
         ctl->run_sums = 0;
         int32_t lazy_uc = 0, lazy_ua = 0, lazy_macc = 0;
-        double lazy_step = 0.0;
-        bool lazy_accept = false;
+        double lazy_a = 1.0;
+        bool lazy_materialise = false;
         rep.orig = ctl->cur_obj;
         rep.fa = det_objective(P, a.chi, ctl->tau, ctl->hrl, results + a.o_ta);
         rep.fb = a.have_b ? det_objective(P, a.chi, ctl->tau, ctl->hrl, results + a.o_tb) : 0.0;
@@ -203,10 +203,21 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                 const double step_acc = choice == 1 ? ctl->phase[VILMA_PHASE_TRIAL].step
                                                     : ctl->phase[VILMA_PHASE_TRIAL].step2;
                 const int32_t macc = choice == 1 ? mc : mb;        // the accepted candidate's moments
-                if (choice == 1 || a.lazy) {
+                // lazy trials: the accepted state is a' (stored vi_mu) + Sig c', a' = (1 - step) a, its c'
+                // beside its moments (PhasePtrs).  While the beta loop goes on that is all that moves;
+                // when it ends the sums pass behind this decision writes the state out (role ua).
+                const double a_acc = (a.lazy ? ctl->a_def : 1.0) * (1.0 - step_acc);
+                if (a.lazy && !ends) {
+                    ctl->a_def = a_acc;
+                    ctl->c_zero = 0;
+                } else if (choice == 1 || a.lazy) {
                     ctl->mu_role[0] = ua; ctl->mu_role[1] = uc; ctl->mu_role[2] = ub;
                 } else {
                     ctl->mu_role[0] = ub; ctl->mu_role[1] = ua; ctl->mu_role[2] = uc;
+                }
+                if (a.lazy && ends) {
+                    ctl->a_def = 1.0;
+                    ctl->c_zero = 1;
                 }
                 // the trial wrote candidate A's moments to slot mc and B's to mb (ma held the state
                 // it started from).  An evaluation next: it takes the accepted candidate's as its
@@ -225,22 +236,22 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                     ctl->run_eval = 0;
                     rep.outcome = VILMA_OUT_ACCEPT_CONTINUE;
                 }
-                ctl->run_sums = (!a.mstep_inside && (ends || a.lazy)) ? 1 : 0;
-                lazy_uc = uc; lazy_ua = ua; lazy_macc = macc; lazy_step = step_acc;
-                lazy_accept = a.lazy != 0;
+                ctl->run_sums = (!a.mstep_inside && ends) ? 1 : 0;
+                lazy_uc = uc; lazy_ua = ua; lazy_macc = macc; lazy_a = a_acc;
+                lazy_materialise = a.lazy != 0 && ends;
                 double Lnext = Lacc / 1.25;
                 Lnext = Lnext > 1.0 ? Lnext : 1.0;
                 ctl->L_try = Lnext;
                 decide_set_phases(a, ctl);
-                if (lazy_accept) {
-                    // the sums pass re-derives the accepted candidate from the state the trial
-                    // started from and the trial's natural gradient, and writes it where the roles
-                    // above already say the current vi_mu is
+                if (lazy_materialise) {
+                    // the sums pass derives the accepted state from the stored vi_mu the beta loop
+                    // started from, (a', c'), and writes it where the roles above already say the
+                    // current vi_mu is
                     PhasePtrs &sp = ctl->phase[VILMA_PHASE_SUMS];
                     sp.mu_in = a.bases.mu[lazy_uc];
                     sp.mu_mat = a.bases.mu[lazy_ua];
-                    sp.g_pend = a.bases.g;
-                    sp.step_pend = lazy_step;
+                    sp.c_pend = a.bases.c[lazy_macc];
+                    sp.a_pend = lazy_a;
                     sp.lse_ref = a.bases.lse[lazy_macc];
                 }
             }
@@ -280,4 +291,5 @@ static __host__ __device__ inline void decide_snapshot_scalars(const SweepDecide
         x[SNAP_MOM_ROLE + q] = (double)ctl->mom_role[q];
     }
     for (int p = 0; p < VILMA_MAX_P; ++p) { x[SNAP_TAU + p] = ctl->tau[p]; x[SNAP_HRL + p] = ctl->hrl[p]; }
+    x[SNAP_A_DEF] = ctl->a_def; x[SNAP_C_ZERO] = (double)ctl->c_zero;
 }

@@ -107,15 +107,24 @@ struct PhasePtrs {
     double *snap_out;
     double step, step2;
     double tau[VILMA_MAX_P];            // error_scaling in force (the device may have updated it)
-    // "lazy" trials (mixtures beyond the on-chip stash, see SnpKernelArgs::g_out): the trial leaves
-    // its natural gradient g [P][N] instead of the candidates' vi_mu; the pass that forms the
-    // accepted candidate's responsibility sums re-derives that candidate from (mu_in, g_pend,
-    // step_pend) and writes it to mu_mat -- one vi_mu array written per accepted update instead
-    // of two per trial
-    double *mu_mat;                     // SUMS phase: where the accepted candidate's vi_mu goes, or nullptr
-    const double *g_pend;               // ... the trial's natural gradient
-    double step_pend;                   // ... the accepted step
-    double *g_out;                      // TRIAL phase: where a lazy trial leaves its natural gradient
+    // "lazy" trials (mixtures beyond the on-chip stash, see SnpKernelArgs::no_store) store no
+    // candidate vi_mu.  Every state the beta loop reaches from a stored vi_mu ("base") is
+    //     mu_k = a mu_k^base + Sig_k c,      Sig_k = (Prec_k + D)^-1,   a scalar, c [P] per SNP,
+    // because a blend mu_k' = Sig_k (s g + (1 - s) Lam_k mu_k) = (1 - s) mu_k + s Sig_k g keeps that form:
+    // a' = (1 - s) a, c' = (1 - s) c + s g.  A lazy trial reads the base, the coefficient a (a_def) and
+    // the vector c of the state it starts from (c_cur; c_zero: that state IS the base) and leaves
+    // its candidates' c' beside their moments (c_out, c_out2); an accepted update that does not end the
+    // beta loop only moves (a, c) in the control block -- nothing of size [M][P][N] is read again or
+    // written.  The pass that forms the responsibility sums when the loop ends derives the accepted
+    // state from (mu_in = base, a_pend, c_pend) and writes it to mu_mat: ONE vi_mu array written per
+    // SWEEP where round 4 wrote one per accepted update.
+    double *mu_mat;                     // SUMS phase: where the accepted state's vi_mu goes, or nullptr
+    const double *c_pend;               // ... its vector c [P][N]
+    double a_pend;                      // ... its coefficient a
+    const double *c_cur;                // TRIAL phase: c of the state the trial starts from
+    double *c_out, *c_out2;             // ... where the candidates' c' go
+    double a_def;                       // ... a of the state the trial starts from
+    int32_t c_zero;                     // ... that state is the stored vi_mu itself (a = 1, c = 0)
 };
 #define VILMA_PHASE_EVAL 0      // an evaluation of the current vi_mu (after the M-step / a tau update)
 #define VILMA_PHASE_TRIAL 1     // a beta trial from the current state
@@ -144,10 +153,13 @@ struct SweepCtl {
     double running;             // running ELBO change as of the start of the sweep in progress
     double tau[VILMA_MAX_P];    // error_scaling in force
     double hrl[VILMA_MAX_P];    // 0.5 * ld_rank * log(tau) (det_log: the host gets the same bits)
+    double a_def;               // lazy trials: the current state is a_def * (vi_mu of role 0) + Sig c, c in
+    int32_t c_zero;             // the c buffer beside the current moments; c_zero: it is that vi_mu itself
     PhasePtrs phase[3];
 };
-// base pointers of the three buffers of each kind, the two snapshot buffers, the gradient buffer
-struct BufferBases { double *mu[3], *pool[3], *m[3], *v[3], *lse[3], *snap[2], *g; };
+// base pointers of the three buffers of each kind (c: the vectors of lazy trials, one beside each set
+// of moments), the two snapshot buffers
+struct BufferBases { double *mu[3], *pool[3], *m[3], *v[3], *lse[3], *c[3], *snap[2]; };
 // The pointers of a phase from the roles at the start of its stage (cur, ta, tb).  The
 // evaluation reads the current vi_mu and writes the moments of role ta; the trial that follows
 // treats those as current (the evaluation is accepted unconditionally), writes candidate A into
@@ -164,16 +176,18 @@ static __host__ __device__ inline void phase_ptrs(const BufferBases &b, const in
     o.pool_cur = b.pool[cur]; o.m_cur = b.m[cur]; o.lse_ref = b.lse[cur];
     o.pool_out = b.pool[ta]; o.m_out = b.m[ta]; o.v_out = b.v[ta]; o.lse_out = b.lse[ta];
     o.pool_out2 = b.pool[tb]; o.m_out2 = b.m[tb]; o.v_out2 = b.v[tb]; o.lse_out2 = b.lse[tb];
+    o.c_cur = b.c[cur]; o.c_out = b.c[ta]; o.c_out2 = b.c[tb];
     o.step = step; o.step2 = step2;
 }
 // (snap_in / snap_out and tau of a PhasePtrs are set by set_phase_extras)
 static __host__ __device__ inline void set_phase_extras(const BufferBases &b, int snap_cur,
                                                         bool two_snapshots, const double *tau,
-                                                        PhasePtrs &o) {
+                                                        double a_def, int32_t c_zero, PhasePtrs &o) {
     o.snap_in = b.snap[snap_cur];
     o.snap_out = b.snap[two_snapshots ? 1 - snap_cur : snap_cur];
     for (int p = 0; p < VILMA_MAX_P; ++p) o.tau[p] = tau[p];
-    o.mu_mat = nullptr; o.g_pend = nullptr; o.step_pend = 0.0; o.g_out = b.g;
+    o.mu_mat = nullptr; o.c_pend = nullptr; o.a_pend = 1.0;
+    o.a_def = a_def; o.c_zero = c_zero;
 }
 // launch attribute of the calling thread like set_launch_predicate: kernels launched while it is
 // set work on *pp's buffers (read on the device when the kernel starts); nullptr = their arguments
@@ -209,11 +223,9 @@ struct SnpKernelArgs {
     // per-tile responsibility sums [candidate][tile][A*M] of the candidates (nullptr: not wanted)
     double *sum_partials;
     TauArg tau;
-    // a LAZY beta trial (no_store != 0; launch_snp_pass without the stash only): the candidates'
-    // vi_mu are not stored -- every candidate is mu(s) = Sig_k (s g + (1 - s) Lam_k mu_k), so the
-    // natural gradient g [P][N] (written to g_out) and the accepted step describe it -- and the pass
-    // that needs the accepted one re-derives it (DeltaArgs::mat)
-    double *g_out;
+    // a LAZY beta trial (no_store != 0; launch_snp_pass without the stash only; queued sweeps only, so
+    // its buffers come from PhasePtrs): the candidates' vi_mu are not stored -- see PhasePtrs --
+    // and the pass that needs the accepted state derives it (DeltaArgs::mat)
     int32_t no_store;
     const int *pred;          // filled by the launcher (set_launch_predicate)
     const PhasePtrs *pp;      // filled by the launcher (set_launch_phase)
@@ -310,13 +322,13 @@ struct DeltaArgs {
     const int32_t *annot;
     const double *prec, *log_det, *lh;
     const double *lse;        // [N]
-    // mat != 0: `mu` is the state a lazy trial started from; the state whose sums are wanted is the
-    // candidate mu_k' = Sig_k (step g + (1 - step) Lam_k mu_k), which is also written to mu_mat
-    // (with pp non-null: PhasePtrs::mu_mat / g_pend / step_pend)
+    // mat != 0: `mu` is the stored vi_mu lazy trials started from; the state whose sums are wanted is
+    // mu_k' = acoef mu_k + Sig_k cvec (PhasePtrs), which is also written to mu_mat
+    // (with pp non-null: PhasePtrs::mu_mat / c_pend / a_pend)
     int32_t mat;
     double *mu_mat;           // [M][P][N]
-    const double *g;          // [P][N]
-    double step;
+    const double *cvec;       // [P][N]
+    double acoef;
     double *out;              // mode 0: partial rows [grid*4][A*M]; mode 1: delta [M][N]
     TauArg tau;
     const int *pred;          // filled by the launcher (set_launch_predicate)
@@ -375,7 +387,7 @@ enum {
     SNAP_CUR_OBJ, SNAP_DELTA_SUM, SNAP_RUNNING, SNAP_RUNNING_NONE, SNAP_INNER_IT, SNAP_ORIG,
     SNAP_FA, SNAP_FB, SNAP_EVAL_OBJ, SNAP_CONSUMED, SNAP_SWEEP_END, SNAP_SWEEP_CHANGE,
     SNAP_L_TRIED, SNAP_SNAP_CUR, SNAP_RUN_EVAL, SNAP_RUN_EVAL2, SNAP_EVAL_PENDING, SNAP_RUN_SUMS,
-    SNAP_MU_ROLE = 26, SNAP_MOM_ROLE = 29, SNAP_TAU = 32, SNAP_HRL = 40,
+    SNAP_MU_ROLE = 26, SNAP_MOM_ROLE = 29, SNAP_TAU = 32, SNAP_HRL = 40, SNAP_A_DEF = 48, SNAP_C_ZERO = 49,
     SNAP_SERIAL = VILMA_SNAP_EXTRA - 1
 };
 #define VILMA_DECIDE_TRIAL 0    // behind a beta trial (and the evaluation in front of it, if one ran)

@@ -1685,7 +1685,8 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
         q.pool_out2 = t->pool_out2; q.m_out2 = t->m_out2; q.v_out2 = t->v_out2; q.lse_out2 = t->lse_out2;
         q.step = t->step; q.step2 = t->step2;
         q.snap_in = t->snap_in; q.snap_out = t->snap_out;
-        q.g_out = t->g_out;
+        q.c_cur = t->c_cur; q.c_out = t->c_out; q.c_out2 = t->c_out2;
+        q.a_def = t->a_def; q.c_zero = t->c_zero;
 #pragma unroll
         for (int p = 0; p < P; ++p) q.tau[p] = t->tau[p];
     } else {
@@ -1695,7 +1696,8 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
         q.pool_out2 = a.pool_out2; q.m_out2 = a.m_out2; q.v_out2 = a.v_out2; q.lse_out2 = a.lse_out2;
         q.step = a.step; q.step2 = a.step2;
         q.snap_in = a.snapshot; q.snap_out = a.snapshot_out;
-        q.g_out = a.g_out;
+        q.c_cur = nullptr; q.c_out = nullptr; q.c_out2 = nullptr;      // (lazy trials are queued ones)
+        q.a_def = 1.0; q.c_zero = 1;
 #pragma unroll
         for (int p = 0; p < P; ++p) q.tau[p] = a.tau.v[p];
     }
@@ -1792,8 +1794,6 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
             const double linked = q.pool_cur[(int64_t)(P + p) * N64 + pos[p]];
             const double m = q.m_cur[p * N64 + ii];
             g[p] = (adj[p] - (linked / se[p] - m * sld[p])) / q.tau[p];
-            // a lazy trial leaves g instead of its candidates' vi_mu (one wave per tile writes it)
-            if (NOSTORE && (SNP_SPLIT != 4 || w == 0) && live) q.g_out[p * N64 + i] = g[p];
         }
     }
     const double *lh = a.lh + (ONE_ANNOT ? 0 : (int64_t)a.annot[ii] * M);
@@ -1811,6 +1811,25 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
     step[0] = q.step;
     mu_out[0] = q.mu_out;
     if (NS == 2) { step[NS - 1] = q.step2; mu_out[NS - 1] = q.mu_out2; }
+    // A lazy trial (PhasePtrs): the state it starts from is a0 (stored vi_mu) + Sig c0, its candidates
+    // are ac (stored vi_mu) + Sig cc with ac = (1 - s) a0, cc = (1 - s) c0 + s g -- the blend
+    // Sig (s g + (1 - s) Lam mu) written in the two numbers that describe it.  The candidates' cc go
+    // beside their moments (one wave per tile writes them).
+    double ac[NS], cc[NS][P];
+    if (NOSTORE) {
+        const double a0 = q.c_zero ? 1.0 : q.a_def;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) ac[c] = a0 * (1.0 - step[c]);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const double c0 = q.c_zero ? 0.0 : q.c_cur[p * N64 + ii];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                cc[c][p] = (1.0 - step[c]) * c0 + step[c] * g[p];
+                if ((SNP_SPLIT != 4 || w == 0) && live) (c == 0 ? q.c_out : q.c_out2)[p * N64 + i] = cc[c][p];
+            }
+        }
+    }
 
     const const_tab prec_tab = as_table(a.prec);
     const const_tab lh_tab = as_table(a.lh);          // one annotation: the row is wave-uniform
@@ -1881,15 +1900,17 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
                 double nat[P], mun[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    nat[p] = BLEND ? (step[c] * g[p] + (1.0 - step[c]) * told[p]) : told[p];
+                    nat[p] = !BLEND ? told[p]
+                             : NOSTORE ? (ac[c] * told[p] + cc[c][p])      // Lam (ac mu + Sig cc)
+                                       : (step[c] * g[p] + (1.0 - step[c]) * told[p]);
                 double quad = 0.0;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     double t = mul[kk][p];
                     if (BLEND) {
-                        t = 0.0;
+                        t = NOSTORE ? ac[c] * mul[kk][p] : 0.0;
 #pragma unroll
-                        for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+                        for (int q = 0; q < P; ++q) t += sig[p][q] * (NOSTORE ? cc[c][q] : nat[q]);
 #if !MU_PAIRED
                         if (!NOSTORE && !MAXONLY) {
 #ifndef SNP_DIAG_NOSTORE                 // (diagnostic builds of profiles/microbench_snp.py only)
@@ -2299,25 +2320,25 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
     // phase starts from (the candidate the decision accepted)
     const double *mu_state = a.mu, *lse_state = a.lse;
     double *mu_mat = a.mu_mat;
-    const double *g_state = a.g;
-    double step = a.step;
+    const double *c_state = a.cvec;
+    double acoef = a.acoef;
     double d[P];
     if (a.pp != nullptr) {
         const phase_tab t = PHASE(a.pp);
         mu_state = t->mu_in;
         lse_state = t->lse_ref;
         mu_mat = t->mu_mat;
-        g_state = t->g_pend;
-        step = t->step_pend;
+        c_state = t->c_pend;
+        acoef = t->a_pend;
 #pragma unroll
         for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / t->tau[p];
     } else {
 #pragma unroll
         for (int p = 0; p < P; ++p) d[p] = a.sld[p * N64 + ii] / a.tau.v[p];
     }
-    double g[P];
+    double cv[P];            // MAT: the state is acoef (stored vi_mu) + Sig cv (PhasePtrs)
 #pragma unroll
-    for (int p = 0; p < P; ++p) g[p] = MAT ? g_state[p * N64 + ii] : 0.0;
+    for (int p = 0; p < P; ++p) cv[p] = MAT ? c_state[p * N64 + ii] : 0.0;
     const int ann = ONE_ANNOT ? 0 : a.annot[ii];
     const double *lh = a.lh + (int64_t)ann * M;
     const double lse = lse_state[ii];
@@ -2388,22 +2409,15 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
             const double lhk = (KS == 1 && ONE_ANNOT) ? lh_tab[k] : lh[k];
             double wdet;
             if (MAT) {
-                double sig[P][P], told[P], nat[P];
+                double sig[P][P], base[P];
                 wdet = spd_inverse<P>(lam, sig);
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int q = 0; q < P; ++q) t += lam[p][q] * mu[u][q];
-                    told[p] = t;
-                }
-#pragma unroll
-                for (int p = 0; p < P; ++p) nat[p] = step * g[p] + (1.0 - step) * told[p];
+                for (int p = 0; p < P; ++p) base[p] = mu[u][p];
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    double t = 0.0;
+                    double t = acoef * base[p];
 #pragma unroll
-                    for (int q = 0; q < P; ++q) t += sig[p][q] * nat[q];
+                    for (int q = 0; q < P; ++q) t += sig[p][q] * cv[q];
                     mu[u][p] = t;
                     if constexpr (!PAIR_BATCH && !PAIR_COMP) MU_STORE(&mu_mat[mu_base + MU_ROW(k * P + p, N64)], t);
                 }

@@ -551,9 +551,9 @@ BufferBases buffer_bases(const vilma_ctx *c) {
     BufferBases b;
     for (int q = 0; q < 3; ++q) {
         b.mu[q] = c->mu[q]; b.pool[q] = c->pool[q]; b.m[q] = c->m[q]; b.v[q] = c->v[q]; b.lse[q] = c->lse[q];
+        b.c[q] = c->cvec[q];
     }
     b.snap[0] = c->snap[0]; b.snap[1] = c->snap[1];
-    b.g = c->gbuf;
     return b;
 }
 
@@ -691,6 +691,8 @@ int pipeline_arm(vilma_ctx *c, SweepState *s, hipStream_t st, const double *L, d
     // moments take that place
     k.mu_role[0] = c->mu_cur; k.mu_role[1] = c->mu_ta; k.mu_role[2] = c->mu_tb;
     k.mom_role[0] = c->mom_ta; k.mom_role[1] = c->mom_cur; k.mom_role[2] = c->mom_tb;
+    k.a_def = 1.0;          // the host's current vi_mu is stored as it is
+    k.c_zero = 1;
     k.L0 = L[0];
     k.L_try = std::max(1.0, L[0] / 1.25);
     k.cur_obj = s->objective;
@@ -774,6 +776,16 @@ int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const DecideR
     s->cur_sums = -1;
     s->armed = false;
     s->resume = SweepState::Resume();
+    if (!k.c_zero) {
+        // handed back in the middle of a beta loop of lazy trials: the current state exists as
+        // (stored vi_mu, a, c) only -- write it out for the host's kernels
+        if (materialise_deferred(c, st, k.mu_role[0], k.mu_role[1], k.mom_role[1], k.a_def, k.tau,
+                                 s->results + s->o_sa)) return 1;
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->mu_cur = k.mu_role[1]; c->mu_ta = k.mu_role[0];
+        s->mirror.a_def = 1.0;
+        s->mirror.c_zero = 1;
+    }
     const bool trial_pending = q.args.mode == VILMA_DECIDE_TRIAL;
     if (trial_pending && q.args.lazy) {
         // the trial's candidates exist as sums only (no vi_mu was stored): the host's line search
@@ -962,8 +974,8 @@ int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, doubl
             if (rep.outcome == VILMA_OUT_ACCEPT_CONTINUE || rep.outcome == VILMA_OUT_REJECTED) {
                 prof_drop_tag(c, 4 * q.tag + 1);
                 prof_drop_tag(c, 4 * q.tag + 2);
-                // (the sums pass runs behind every accepted lazy trial: it is what stores the candidate)
-                if (rep.outcome == VILMA_OUT_REJECTED || !q.args.lazy) prof_drop_tag(c, 4 * q.tag + 3);
+                // (so does the sums pass: the state lazy trials reach is only written out when the loop ends)
+                prof_drop_tag(c, 4 * q.tag + 3);
             }
         } else if (q.args.mode == VILMA_DECIDE_EVAL && q.tag && rep.outcome != VILMA_OUT_TAU_UPDATED) {
             prof_drop_tag(c, 4 * q.tag + 2);        // the re-evaluation's launches exit at once
