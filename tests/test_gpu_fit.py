@@ -534,3 +534,39 @@ def test_output_arrays_formed_on_the_device(name):
         np.testing.assert_allclose(dev, host, rtol=1e-12, atol=1e-300)
     assert vi_delta.shape == (vi.num_loci, vi.num_mix) and vi_delta.flags.c_contiguous
     np.testing.assert_allclose(vi_delta.sum(axis=1), 1.0, rtol=1e-12)
+
+
+@pytest.mark.parametrize('kill', [1, 3])
+def test_a_lazy_beta_loop_handed_back_to_the_host_mid_way(monkeypatch, kill):
+    """Lazy trials carry the beta loop's state as (stored vi_mu, a, c) and nothing of size [M][P][N]
+    is written until the loop ends.  If the device hands a sweep back to the host in the middle of
+    such a loop (VILMA_DEBUG_KILL_DEFERRED=k: the k-th trial decision that finds the state in that
+    form refuses to decide; in a real fit: a line search beyond L_MAX), the host writes the state
+    out and its own line search -- which works on stored vi_mu -- finishes the sweep: the fit equals
+    the host-decided one (every decision, values to rounding)."""
+    g = golden('traj_p2_mid.npz')
+    monkeypatch.setenv('VILMA_TILE_SUMS', '0')
+    monkeypatch.setenv('VILMA_PIPE_LAZY', '1')
+
+    def run(lookahead, kill_at):
+        monkeypatch.setenv('VILMA_LOOKAHEAD', '1' if lookahead else '0')
+        monkeypatch.setenv('VILMA_DEBUG_KILL_DEFERRED', str(kill_at))
+        vi, _ = product_vi_from_traj(g)
+        np.random.seed(int(g['seed']))
+        vi._initialize()
+        state, trace = None, []
+        for k in range(len(g['elbo'])):
+            state, stats = vi.sweep(state, lookahead=k + 1 < len(g['elbo']))
+            trace.append((state['elbo'], tuple(state['L']), state['running']))
+        out = (trace, vi._params()[0].copy(), vi.n_trials, vi.n_stages_skipped)
+        vi.engine.close()
+        return out
+    host, dev = run(False, 0), run(True, kill)
+    assert dev[3] >= 1                                  # a sweep did come back to the host
+    for (e_d, L_d, r_d), (e_h, L_h, r_h) in zip(dev[0], host[0]):
+        assert L_d == L_h
+        assert abs(e_d - e_h) <= 1e-12 * abs(e_h) and abs(r_d - r_h) <= 1e-9 * abs(r_h)
+    np.testing.assert_allclose(dev[1], host[1], rtol=1e-10, atol=1e-14)
+    assert dev[2] == host[2]
+    for (e_d, _, _), e_ref in zip(dev[0], g['elbo']):
+        assert abs(e_d - e_ref) < 1e-9 * abs(e_ref)     # ... and the reference's own trajectory

@@ -12,7 +12,7 @@ struct SweepDecideArgs {
     int32_t mode, P, A, M;
     int32_t check_convergence;       // veto when dsum[0] == 0
     int32_t have_b, have_sums_b;     // candidate B evaluated / its responsibility sums available
-    int32_t mstep_inside, lazy, scale_se, two_snapshots, max_inner;
+    int32_t mstep_inside, lazy, scale_se, two_snapshots, max_inner, debug_kill_deferred;
     double chi[VILMA_MAX_P], ranks[VILMA_MAX_P];
     double rel_tol, abs_tol, rate, l_max, em_tol;
     SweepCtl *ctl;
@@ -33,6 +33,7 @@ static inline SweepDecideArgs decide_args(const SweepDecideParams &p) {
     a.mstep_inside = p.mstep_inside; a.lazy = p.lazy; a.scale_se = p.scale_se;
     a.two_snapshots = p.two_snapshots;
     a.max_inner = p.max_inner;
+    a.debug_kill_deferred = p.debug_kill_deferred;
     for (int q = 0; q < VILMA_MAX_P; ++q) {
         a.chi[q] = q < p.P ? p.chi[q] : 0.0;
         a.ranks[q] = q < p.P ? p.ranks[q] : 1.0;
@@ -146,6 +147,10 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
         }
     }
     if (a.mode == VILMA_DECIDE_EVAL && rep.outcome != VILMA_OUT_TAU_UPDATED) ctl->run_eval2 = 0;
+    if (a.mode == VILMA_DECIDE_TRIAL && !dead && a.debug_kill_deferred > 0 && !ctl->c_zero) {
+        ctl->dbg_deferred += 1;
+        if (ctl->dbg_deferred == a.debug_kill_deferred) dead = true;
+    }
     // ---- (2) the line search on the trial's candidates
     if (a.mode == VILMA_DECIDE_TRIAL && !dead) {
         ctl->run_eval2 = 0;

@@ -155,6 +155,7 @@ struct SweepCtl {
     double hrl[VILMA_MAX_P];    // 0.5 * ld_rank * log(tau) (det_log: the host gets the same bits)
     double a_def;               // lazy trials: the current state is a_def * (vi_mu of role 0) + Sig c, c in
     int32_t c_zero;             // the c buffer beside the current moments; c_zero: it is that vi_mu itself
+    int32_t dbg_deferred;       // (tests) TRIAL decisions that found the state in that form so far
     PhasePtrs phase[3];
 };
 // base pointers of the three buffers of each kind (c: the vectors of lazy trials, one beside each set
@@ -411,6 +412,8 @@ struct SweepDecideParams {
     int scale_se;                   // an EVAL decision may update tau
     int two_snapshots;              // evaluations write their means to the other snapshot buffer
     int max_inner;                  // MAX_NUM_ITERS
+    int debug_kill_deferred;        // tests (VILMA_DEBUG_KILL_DEFERRED=k): the k-th TRIAL decision that finds
+                                    // the state carried as (a, c) hands the sweep back to the host undecided
     const double *chi, *ranks;      // host [P]
     double rel_tol, abs_tol, rate, l_max, em_tol;
     SweepCtl *ctl;

@@ -570,6 +570,10 @@ SweepDecideParams decide_params(vilma_ctx *c, SweepState *s, int mode, bool veto
     p.scale_se = (s->scale_se && allow_tau) ? 1 : 0;
     p.two_snapshots = 1;
     p.max_inner = MAX_NUM_ITERS;
+    {
+        const char *e = std::getenv("VILMA_DEBUG_KILL_DEFERRED");
+        p.debug_kill_deferred = e ? std::atoi(e) : 0;
+    }
     p.chi = s->chi.data(); p.ranks = s->ranks.data();
     p.rel_tol = REL_TOL; p.abs_tol = ABS_TOL; p.rate = s->pipe_rate; p.l_max = L_MAX; p.em_tol = EM_TOL;
     p.ctl = c->ctl; p.results = s->results;
