@@ -395,7 +395,11 @@ def main(argv=None, engine_factory=None):
     # store, two products) are bracketed separately and pooled for the roofline: the algorithmic
     # bytes of a launch are the store once either way
     sym1, sym2 = prof['ld_sym_kernel'], prof['ld_sym_kernel_two_rhs']
-    pooled = {'ld_sym_kernel': (sym1[0] + sym2[0], sym1[1] + sym2[1]),
+    # (the library's bracket kinds keep round 1's names; the kernel behind the dense product is
+    # ld_tile_kernel since round 5 -- ld_sym_kernel with VILMA_LD_TILE=0)
+    tile_rows, tile_slabs, tile_items = engine.ld_tile() if hasattr(engine, 'ld_tile') else (0, 0, 0)
+    sym_name = 'ld_tile_kernel' if tile_rows > 0 else 'ld_sym_kernel'
+    pooled = {sym_name: (sym1[0] + sym2[0], sym1[1] + sym2[1]),
               'ld_eig_fused_kernel': prof['ld_eig_fused_kernel']}
     dom = max(pooled, key=lambda k: pooled[k][0])
     kernel_ms, launches = pooled[dom]
@@ -428,8 +432,8 @@ def main(argv=None, engine_factory=None):
     # bracketed on the same sampling tick, so launches_k / sampled products = launches of kind k
     # per LD product, and the sweep's algorithmic bytes follow from the exact product count.
     mp_bytes = 8.0 * shard.N * M * P
-    kinds = [('ld_sym_kernel<1>', 'ld_sym_kernel', alg_dense),
-             ('ld_sym_kernel<2>', 'ld_sym_kernel_two_rhs', alg_dense),
+    kinds = [(sym_name + '<1>', 'ld_sym_kernel', alg_dense),
+             (sym_name + '<2>', 'ld_sym_kernel_two_rhs', alg_dense),
              ('ld_eig_fused_kernel', 'ld_eig_fused_kernel', alg_eig),
              ('snp_pass_eval', 'snp_pass_eval', mp_bytes),
              ('snp_pass_trial', 'snp_pass_trial', 2 * mp_bytes),
@@ -492,6 +496,9 @@ def main(argv=None, engine_factory=None):
                                              '8 n^2 as full matrices; the symmetric kernel needs the lower triangle, half of it' if shard.kind == 'ar1' else '8 n r, U counted once',
                                              'WITH --learn-scaling (error_scaling updated by EM)' if args.learn_scaling else 'no --learn-scaling'),
             'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
+            'ld_work_items': ('%d per launch: tiles of %d rows x %d slabs of 128 columns (ld_tile_kernel)'
+                              % (tile_items, tile_rows, tile_slabs)) if tile_rows > 0 else
+                             ('%d per launch: one slab chunk each (ld_sym_kernel)' % tile_items),
             'points_evaluated_per_sweep': n_eval / args.steps,
             # a beta trial evaluates the step the line search tries now and the one it would try
             # next in ONE pass over the LD store: fewer passes than points

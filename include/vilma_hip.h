@@ -125,6 +125,12 @@ int vilma_ld_end(vilma_ctx *ctx, int cohort);
  * (matrix_structures.py:389-408) including the perm gather, inv_perm scatter and zeros at
  * missing.  x, y: device pointers [P*N] in SNP order (row p = cohort p). */
 int vilma_ld_matvec(vilma_ctx *ctx, void *stream, int cohort, const double *x, double *y);
+/* The same product for TWO right-hand sides in one pass over the LD store (every element is loaded
+ * once for both): what the product behind a two-step beta trial does; each result is bit-identical
+ * to vilma_ld_matvec's.  BlockDiagonalMatrix.dot with a two-column right-hand side
+ * (matrix_structures.py:389-408). */
+int vilma_ld_matvec2(vilma_ctx *ctx, void *stream, int cohort, const double *x0, const double *x1,
+                     double *y0, double *y1);
 
 /* Algorithmic bytes one vilma_eval/vilma_trial_beta streams from the LD store (all cohorts):
  * 8 * sum_b n_b^2 (dense) or 8 * sum_b n_b r_b (eigen form, U counted once) -- SURVEY.md 8(d).
@@ -443,6 +449,11 @@ int vilma_prof_stream_pattern(vilma_ctx *ctx, void *stream, int passes, int chun
                               int scattered, int grid, int writes, double *ms_per_pass,
                               int64_t *bytes_per_pass);
 int vilma_prof_ld_order(vilma_ctx *ctx, int order);
+/* Shape of the dense product's work items once the LD store is complete: rows per row strip and
+ * 128-column slabs per column strip of ld_tile_kernel (chosen from the shard's size unless
+ * VILMA_LD_TILE=rows,slabs says otherwise; 0, 0 with VILMA_LD_TILE=0: one workgroup per slab chunk,
+ * ld_sym_kernel), and the number of work items of one launch over all cohorts. */
+int vilma_prof_ld_tile(vilma_ctx *ctx, int *tile_rows, int *tile_slabs, int *n_items);
 int vilma_prof_ld_trace(vilma_ctx *ctx, double *buf_dev, int64_t capacity_rows);
 
 /* Debug poison.  With VILMA_DEBUG_POISON=1 in the environment when vilma_create runs, every beta trial

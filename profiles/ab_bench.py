@@ -20,26 +20,30 @@ def main():
     ap.add_argument('--libs', required=True, help='comma-separated: "default" or a path to a variant .so')
     ap.add_argument('--runs', nargs='+', required=True, help='bench.py argument strings')
     ap.add_argument('--repeat', type=int, default=2)
+    ap.add_argument('--envs', nargs='*', default=[''],
+                    help='environment variants alternated like the libraries: "NAME=VALUE[ NAME2=VALUE2]" ("" = none)')
     a = ap.parse_args()
     libs = a.libs.split(',')
     for run in a.runs:
         for _ in range(a.repeat):
-            for lib in libs:
+            for lib, ev in [(l, e) for l in libs for e in a.envs]:
                 env = dict(os.environ)
                 env.pop('VILMA_HIP_LIB', None)
+                for kv in ev.split():
+                    env[kv.split('=', 1)[0]] = kv.split('=', 1)[1]
                 if lib != 'default':
                     env['VILMA_HIP_LIB'] = os.path.join(ROOT, lib)
                 cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu-baseline'] + run.split()
                 r = subprocess.run(cmd, env=env, capture_output=True, text=True)
                 line = [l for l in r.stdout.splitlines() if l.startswith('{')]
                 if r.returncode or not line:
-                    print('%-34s %s | FAILED rc %d: %s' % (lib, run, r.returncode, r.stderr[-300:]), flush=True)
+                    print('%-34s %s | FAILED rc %d: %s' % (lib + ' ' + ev, run, r.returncode, r.stderr[-300:]), flush=True)
                     continue
                 j = json.loads(line[-1])
                 rf = j.get('roofline', {})
                 ks = {k['name']: round(k['avg_ms'], 4) for k in rf.get('kernels', [])}
                 print('%-34s %s | %.1f sweeps/s %.4f ms | %s %.4f ms frac %.3f | %s'
-                      % (lib, run, j['value'], j['ms_per_step'], rf.get('kernel'), rf.get('avg_launch_ms', 0.0),
+                      % (lib + ' ' + ev, run, j['value'], j['ms_per_step'], rf.get('kernel'), rf.get('avg_launch_ms', 0.0),
                          rf.get('frac', 0.0), ks), flush=True)
 
 

@@ -14,7 +14,7 @@ import sys
 
 import pandas as pd
 
-OURS = ("ld_sym_combine_kernel", "ld_sym_kernel", "ld_eig_fused_kernel", "ld_eig_wave_kernel",
+OURS = ("ld_tile_combine_kernel", "ld_tile_kernel", "ld_sym_combine_kernel", "ld_sym_kernel", "ld_eig_fused_kernel", "ld_eig_wave_kernel",
         "ld_rowsum_combine_kernel", "sweep_decide_kernel", "tile_sums_kernel",
         "ld_rowsum_kernel", "ld_colsum_kernel", 'snp_pass_kernel', 'delta_kernel', 'reduce_cols_kernel',
         'finalize_kernel', 'mean_diff', 'gather_x_kernel', 'scatter_y_kernel', 'mstep_kernel',
@@ -64,11 +64,18 @@ def main():
         # the dominant kernel's launches split by size: the big launches are the full LD product
         # (launches of a stage queued ahead of a line-search decision that then went the other way
         # exit at once: a few microseconds each; they are not products)
-        ld = df[df.k == 'ld_sym_kernel']
-        if len(ld):
-            big = ld[ld.us > 0.5 * ld.us.max()]
-            out['ld_sym_kernel_full_product'] = {'calls': int(len(big)), 'avg_us': float(big.us.mean()),
-                                                 'skipped_launches': int(len(ld) - len(big))}
+        for kname in ('ld_tile_kernel', 'ld_sym_kernel'):
+            ld = df[df.k == kname]
+            if len(ld):
+                big = ld[ld.us > 0.5 * ld.us.max()]
+                out[kname + '_full_product'] = {'calls': int(len(big)), 'avg_us': float(big.us.mean()),
+                                                'skipped_launches': int(len(ld) - len(big))}
+                for nr in (1, 2):       # by right-hand sides per pass
+                    sub = ld[ld.Kernel_Name.str.contains('%s<%d>' % (kname, nr), regex=False)]
+                    sub = sub[sub.us > 0.5 * ld.us.max()]
+                    if len(sub):
+                        out['%s<%d>_full_product' % (kname, nr)] = {'calls': int(len(sub)),
+                                                                    'avg_us': float(sub.us.mean())}
         # an eigen-form product = one launch per block-height class (template argument R): the
         # product's kernel time is the sum over the classes of the mean full launch
         eig = per_class(df[df.k == 'ld_eig_fused_kernel'], 'us')

@@ -356,6 +356,54 @@ def test_ld_matvec_block_sizes(sizes):
     eng.close()
 
 
+@pytest.mark.parametrize('tile', ['0', '512,1', '512,2', '512,4', '256,2', '128,1', 'auto'])
+def test_ld_tile_shapes_and_two_right_hand_sides(tile, monkeypatch):
+    """The tiled symmetric product (ld_tile_kernel) in every strip shape, the decomposition of round 4
+    (VILMA_LD_TILE=0) and the automatic choice: against numpy, and two right-hand sides in one pass
+    (vilma_ld_matvec2) bit-identical to two passes -- launch after launch (round 5: a partial-sum
+    store of the first right-hand side had its data registers overwritten by the second one's
+    arithmetic, a few entries per launch, in shapes with rows below the diagonal tile)."""
+    from vilma_amd.engine import HipEngine
+    if tile == 'auto':
+        monkeypatch.delenv('VILMA_LD_TILE', raising=False)
+    else:
+        monkeypatch.setenv('VILMA_LD_TILE', tile)
+    rng = np.random.default_rng(11)
+    sizes = [200] * 60 + [700, 300, 1025, 64, 513, 129, 2431, 512, 1, 127]
+    n_ld = sum(sizes)
+    N = n_ld + 5
+    perm = rng.permutation(N).astype(np.int64)
+    mats = []
+    for n in sizes:
+        A = rng.normal(size=(n, n)) / np.sqrt(n)
+        mats.append(A @ A.T + np.eye(n))
+    eng = HipEngine(1, N, 3, 1)
+    eng.load_ld(0, [('dense', R) for R in mats], perm, n_ld)
+    rows, slabs, items = eng.ld_tile()
+    if tile == 'auto':
+        assert (rows, slabs) == (512, 1)            # 70 blocks: far fewer items than workgroup slots
+    elif tile == '0':
+        assert (rows, slabs) == (0, 0)
+    else:
+        assert (rows, slabs) == tuple(int(v) for v in tile.split(','))
+    assert items >= len(sizes)
+    for rep in range(6):
+        xa, xb = rng.normal(size=(1, N)), rng.normal(size=(1, N))
+        ya, yb = eng.ld_matvec(xa), eng.ld_matvec(xb)
+        want = np.zeros((2, N))
+        lo = 0
+        for n, R in zip(sizes, mats):
+            idx = perm[lo:lo + n]
+            want[0, idx] = R @ xa[0, idx]
+            want[1, idx] = R @ xb[0, idx]
+            lo += n
+        _close(ya[0], want[0], rtol=1e-11, atol=1e-11)
+        _close(yb[0], want[1], rtol=1e-11, atol=1e-11)
+        y2a, y2b = eng.ld_matvec2(xa, xb)
+        assert np.array_equal(y2a, ya) and np.array_equal(y2b, yb)
+    eng.close()
+
+
 def test_device_mstep_matches_host_formula():
     """vilma_mstep == the M-step of _update_hyper_delta (variational_inference.py:832-848)."""
     from oracle import numerics as nm

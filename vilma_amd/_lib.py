@@ -88,6 +88,7 @@ def load():
         'vilma_ld_add_lowrank': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
         'vilma_ld_end': (C.c_int, [vp, C.c_int]),
         'vilma_ld_matvec': (C.c_int, [vp, vp, C.c_int, vp, vp]),
+        'vilma_ld_matvec2': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
         'vilma_ld_bytes': (C.c_int, [vp, _c_i64_p, _c_i64_p]),
         'vilma_set_mu': (C.c_int, [vp, vp]),
         'vilma_get_mu': (C.c_int, [vp, vp]),
@@ -132,6 +133,7 @@ def load():
         'vilma_debug_result_slot': (C.c_int, [vp, C.c_int, vp, C.c_int]),
         'vilma_prof_stream_pattern': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
         'vilma_prof_ld_order': (C.c_int, [vp, C.c_int]),
+        'vilma_prof_ld_tile': (C.c_int, [vp, vp, vp, vp]),
         'vilma_prof_ld_trace': (C.c_int, [vp, vp, C.c_int64]),
         # include/vilma_numerics.h -- the Function API (vilma_amd/numerics.py)
         'vilma_num_last_error': (C.c_char_p, []),

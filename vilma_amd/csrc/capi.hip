@@ -9,7 +9,7 @@ namespace vilma_detail { std::string g_create_error; }
 namespace {
 
 void free_items(ItemSet &it) {
-    dev_free(it.sym); dev_free(it.comb); dev_free(it.a); dev_free(it.row); dev_free(it.rcomb);
+    dev_free(it.sym); dev_free(it.comb); dev_free(it.tile); dev_free(it.tcomb); dev_free(it.a); dev_free(it.row); dev_free(it.rcomb);
     for (int k = 0; k < 5; ++k) dev_free(it.eig[k]);
     dev_free(it.eig_all);
     dev_free(it.fcomb);
@@ -30,6 +30,8 @@ void free_ready(vilma_ctx *c) {
 struct HostItems {
     std::vector<SymItem> sym;
     std::vector<SymCombItem> comb;
+    std::vector<SymTile> tile;
+    std::vector<TileCombItem> tcomb;
     std::vector<LdItem> a;
     std::vector<RowItem> row;
     std::vector<RowCombItem> rcomb;
@@ -44,7 +46,44 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
     const int32_t PN = (int32_t)(c->P * c->N), pN = (int32_t)(p * c->N);
     int32_t s_off = s_base;
     for (const BlockRec &b : co.blocks) {
-        if (b.form == 0) {
+        if (b.form == 0 && c->tile_rows > 0) {
+            // tiled product: row strip I x column strip K (lower triangle of the strip grid)
+            const int TR = c->tile_rows, TS = c->tile_slabs, CW = 128 * TS, q = TR / CW;
+            const int G = (b.n + TR - 1) / TR, ns = n_slabs(b.n), sn = pad2(b.n);
+            if (b.n <= CW) {             // (CW <= TR) one item takes the block: y written directly
+                SymTile it;
+                it.a = co.store + b.off_a; it.n = b.n; it.x_off = pN + b.start;
+                it.R0 = 0; it.R1 = b.n; it.J0 = 0; it.nJ = ns; it.out0 = 0;
+                it.row_off = PN + pN + b.start; it.col_off = -1; it.direct = 1 + slot++;
+                H.tile.push_back(it);
+                continue;
+            }
+            for (int I = 0; I < G; ++I) {
+                const int R0 = I * TR, R1 = std::min(b.n, R0 + TR);
+                for (int K = 0; K * CW < R1; ++K) {
+                    const int c0 = K * CW;
+                    const bool diag = c0 >= R0;
+                    SymTile it;
+                    it.a = co.store + b.off_a; it.n = b.n; it.x_off = pN + b.start;
+                    it.R0 = R0; it.R1 = R1; it.J0 = K * TS;
+                    // slabs that begin below the item's last row have nothing in it
+                    it.nJ = std::min(std::min(TS, ns - it.J0), (R1 - c0 + 127) / 128);
+                    it.out0 = std::max(R0, c0);
+                    it.row_off = s_off + K * sn + it.out0;
+                    it.col_off = diag ? -1 : s_off + (K + I - K / q) * sn + c0;
+                    it.direct = 0;
+                    H.tile.push_back(it);
+                }
+            }
+            for (int j0 = 0; j0 < b.n; j0 += 256) {
+                TileCombItem cb;
+                cb.n = b.n; cb.s_base = s_off; cb.y_off = PN + pN + b.start;
+                cb.dot_off = pN + b.start; cb.dot_slot = slot++; cb.j0 = j0;
+                cb.cw = CW; cb.tr = TR; cb.G = G;
+                H.tcomb.push_back(cb);
+            }
+            s_off += tile_scratch_elems(b.n, TR, CW);
+        } else if (b.form == 0) {
             int64_t off = b.off_a;
             const int ns = n_slabs(b.n);
             const int CH = c->chunk_rows;
@@ -149,6 +188,17 @@ void sort_items(HostItems &H, int order) {
             return (int64_t)x.rows * x.w > (int64_t)y.rows * y.w;
         });
     }
+    // (tiled product: elements an item streams, longest first)
+    auto tile_elems = [](const SymTile &t) {
+        int64_t e = 0;
+        for (int J = t.J0; J < t.J0 + t.nJ; ++J)
+            e += (int64_t)(t.R1 - std::max(t.R0, 128 * J)) * pad_ld(slab_width(t.n, J));
+        return e;
+    };
+    if (order == 0)
+        std::stable_sort(H.tile.begin(), H.tile.end(), [&](const SymTile &x, const SymTile &y) {
+            return tile_elems(x) > tile_elems(y);
+        });
     if (order == 0) {
         std::stable_sort(H.sym.begin(), H.sym.end(), [](const SymItem &x, const SymItem &y) {
             return (int64_t)x.rows * x.ld > (int64_t)y.rows * y.ld;
@@ -193,9 +243,43 @@ int upload_items(vilma_ctx *c, HostItems &H, ItemSet &out) {
     });
     if (upload_vec(c, eig_all, &out.eig_all, &out.n_eig_all)) return 1;
     if (upload_vec(c, H.fcomb, &out.fcomb, &out.n_fcomb)) return 1;
+    if (upload_vec(c, H.tile, &out.tile, &out.n_tile) || upload_vec(c, H.tcomb, &out.tcomb, &out.n_tcomb))
+        return 1;
     return upload_vec(c, H.sym, &out.sym, &out.n_sym) || upload_vec(c, H.comb, &out.comb, &out.n_comb) ||
            upload_vec(c, H.a, &out.a, &out.n_a) || upload_vec(c, H.row, &out.row, &out.n_row) ||
            upload_vec(c, H.rcomb, &out.rcomb, &out.n_rcomb);
+}
+
+// scratch entries one dense block needs per right-hand side
+int64_t dense_scratch_elems(const vilma_ctx *c, int n) {
+    if (c->tile_rows <= 0) return sym_scratch_elems(n, c->chunk_rows);
+    const int cw = 128 * c->tile_slabs;
+    return n <= cw ? 0 : tile_scratch_elems(n, c->tile_rows, cw);
+}
+
+// Width of the tiled product's column strips for THIS shard.  The wider an item, the fewer
+// workgroups store partial sums (what holds the kernel under the bare read of the store,
+// profiles/r05i_ld_tiles.txt) -- but a launch wants a few items per workgroup slot to balance, and a
+// shard with fewer items than slots runs for as long as its longest item streams.  Measured on one
+// box (full C3 / its 2-, 4-, 8-way shards / C2): 4 slabs win from about 2 items per slot, 2 slabs
+// between, 1 slab (the decomposition of ld_sym_kernel, merged stores) on the small ones.
+void choose_tile(vilma_ctx *c) {
+    if (!c->tile_auto || c->tile_rows <= 0) return;
+    const int64_t slots = 4 * (int64_t)c->n_cu;            // four workgroups of four waves per CU
+    for (int ts : {4, 2}) {
+        const int tr = 512, cw = 128 * ts;
+        int64_t items = 0;
+        for (const CohortLd &co : c->ld)
+            for (const BlockRec &b : co.blocks) {
+                if (b.form != 0) continue;
+                if (b.n <= cw) { ++items; continue; }
+                for (int R0 = 0; R0 < b.n; R0 += tr)
+                    items += (std::min(b.n, R0 + tr) + cw - 1) / cw;   // column strips left of the strip's end
+            }
+        if (items >= 2 * slots) { c->tile_rows = tr; c->tile_slabs = ts; return; }
+    }
+    c->tile_rows = 512;
+    c->tile_slabs = 1;
 }
 
 // the device-resident work lists of every cohort's product (and of all cohorts together)
@@ -230,6 +314,12 @@ int ensure_ready(vilma_ctx *c) {
     dev_free(c->repack_tmp);             // load-time staging of the eigen-form repack: done with
     c->repack_tmp = nullptr;
     c->repack_elems = 0;
+    choose_tile(c);
+    for (CohortLd &co : c->ld) {
+        co.s_used = co.s_eig_used;
+        for (const BlockRec &b : co.blocks)
+            if (b.form == 0) co.s_used += dense_scratch_elems(c, b.n);
+    }
     // work items carry 32-bit offsets into the vector pool and the scratch: check the totals
     // BEFORE any offset is formed
     {
@@ -318,6 +408,12 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
         launch_ld_sym(it.sym, it.n_sym, pl, pl2, c->sym_scratch, c->s_stride, s);
         prof_end(c, s, e0, pl2 ? VILMA_PROF_LD_SYM2 : VILMA_PROF_LD_SYM);
     }
+    if (it.n_tile > 0) {
+        prof_begin(c, s, e0);
+        launch_ld_tile(it.tile, it.n_tile, c->tile_slabs, pl, pl2, c->sym_scratch, c->s_stride,
+                       c->dot_partials, c->dot_stride, s);
+        prof_end(c, s, e0, pl2 ? VILMA_PROF_LD_SYM2 : VILMA_PROF_LD_SYM);
+    }
     // eigen-form blocks, group by group (one group unless VILMA_EIGEN_GROUP_MB says otherwise):
     // both passes over the group's U back to back; one bracket around all = one product
     if (!it.groups.empty() || it.n_fcomb > 0) {
@@ -345,6 +441,9 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
         }
         prof_end(c, s, e0, VILMA_PROF_LD_EIG);
     }
+    if (it.n_tcomb > 0)
+        launch_ld_tile_combine(it.tcomb, it.n_tcomb, pl, pl2, c->sym_scratch, c->s_stride,
+                               c->dot_partials, c->dot_stride, s);
     if (it.n_comb > 0)      // not bracketed: tiny, and every event pair costs host time
         launch_ld_sym_combine(it.comb, it.n_comb, pl, pl2, c->sym_scratch, c->s_stride,
                               c->dot_partials, c->dot_stride, s);
@@ -655,6 +754,11 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     vilma_ctx *c = new vilma_ctx();
     c->P = P; c->N = N; c->M = M; c->A = A;
     (void)hipGetDevice(&c->device);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0)
+            c->n_cu = cus;
+    }
     c->ld.resize(P);
     for (int p = 0; p < VILMA_MAX_P; ++p) c->tau[p] = 1.0;
     const int64_t PN = (int64_t)P * N;
@@ -708,6 +812,16 @@ int vilma_create(int P, int64_t N, int M, int A, vilma_ctx **out) {
     if (const char *cr = std::getenv("VILMA_LD_CHUNK_ROWS")) {
         const int v = std::atoi(cr);
         if (v >= 128) c->chunk_rows = std::min((v + 31) / 32 * 32, 512);    // LD_MAX_CHUNK_ROWS (kernels.hip)
+    }
+    if (const char *lt = std::getenv("VILMA_LD_TILE")) {
+        int tr = 0, ts = 1;
+        if (std::sscanf(lt, "%d,%d", &tr, &ts) >= 1) {
+            ts = std::max(1, std::min(ts, 4));                  // LD_TILE_MAX_SLABS
+            tr = std::min(tr, 512) / (128 * ts) * (128 * ts);   // LD_TILE_MAX_ROWS; whole column strips
+            c->tile_rows = tr;
+            c->tile_slabs = ts;
+            c->tile_auto = false;
+        }
     }
     // VILMA_OVERLAP=0 keeps everything on the caller's stream (A/B measurements)
     if (const char *po = std::getenv("VILMA_DEBUG_POISON")) c->poison = po[0] != '0' && po[0] != 0;
@@ -880,7 +994,6 @@ int vilma_ld_add_dense(vilma_ctx *c, int cohort, int n, const double *R) {
     co.store_used += need;
     co.next_start += n;
     co.alg_bytes += (int64_t)8 * n * n;
-    co.s_used += sym_scratch_elems(n, c->chunk_rows);
     return 0;
 }
 
@@ -924,7 +1037,7 @@ int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U
     co.next_start += n;
     co.t_used += pad_ld(r);
     // partial row sums S[slab][n]
-    co.s_used += (int64_t)(W > 0 ? eig_n_slabs(n, r, W) : (r + 127) / 128) * pad2(n);
+    co.s_eig_used += (int64_t)(W > 0 ? eig_n_slabs(n, r, W) : (r + 127) / 128) * pad2(n);
     co.alg_bytes += (int64_t)8 * n * r;
     return 0;
 }
@@ -959,6 +1072,23 @@ int vilma_ld_matvec(vilma_ctx *c, void *stream, int cohort, const double *x, dou
     launch_gather_x(x, c->invperm, pl, (int)c->N, c->P, s);
     run_ld(c, s, pl, nullptr, cohort);
     launch_scatter_y(pl + (int64_t)c->P * c->N, c->invperm, y, (int)c->N, c->P, s);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int vilma_ld_matvec2(vilma_ctx *c, void *stream, int cohort, const double *x0, const double *x1,
+                     double *y0, double *y1) {
+    if (!c) return 1;
+    if (vilma_sweep_drain(c)) return 1;
+    if (cohort >= c->P) return fail(c, "cohort out of range");
+    if (ensure_ready(c)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    double *pa = c->pool[c->mom_ta], *pb = c->pool[c->mom_tb];   // the trial pools double as workspace
+    launch_gather_x(x0, c->invperm, pa, (int)c->N, c->P, s);
+    launch_gather_x(x1, c->invperm, pb, (int)c->N, c->P, s);
+    run_ld(c, s, pa, pb, cohort);
+    launch_scatter_y(pa + (int64_t)c->P * c->N, c->invperm, y0, (int)c->N, c->P, s);
+    launch_scatter_y(pb + (int64_t)c->P * c->N, c->invperm, y1, (int)c->N, c->P, s);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1365,6 +1495,15 @@ int vilma_prof_stream_pattern(vilma_ctx *c, void *stream, int passes, int chunk_
     (void)hipEventDestroy(e1);
     if (ms_per_pass) *ms_per_pass = total / passes;
     if (bytes_per_pass) *bytes_per_pass = bytes;
+    return 0;
+}
+
+int vilma_prof_ld_tile(vilma_ctx *c, int *tile_rows, int *tile_slabs, int *n_items) {
+    if (!c) return 1;
+    if (ensure_ready(c)) return 1;
+    if (tile_rows) *tile_rows = c->tile_rows;
+    if (tile_slabs) *tile_slabs = c->tile_rows > 0 ? c->tile_slabs : 0;
+    if (n_items) *n_items = c->tile_rows > 0 ? c->all.n_tile : c->all.n_sym;
     return 0;
 }
 

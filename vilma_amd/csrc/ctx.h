@@ -37,7 +37,8 @@ struct CohortLd {
     int64_t t_used = 0;
     std::vector<BlockRec> blocks;
     int64_t alg_bytes = 0;
-    int64_t s_used = 0;                            // scratch entries of the symmetric product
+    int64_t s_used = 0;                            // scratch entries of the LD product (set by ensure_ready)
+    int64_t s_eig_used = 0;                        // ... of which for the eigen-form blocks (known at add time)
 };
 
 // device-resident work lists of one LD product (all cohorts, or one cohort)
@@ -48,6 +49,9 @@ struct EigenGroup { int a0, na, r0, nr, c0, nc; };
 struct ItemSet {
     SymItem *sym = nullptr;
     SymCombItem *comb = nullptr;
+    SymTile *tile = nullptr;         // tiled symmetric product (vilma_ctx::tile_rows > 0)
+    TileCombItem *tcomb = nullptr;
+    int n_tile = 0, n_tcomb = 0;
     LdItem *a = nullptr;
     RowItem *row = nullptr;
     RowCombItem *rcomb = nullptr;
@@ -109,6 +113,15 @@ inline int n_slabs(int n) { return (n + 127) / 128; }
 inline int32_t sym_scratch_elems(int n, int chunk_rows) {
     return n_slabs(n) * (pad2(n) + ((n + chunk_rows - 1) / chunk_rows) * 128);
 }
+// scratch of the TILED symmetric product for one block (kernels.hip, ld_tile_kernel): S[slot][pad2(n)],
+// entry j uses slots 0 .. j / cw + G - j / tr - 1 (cw = 128 tile_slabs, G = ceil(n / tr))
+inline int tile_slots(int n, int tr, int cw) {
+    const int G = (n + tr - 1) / tr;
+    int most = 0;
+    for (int j = 0; j < n; j += 128) most = std::max(most, j / cw + G - j / tr);
+    return most;
+}
+inline int32_t tile_scratch_elems(int n, int tr, int cw) { return tile_slots(n, tr, cw) * pad2(n); }
 
 }  // namespace vilma_detail
 using namespace vilma_detail;
@@ -172,6 +185,12 @@ struct vilma_ctx {
     bool ready = false;
     // rows per work item of the symmetric product (multiple of 32); VILMA_LD_CHUNK_ROWS overrides
     int chunk_rows = 512;
+    // tiled symmetric product: row strips of tile_rows rows (a multiple of 128 tile_slabs, at most 512),
+    // column strips of tile_slabs slabs (at most 4); tile_rows = 0: one workgroup per slab chunk
+    // (ld_sym_kernel).  VILMA_LD_TILE=rows,slabs overrides.
+    int tile_rows = 512, tile_slabs = 4;
+    bool tile_auto = true;          // pick tile_slabs from the shard's size when the work lists are built
+    int n_cu = 256;                 // compute units of the device
     // order of the symmetric product's work items (capi.hip: sort_items); VILMA_LD_ORDER /
     // vilma_prof_ld_order override
     int ld_order = 0;

@@ -88,6 +88,31 @@ struct SymCombItem {
     int32_t chunk_rows;
 };
 
+// One work item of the TILED symmetric product (ld_tile_kernel): rows [R0, R1) of the slabs
+// J0 .. J0 + nJ - 1 of one block.  Row strips are `tile_rows` high, column strips `tile_slabs` slabs
+// wide (tile_rows a multiple of the strip width); an item whose columns lie among its rows
+// ("diagonal": col_off < 0) starts every slab at that slab's diagonal tile.
+struct SymTile {
+    const double *a;     // the block's store (panel 0, row 0), 128-byte aligned
+    int32_t n;           // block size
+    int32_t x_off;       // pool offset of x[0] of the block
+    int32_t R0, R1;      // rows of the block this item takes
+    int32_t J0, nJ;      // its slabs
+    int32_t out0;        // first row it has a row sum for: max(R0, 128 J0)
+    int32_t row_off;     // scratch offset of that row's partial (slot J0 / tile_slabs)
+    int32_t col_off;     // scratch offset of column 128 J0's partial, or -1: merged into the rows' run
+    int32_t direct;      // > 0: the item is the whole block -- row_off is the POOL offset of y[0] and
+                         // direct - 1 the slot of the block's y.z partial; nothing goes to scratch
+};
+// combine step of the tiled product: y[j] = sum of slots 0 .. j / cw + G - j / tr - 1 of S[slot][pad2(n)]
+struct TileCombItem {
+    int32_t n;
+    int32_t s_base;
+    int32_t y_off, dot_off, dot_slot;
+    int32_t j0;               // first of the (up to) 256 entries this workgroup combines
+    int32_t cw, tr, G;        // column-strip width, row-strip height, number of row strips
+};
+
 struct TauArg { double v[VILMA_MAX_P]; };
 
 // ---- device-resident sweep (sweep.hip): what changes from sweep to sweep lives on the device ----
@@ -297,6 +322,12 @@ void launch_ld_sym(const SymItem *items, int n_items, const double *pool0, const
 // buf = {s_memrealtime at start, at end (100 MHz ticks), XCC id, bytes of the chunk, core-clock
 // cycles (s_memtime) between start and end}
 int set_ld_trace(double *buf_dev, int64_t capacity_rows);
+void launch_ld_tile(const SymTile *items, int n_items, int max_slabs, double *pool0, double *pool1,
+                    double *scratch, int64_t s_stride, double *dot_partials, int dot_stride,
+                    hipStream_t s);
+void launch_ld_tile_combine(const TileCombItem *items, int n_items, double *pool0, double *pool1,
+                            const double *scratch, int64_t s_stride, double *dot_partials,
+                            int dot_stride, hipStream_t s);
 void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0, double *pool1,
                            const double *scratch, int64_t s_stride, double *dot_partials,
                            int dot_stride, hipStream_t s);

@@ -104,7 +104,12 @@ typedef const v2d __attribute__((address_space(1))) *gd2_ptr;
 typedef int ld_v4i __attribute__((ext_vector_type(4)));
 static __device__ __forceinline__ void ld_store2_wt(double *p, double a, double b) {
     const ld_v4i v = {__double2loint(a), __double2hiint(a), __double2loint(b), __double2hiint(b)};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // A store of more than 8 bytes reads its data registers late: a vector-ALU write to them within two
+    // wait states of the store reaches memory instead of the value stored (the compiler pads its own
+    // stores; it cannot see into this one and is free to reuse the registers at once -- seen in round 5:
+    // the first right-hand side's partial sums overwritten by the second one's arithmetic, a few
+    // entries per launch).  The s_nop keeps the slots empty.
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 #if LD_STORE_MODE == 1
 #define LD_PARTIAL_STORE(p, v) do { if ((v) == 1.2345e300) *(p) = (v); } while (0)
@@ -896,6 +901,295 @@ void launch_ld_sym_combine(const SymCombItem *items, int n_items, double *pool0,
     pp.p[0] = pool0;
     pp.p[1] = pool1 ? pool1 : pool0;
     hipLaunchKernelGGL(ld_sym_combine_kernel, dim3(n_items, pool1 ? 2 : 1), dim3(256), 0, s, items,
+                       pp, scratch, s_stride, dot_partials, dot_stride, g_pred, g_phase);
+}
+
+// --------------------------------------------------------------------------------------------
+// Tiled symmetric product (round 5): ONE workgroup takes the rows [R0, R1) of up to LD_TILE_MAX_SLABS
+// neighbouring 128-column slabs of a block -- what ld_sym_kernel gives to as many workgroups -- and
+// stores its partial sums once, merged:
+//   * a row of the block is handled by the same lane of the same wave in every slab (panel rows
+//     start a multiple of 128 below each other and groups of 8 rows go round the 4 waves), so the
+//     row sums of the slabs are ADDED in LDS without any synchronisation, in slab order;
+//   * each wave keeps a slab's column sums in registers and parks them in LDS when the slab ends;
+//     no barrier between slabs, one at the end;
+//   * an item on the diagonal (its columns are among its rows) writes rows and columns as ONE run
+//     y_part[j] = row sum (strictly lower part) + column sum: the two belong to the same entries.
+// What leaves per item: (rows + columns) doubles instead of (slabs x rows + slabs x 128 per chunk).
+// Scratch: S[slot][pad2(n)] per block; entry j (column strip k = j / CW, row strip g = j / TR, G row
+// strips) receives its row partials of strips 0 .. k in slots 0 .. k and its column partials of the
+// row strips g + 1 .. G - 1 in slots k + 1 .. k + G - 1 - g; ld_tile_combine_kernel adds slots
+// 0 .. k + G - g - 1 in order.  Fixed order throughout: results do not depend on scheduling.
+// --------------------------------------------------------------------------------------------
+#define LD_TILE_MAX_SLABS 4
+#define LD_TILE_MAX_ROWS 512
+
+template <bool FULL>
+static __device__ __forceinline__ void tile_group(const v2d (&v)[CS_ROWS], const double *__restrict__ xrow,
+                                                  int r0, int rows, double xs0, double xs1,
+                                                  double &acc0, double &acc1, int lane,
+                                                  double *__restrict__ srow, bool first) {
+    double p[CS_ROWS];
+#pragma unroll
+    for (int u = 0; u < CS_ROWS; ++u) {
+        const double xv = xrow[FULL ? r0 + u : min(r0 + u, rows - 1)];
+        const double xz = (FULL || r0 + u < rows) ? xv : 0.0;
+        acc0 = fma(v[u].x, xz, acc0);
+        acc1 = fma(v[u].y, xz, acc1);
+        p[u] = fma(v[u].x, xs0, v[u].y * xs1);
+    }
+    int rsub;
+    const double t1 = sym_rowsum8(p, lane, rsub);
+    const int rr = r0 + rsub;
+    if ((lane & 7) == 0 && (FULL || rr < rows)) srow[rr] = first ? t1 : srow[rr] + t1;
+}
+static __device__ __forceinline__ void tile_group_diag(const v2d (&v)[CS_ROWS],
+                                                       const double *__restrict__ xrow, int r0,
+                                                       int rows, int cl, double xs0, double xs1,
+                                                       double &acc0, double &acc1, int lane,
+                                                       double *__restrict__ srow, bool first) {
+    double p[CS_ROWS];
+#pragma unroll
+    for (int u = 0; u < CS_ROWS; ++u) {
+        const int r = r0 + u;
+        const double xv = xrow[min(r, rows - 1)];
+        const double xz = r < rows ? xv : 0.0;
+        const double a0 = cl <= r ? v[u].x : 0.0, a1 = cl + 1 <= r ? v[u].y : 0.0;   // c <= r
+        acc0 = fma(a0, xz, acc0);
+        acc1 = fma(a1, xz, acc1);
+        const double b0 = cl < r ? v[u].x : 0.0, b1 = cl + 1 < r ? v[u].y : 0.0;     // c <  r
+        p[u] = fma(b0, xs0, b1 * xs1);
+    }
+    int rsub;
+    const double t1 = sym_rowsum8(p, lane, rsub);
+    const int rr = r0 + rsub;
+    if ((lane & 7) == 0 && rr < rows) srow[rr] = first ? t1 : srow[rr] + t1;
+}
+
+// element offset of panel J inside a block's store: panels 0 .. J-1 are full slabs (ld = 128)
+static __device__ __forceinline__ int64_t sym_panel_off(int n, int J) {
+    return 128 * ((int64_t)J * n - 64 * (int64_t)J * (J - 1));
+}
+
+template <int NR>
+__global__ __launch_bounds__(CS_WAVES * 64) void ld_tile_kernel(
+    const SymTile *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
+    int64_t s_stride, PoolPairRW ypools_arg, double *__restrict__ dot_partials, int dot_stride,
+    int max_slabs, const int *pred, const PhasePtrs *pp) {
+    // rs[NR][LD_TILE_MAX_ROWS] then red[NR][max_slabs][CS_WAVES][128]
+    extern __shared__ double tile_lds[];
+    PRED_EXIT(pred);
+    PoolPair pools = pools_arg;
+    if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
+    const SymTile it = items[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cl = 2 * lane;
+    const int n = it.n;
+    const bool diag = it.col_off < 0;                 // the item's columns are among its rows
+    double *const red = tile_lds + NR * LD_TILE_MAX_ROWS;
+    const double *xblk[NR];
+    double xs0n[NR], xs1n[NR], acc0[NR], acc1[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        xblk[r] = pools.p[r] + it.x_off;
+        // x of this lane's two columns in the first slab (lanes past the block's end read its last entry)
+        const int c = 128 * it.J0 + cl;
+        xs0n[r] = xblk[r][min(c, n - 1)];
+        xs1n[r] = xblk[r][min(c + 1, n - 1)];
+    }
+    for (int Jl = 0; Jl < it.nJ; ++Jl) {
+        const int J = it.J0 + Jl, j0 = 128 * J;
+        const int wJ = min(128, n - j0);
+        const int64_t ld = (wJ + 15) & ~15;
+        const bool active = cl < wJ;
+        const bool first = Jl == 0;
+        const int rstart = diag ? j0 : it.R0;         // block row of the first panel row taken
+        const int rows = it.R1 - rstart;
+        double xs0[NR], xs1[NR];
+        const double *xrow[NR];
+        double *srow[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            xs0[r] = active ? xs0n[r] : 0.0;
+            xs1[r] = (cl + 1 < wJ) ? xs1n[r] : 0.0;
+            // the next slab's x, a slab ahead of its use
+            const int c = j0 + 128 + cl;
+            xs0n[r] = xblk[r][min(c, n - 1)];
+            xs1n[r] = xblk[r][min(c + 1, n - 1)];
+            xrow[r] = xblk[r] + rstart;
+            srow[r] = tile_lds + r * LD_TILE_MAX_ROWS + (rstart - it.out0);
+            acc0[r] = 0.0;
+            acc1[r] = 0.0;
+        }
+        const double *ap = it.a + sym_panel_off(n, J) + (int64_t)(rstart - j0) * ld + (active ? cl : 0);
+        const int ngroups = (rows + CS_ROWS - 1) / CS_ROWS;     // group g belongs to wave g % 4
+        const int ndiag = diag ? (wJ + CS_ROWS - 1) / CS_ROWS : 0;   // groups inside the diagonal tile
+        const int nfull = rows / CS_ROWS;
+        const int64_t gstride = (int64_t)CS_WAVES * CS_ROWS * ld;
+        const double *rp = ap + (int64_t)w * CS_ROWS * ld;
+        int g = w;
+        v2d v[CS_ROWS];
+        for (; g < ndiag && g < ngroups; g += CS_WAVES, rp += gstride) {
+            sym_load_diag(v, rp, ld, g * CS_ROWS, rows, lane);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                tile_group_diag(v, xrow[r], g * CS_ROWS, rows, active ? cl : 2 * 64, xs0[r], xs1[r],
+                                acc0[r], acc1[r], lane, srow[r], first);
+        }
+        for (; g < nfull; g += CS_WAVES, rp += gstride) {
+#pragma unroll
+            for (int u = 0; u < CS_ROWS; ++u) v[u] = LD_STREAM_LOAD(rp + (int64_t)u * ld);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                tile_group<true>(v, xrow[r], g * CS_ROWS, rows, xs0[r], xs1[r], acc0[r], acc1[r],
+                                 lane, srow[r], first);
+        }
+        if (g == nfull && g < ngroups) {                        // the one partial group, below the tile
+            const int r0 = nfull * CS_ROWS;
+#pragma unroll
+            for (int u = 0; u < CS_ROWS; ++u)     // rows past the end re-read the last row
+                v[u] = LD_STREAM_LOAD(ap + (int64_t)min(r0 + u, rows - 1) * ld);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                tile_group<false>(v, xrow[r], r0, rows, xs0[r], xs1[r], acc0[r], acc1[r], lane,
+                                  srow[r], first);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double *rd = red + (((int64_t)r * max_slabs + Jl) * CS_WAVES + w) * 128;
+            *(v2d *)(rd + cl) = v2d{acc0[r], acc1[r]};
+        }
+    }
+    __syncthreads();
+    // one store phase: two entries per thread and pass
+    const int ncols = min(128 * it.nJ, n - 128 * it.J0);
+    const int nrows = it.R1 - it.out0;
+    const int t = 2 * (int)threadIdx.x;
+    double ydot[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double *rs = tile_lds + r * LD_TILE_MAX_ROWS;
+        const double *rd = red + (int64_t)r * max_slabs * CS_WAVES * 128;
+        double c0 = 0.0, c1 = 0.0;
+        if (t < ncols) {
+            const double *q = rd + (int64_t)(t >> 7) * CS_WAVES * 128 + (t & 127);
+            c0 = q[0]; c1 = q[1];
+#pragma unroll
+            for (int ww = 1; ww < CS_WAVES; ++ww) { c0 += q[ww * 128]; c1 += q[ww * 128 + 1]; }
+        }
+        ydot[r] = 0.0;
+        if (it.direct) {
+            // the item is the whole block: these ARE y's entries (row_off is y's pool offset), and
+            // the block's share of y.z is formed here -- no scratch, no combine item
+            double *yp = (pp != nullptr ? (r == 0 ? PHASE(pp)->pool_out : PHASE(pp)->pool_out2)
+                                        : (r == 0 ? ypools_arg.p[0] : ypools_arg.p[1])) + it.row_off;
+            if (t < nrows) {
+                const double y0 = rs[t] + c0;
+                yp[t] = y0;
+                ydot[r] = y0 * xblk[r][t];
+            }
+            if (t + 1 < nrows) {
+                const double y1 = rs[t + 1] + c1;
+                yp[t + 1] = y1;
+                ydot[r] = fma(y1, xblk[r][t + 1], ydot[r]);
+            }
+            continue;
+        }
+        double *dst = scratch + r * s_stride + it.row_off;
+        if (diag) {
+            if (t + 1 < nrows) LD_PARTIAL_STORE2(&dst[t], rs[t] + c0, rs[t + 1] + c1);
+            else if (t < nrows) LD_PARTIAL_STORE(&dst[t], rs[t] + c0);
+        } else {
+            if (t + 1 < nrows) LD_PARTIAL_STORE2(&dst[t], rs[t], rs[t + 1]);
+            else if (t < nrows) LD_PARTIAL_STORE(&dst[t], rs[t]);
+            double *cd = scratch + r * s_stride + it.col_off;
+            if (t + 1 < ncols) LD_PARTIAL_STORE2(&cd[t], c0, c1);
+            else if (t < ncols) LD_PARTIAL_STORE(&cd[t], c0);
+        }
+    }
+    if (it.direct) {                    // (uniform over the workgroup)
+        double *dred = red;             // the column sums have been consumed by their own threads only
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const double dv = wave_sum(ydot[r]);
+            if (lane == 0) dred[r * CS_WAVES + w] = dv;
+        }
+        __syncthreads();
+        if (threadIdx.x < NR) {
+            const double *d = dred + threadIdx.x * CS_WAVES;
+            dot_partials[(int64_t)threadIdx.x * dot_stride + it.direct - 1] = (d[0] + d[1]) + (d[2] + d[3]);
+        }
+    }
+}
+
+// y[j] = S[0][j] + ... + S[nt - 1][j], nt = j / CW + G - j / TR, for 256 entries of one block, with the
+// chunk's y.z partial.  blockIdx.y = right-hand side.
+__global__ __launch_bounds__(256) void ld_tile_combine_kernel(
+    const TileCombItem *__restrict__ items, const PoolPairRW pools_arg,
+    const double *__restrict__ scratch0, int64_t s_stride, double *__restrict__ dot_partials0,
+    int dot_stride, const int *pred, const PhasePtrs *pp) {
+    __shared__ double dred[4];
+    PRED_EXIT(pred);
+    const int rhs = blockIdx.y;
+    double *const pool_r = pp != nullptr ? (rhs == 0 ? PHASE(pp)->pool_out : PHASE(pp)->pool_out2)
+                                         : (rhs == 0 ? pools_arg.p[0] : pools_arg.p[1]);
+    const double *__restrict__ xpool = pool_r;
+    double *__restrict__ ypool = pool_r;
+    const double *__restrict__ scratch = scratch0 + rhs * s_stride;
+    double *__restrict__ dot_partials = dot_partials0 + (int64_t)rhs * dot_stride;
+    const TileCombItem it = items[blockIdx.x];
+    const int j = it.j0 + threadIdx.x;
+    const bool live = j < it.n;
+    const int jj = live ? j : it.n - 1;
+    const int sn = (it.n + 1) & ~1;
+    const int nt = jj / it.cw + it.G - jj / it.tr;
+    const double *sj = scratch + it.s_base + jj;
+    const double xj = xpool[it.dot_off + jj];
+    double s = 0.0;
+    for (int T = 0; T < nt; T += COMB_GROUP) {
+        double t[COMB_GROUP];
+#pragma unroll
+        for (int u = 0; u < COMB_GROUP; ++u) t[u] = sj[(int64_t)min(T + u, nt - 1) * sn];
+#pragma unroll
+        for (int u = 0; u < COMB_GROUP; ++u) s += (T + u < nt) ? t[u] : 0.0;
+    }
+    if (live) ypool[it.y_off + j] = s;
+    double dv = wave_sum(live ? s * xj : 0.0);
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = dv;
+    __syncthreads();
+    if (threadIdx.x == 0) dot_partials[it.dot_slot] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+}
+
+void launch_ld_tile(const SymTile *items, int n_items, int max_slabs, double *pool0, double *pool1,
+                    double *scratch, int64_t s_stride, double *dot_partials, int dot_stride,
+                    hipStream_t s) {
+    if (n_items <= 0) return;
+    PoolPair pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    PoolPairRW yp;
+    yp.p[0] = pool0;
+    yp.p[1] = pool1 ? pool1 : pool0;
+    const int nr = pool1 ? 2 : 1;
+    const size_t lds = sizeof(double) * nr * (LD_TILE_MAX_ROWS + (size_t)max_slabs * CS_WAVES * 128);
+    if (pool1)
+        hipLaunchKernelGGL(ld_tile_kernel<2>, dim3(n_items), dim3(CS_WAVES * 64), lds, s, items, pp,
+                           scratch, s_stride, yp, dot_partials, dot_stride, max_slabs, g_pred, g_phase);
+    else
+        hipLaunchKernelGGL(ld_tile_kernel<1>, dim3(n_items), dim3(CS_WAVES * 64), lds, s, items, pp,
+                           scratch, s_stride, yp, dot_partials, dot_stride, max_slabs, g_pred, g_phase);
+}
+
+void launch_ld_tile_combine(const TileCombItem *items, int n_items, double *pool0, double *pool1,
+                            const double *scratch, int64_t s_stride, double *dot_partials,
+                            int dot_stride, hipStream_t s) {
+    if (n_items <= 0) return;
+    PoolPairRW pp;
+    pp.p[0] = pool0;
+    pp.p[1] = pool1 ? pool1 : pool0;
+    hipLaunchKernelGGL(ld_tile_combine_kernel, dim3(n_items, pool1 ? 2 : 1), dim3(256), 0, s, items,
                        pp, scratch, s_stride, dot_partials, dot_stride, g_pred, g_phase);
 }
 

@@ -218,6 +218,22 @@ class HipEngine:
         self.ld_matvec_device(xd, yd, cohort)
         return yd.cpu().numpy()
 
+    def ld_tile(self):
+        """(rows per row strip, slabs per column strip, work items per launch) of the dense product."""
+        v = [C.c_int(), C.c_int(), C.c_int()]
+        self._check(self.lib.vilma_prof_ld_tile(self.ctx, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def ld_matvec2(self, xa, xb, cohort=-1):
+        """Two right-hand sides in one pass over the LD store -> (numpy [P,N], numpy [P,N])."""
+        t = self.torch
+        xs = [t.as_tensor(_f64(x).reshape(self.P, self.N), device=self.device) for x in (xa, xb)]
+        ys = [t.zeros_like(x) for x in xs]
+        self._check(self.lib.vilma_ld_matvec2(self.ctx, self._stream(), cohort,
+                                              C.c_void_p(xs[0].data_ptr()), C.c_void_p(xs[1].data_ptr()),
+                                              C.c_void_p(ys[0].data_ptr()), C.c_void_p(ys[1].data_ptr())))
+        return ys[0].cpu().numpy(), ys[1].cpu().numpy()
+
     def ld_matvec_device(self, xd, yd, cohort=-1):
         self._check(self.lib.vilma_ld_matvec(self.ctx, self._stream(), cohort,
                                              C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr())))
