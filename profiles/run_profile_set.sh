@@ -25,7 +25,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     d=/tmp/rp_$(echo $ctr | tr A-Z a-z | cut -d_ -f1)
     # counters only for the library's kernels: the synthetic setup issues ~100 k torch dispatches
     # that a counter pass would serialise one by one
-    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "ld_sym|ld_eig|ld_colsum|ld_rowsum|snp_pass|delta_kernel|finalize|sweep_decide|tile_sums" --output-format csv -d $d -- \
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "ld_tile|ld_sym|ld_eig|ld_colsum|ld_rowsum|snp_pass|delta_kernel|finalize|sweep_decide|tile_sums" --output-format csv -d $d -- \
         python3 "$ROOT/bench.py" --workload $WL --ld-form $FORM --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
     python3 "$ROOT/profiles/summarize_rocprof.py" $d "$OUT/${PFX}_$(echo $ctr | tr A-Z a-z | cut -d_ -f1)" || exit 1
     rm -rf $d
@@ -42,7 +42,7 @@ out = {'source': 'profiles/%s + %s (rocprofv3 --pmc, separate passes)' % tuple(a
        'formula': '(2*FETCH_SIZE + WRITE_SIZE)*1024 over the full-product launches',
        'workload': sys.argv[4], 'ld_form': sys.argv[5],
        'kernels_hip_sha16': hashlib.sha256(open('vilma_amd/csrc/kernels.hip', 'rb').read()).hexdigest()[:16]}
-for k in ('ld_sym_kernel', 'ld_eig_fused_kernel'):
+for k in ('ld_tile_kernel', 'ld_sym_kernel', 'ld_eig_fused_kernel'):
     if k in f and k in w:
         out[k + '_bytes_per_launch'] = (2 * f[k]['FETCH_SIZE']['mean_over_large_dispatches']
                                         + w[k]['WRITE_SIZE']['mean_over_large_dispatches']) * 1024
