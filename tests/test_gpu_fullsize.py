@@ -326,7 +326,36 @@ def _sample_against_oracle(workload, block_range, n_sweeps, form='auto', scale_s
     sh, eng, drv = _setup(workload, form=form, block_range=block_range, scale_se=scale_se)
     assert len(sh.blocks) == block_range[1] - block_range[0]
     assert len(sh.blocks) >= 0.1 * len(sh.sizes_all)
-    if sh.kind == 'lowrank':
+    if sh.kind == 'lowrank' and sh.spectrum == 'factor':
+        # The oracle decomposes the sample's DENSE blocks itself: each block's matrix is formed again
+        # on the host from its seeded stream (SURVEY 8d's recipe, numpy) and goes through the
+        # oracle's own restatement of _svd_threshold / LowRankMatrix.__init__ with host LAPACK
+        # (matrix_structures.py:15-28, 95-146).  The product's factors come from its GPU loader
+        # (rocSOLVER stacks + select_eigenpairs): the comparison below pins the decomposition and the
+        # kept ranks as well as the sweep.
+        from concurrent.futures import ThreadPoolExecutor
+        from threadpoolctl import threadpool_limits
+        from vilma_amd.synthetic import FACTOR_LD_THRESH
+
+        def host_block(ip):
+            i, p = ip
+            n = sh.blocks[i].n
+            m = -(-n // 4)
+            F = np.random.default_rng([sh.seed, 5000 + sh.b0 + i, p]).normal(size=(n, m))
+            R = F @ F.T / m
+            R[np.diag_indices(n)] += 0.05
+            d = 1.0 / np.sqrt(np.diag(R))
+            R = d[:, None] * R * d[None, :]
+            return EigenBlock(X=0.5 * (R + R.T), t=FACTOR_LD_THRESH)
+        with threadpool_limits(limits=1), ThreadPoolExecutor(max_workers=16) as pool:
+            host = list(pool.map(host_block, [(i, p) for p in range(sh.P) for i in range(len(sh.blocks))]))
+        nb = len(sh.blocks)
+        for p in range(sh.P):
+            for i in range(nb):
+                assert host[p * nb + i].s.size == sh._eig[p][i][0].shape[1], (p, i)    # kept ranks agree
+        ld = [BlockDiagonalLD(host[p * nb:(p + 1) * nb], perm=sh.perm, missing=sh.missing)
+              for p in range(sh.P)]
+    elif sh.kind == 'lowrank':
         ld = [BlockDiagonalLD([EigenBlock(u=U.cpu().numpy(), s=sv.cpu().numpy(), t=1.0)
                                for U, sv in sh._eig[p]], perm=sh.perm, missing=sh.missing)
               for p in range(sh.P)]

@@ -111,16 +111,23 @@ void make_items(const vilma_ctx *c, int p, const CohortLd &co, int32_t t_base, i
             s_off += sym_scratch_elems(b.n, CH);
         } else if (b.w > 0) {
             // eigen form, fused product: column-major U, one item per slab of columns
-            const int R = b.w, cols = eig_slab_cols(b.n, R);
-            const int ns = eig_n_slabs(b.n, b.r, R), ldc = pad2(b.n);
+            const int R = b.w, cols = eig_slab_cols(b.n, b.r, R);
+            const int ns = (b.r + cols - 1) / cols, ldc = pad2(b.n);
             const double *U = co.store + b.off_a, *sv = co.store + b.off_v;
+            if (ns == 1) {               // one slab: the item writes y and the block's y.z partial
+                EigItem it;
+                it.a = U; it.scale = sv; it.n = b.n; it.ncols = b.r; it.ldc = ldc;
+                it.x_off = pN + b.start; it.s_off = PN + pN + b.start; it.direct = 1 + slot++;
+                H.eig[eig_class(R)].push_back(it);
+                continue;
+            }
             for (int J = 0; J < ns; ++J) {
                 EigItem it;
                 const int c0 = J * cols;
                 it.a = U + (int64_t)c0 * ldc;
                 it.scale = sv + c0;
                 it.n = b.n; it.ncols = std::min(cols, b.r - c0); it.ldc = ldc;
-                it.x_off = pN + b.start; it.s_off = s_off + J * pad2(b.n); it.pad = 0;
+                it.x_off = pN + b.start; it.s_off = s_off + J * pad2(b.n); it.direct = 0;
                 H.eig[eig_class(R)].push_back(it);
             }
             for (int i0 = 0; i0 < b.n; i0 += 256) {
@@ -416,21 +423,24 @@ void run_ld(vilma_ctx *c, hipStream_t s, double *pl, double *pl2, int cohort) {
     }
     // eigen-form blocks, group by group (one group unless VILMA_EIGEN_GROUP_MB says otherwise):
     // both passes over the group's U back to back; one bracket around all = one product
-    if (!it.groups.empty() || it.n_fcomb > 0) {
+    if (!it.groups.empty() || it.n_fcomb > 0 || it.n_eig_all > 0 || it.n_eig[4] > 0) {
         prof_begin(c, s, e0);
         // fused product (U read once): one launch per block-height class present -- or, on a small
         // shard, all classes in one launch -- then the combine
         if (it.n_eig_all < c->eig_merge_below)
-            launch_ld_eig_fused_all(it.eig_all, it.n_eig_all, pl, pl2, c->sym_scratch, c->s_stride, s);
+            launch_ld_eig_fused_all(it.eig_all, it.n_eig_all, pl, pl2, c->sym_scratch, c->s_stride,
+                                    c->dot_partials, c->dot_stride, s);
         else
             for (int k = 0; k < 4; ++k) {
                 if (k == 0 && c->eig_wave)
-                    launch_ld_eig_wave(it.eig[0], it.n_eig[0], pl, pl2, c->sym_scratch, c->s_stride, s);
+                    launch_ld_eig_wave(it.eig[0], it.n_eig[0], pl, pl2, c->sym_scratch, c->s_stride,
+                                       c->dot_partials, c->dot_stride, s);
                 else
                     launch_ld_eig_fused(it.eig[k], it.n_eig[k], eig_class_rows(k), pl, pl2,
-                                        c->sym_scratch, c->s_stride, s);
+                                        c->sym_scratch, c->s_stride, c->dot_partials, c->dot_stride, s);
             }
-        launch_ld_eig_tall(it.eig[4], it.n_eig[4], pl, pl2, c->sym_scratch, c->s_stride, s);
+        launch_ld_eig_tall(it.eig[4], it.n_eig[4], pl, pl2, c->sym_scratch, c->s_stride,
+                           c->dot_partials, c->dot_stride, s);
         launch_ld_rowsum_combine(it.fcomb, it.n_fcomb, pl, pl2, c->sym_scratch, c->s_stride,
                                  c->dot_partials, c->dot_stride, s);
         for (const EigenGroup &g : it.groups) {
@@ -1037,7 +1047,12 @@ int vilma_ld_add_lowrank(vilma_ctx *c, int cohort, int n, int r, const double *U
     co.next_start += n;
     co.t_used += pad_ld(r);
     // partial row sums S[slab][n]
-    co.s_eig_used += (int64_t)(W > 0 ? eig_n_slabs(n, r, W) : (r + 127) / 128) * pad2(n);
+    {
+        // partial row sums S[slab][n]; a fused block of one slab needs none (make_items)
+        const int cols = W > 0 ? eig_slab_cols(n, r, W) : 128;
+        const int ns = (r + cols - 1) / cols;
+        co.s_eig_used += (W > 0 && ns == 1) ? 0 : (int64_t)ns * pad2(n);
+    }
     co.alg_bytes += (int64_t)8 * n * r;
     return 0;
 }

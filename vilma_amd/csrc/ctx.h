@@ -69,29 +69,25 @@ struct ItemSet {
 inline int eig_class(int R) { return R == 2 ? 0 : R == 4 ? 1 : R == 8 ? 2 : R == 12 ? 3 : 4; }
 inline int eig_class_rows(int k) { return k == 0 ? 2 : k == 1 ? 4 : k == 2 ? 8 : k == 3 ? 12 : 24; }
 inline int pad2(int n) { return (n + 1) & ~1; }
-// columns of U one workgroup of the fused product takes (a whole number of batches): about
-// g_eig_slab_elems elements (default 96 k = 768 KB) of U per workgroup, at most EIG_SLAB_MAX_COLS
-// columns (VILMA_EIG_SLAB_ELEMS, read when a context is created, keeps the sweep reproducible).
-// Every slab re-reads the block's x and writes (and the combine re-reads) a partial y of the
-// block's height: 3 / columns of the slab's own bytes.  48 k -> 96 k elements: C4 product
-// 0.66 - 0.69 -> 0.59 - 0.63 ms, an 8-way shard of it 0.088 -> 0.083 ms
-// (profiles/r03u_eigen_slab_size.txt; round 2 had settled on 48 k with guarded loads).  At C4
-// the gain needs the single launch for all block heights, which 96 k brings along (about 6 000
-// work items, below eig_merge_below): with one launch per class 96 k and 48 k measure the same.
-#ifndef EIG_SLAB_MAX_COLS
-#define EIG_SLAB_MAX_COLS 128
-#endif
-inline int g_eig_slab_elems = 98304;
-inline int eig_slab_cols(int n, int R) {
-    const int C = eig_batch_cols(R);
-    // blocks of up to 512 rows (R = 2) are taken one slab per WAVE: a quarter of the budget each
-    const int budget = R == 2 ? g_eig_slab_elems / 2 : g_eig_slab_elems;
-    const int want = (budget / n + C - 1) / C * C;
-    return std::max(C, std::min(EIG_SLAB_MAX_COLS, want));
-}
+// Columns of U one workgroup of the fused product takes ("slab"): the block's columns are cut into
+// the fewest slabs of at most g_eig_slab_elems elements of U, equal to within a batch
+// (VILMA_EIG_SLAB_ELEMS, read when a context is created, keeps the sweep reproducible).  Every slab
+// re-reads the block's x, leaves a partial y of the block's height and ends in a store phase; a
+// block of ONE slab writes y and its y.z partial itself (no scratch, no combine item).  History:
+// 48 k elements (r02, guarded loads) -> 96 k with the single launch for all block heights (r03:
+// C4 product 0.66 - 0.69 -> 0.59 - 0.63 ms, profiles/r03u_eigen_slab_size.txt) -> 384 k and no cap on
+// the columns (r05: 0.603 - 0.643 -> 0.578 - 0.588 ms with slabs of <= 512 columns before the direct
+// path, profiles/r05n_eigen_slabs.txt): as for the dense kernel, what the store phases cost falls
+// with their number.
+inline int g_eig_slab_elems = 393216;
 inline int eig_n_slabs(int n, int r, int R) {
-    const int cols = eig_slab_cols(n, R);
-    return (r + cols - 1) / cols;
+    // blocks of up to 512 rows (R = 2) are taken one slab per WAVE by the per-class launch: half the budget
+    const int64_t budget = R == 2 ? g_eig_slab_elems / 2 : g_eig_slab_elems;
+    return (int)std::max<int64_t>(1, ((int64_t)n * r + budget - 1) / budget);
+}
+inline int eig_slab_cols(int n, int r, int R) {
+    const int C = eig_batch_cols(R), ns = eig_n_slabs(n, r, R);
+    return std::max(C, ((r + ns - 1) / ns + C - 1) / C * C);
 }
 
 // number of doubles a dense block occupies: per 128-column slab J the panel of rows >= 128 J

@@ -55,7 +55,8 @@ struct EigItem {
     int32_t ldc;           // column stride in doubles (even)
     int32_t x_off;         // pool offset of x[0] of the block
     int32_t s_off;         // scratch offset of S[slab][0]
-    int32_t pad;
+    int32_t direct;        // > 0: the slab is the whole block -- s_off is the POOL offset of y[0] and
+                           // direct - 1 the slot of the block's y.z partial; nothing goes to scratch
 };
 
 // One work item of the SYMMETRIC dense product: the panel of one block below (and including)
@@ -300,16 +301,19 @@ int eig_rows_per_thread(int n);
 int eig_batch_cols(int R);
 // One launch takes the items of ONE class R (rows per thread).
 void launch_ld_eig_fused(const EigItem *items, int n_items, int R, const double *pool0,
-                         const double *pool1, double *scratch, int64_t s_stride, hipStream_t s);
+                         const double *pool1, double *scratch, int64_t s_stride,
+                         double *dot_partials, int dot_stride, hipStream_t s);
 // the class of blocks of up to 512 rows (R = 2): one WAVE per slab of columns, no barrier
 void launch_ld_eig_tall(const EigItem *items, int n_items, const double *pool0, const double *pool1,
-                        double *scratch, int64_t s_stride, hipStream_t s);
+                        double *scratch, int64_t s_stride, double *dot_partials, int dot_stride,
+                        hipStream_t s);
 void launch_ld_eig_wave(const EigItem *items, int n_items, const double *pool0, const double *pool1,
-                        double *scratch, int64_t s_stride, hipStream_t s);
+                        double *scratch, int64_t s_stride, double *dot_partials, int dot_stride,
+                        hipStream_t s);
 // the items of every class in one launch (small shards: one ramp and tail instead of four)
 void launch_ld_eig_fused_all(const EigItem *items, int n_items, const double *pool0,
                              const double *pool1, double *scratch, int64_t s_stride,
-                             hipStream_t s);
+                             double *dot_partials, int dot_stride, hipStream_t s);
 // row-major [n x r] -> column-major [r][ldc], rows n .. ldc-1 zero (load time)
 void launch_repack_columns(const double *src, int n, int r, int64_t ldc, double *dst,
                            hipStream_t s);

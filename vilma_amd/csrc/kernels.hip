@@ -1345,7 +1345,7 @@ int eig_batch_cols(int R) { return R <= 2 ? 8 : (R <= 4 ? 4 : 2); }
 template <int R, int NR, int T = EIG_THREADS>
 static __device__ __forceinline__ void eig_fused_body(
     const EigItem &it, const PoolPair &pools, double *__restrict__ scratch, int64_t s_stride,
-    double (&red)[2][T / 64][EIG_RED_SLOTS]) {
+    double *__restrict__ dot_partials, int dot_stride, double (&red)[2][T / 64][EIG_RED_SLOTS]) {
     constexpr int H = R / 2;                       // 16-byte loads per column per thread
     constexpr int C = R <= 2 ? 8 : (R <= 4 ? 4 : 2);   // columns per batch: <= 12 loads in flight
     constexpr int V = C * NR;                      // values reduced per batch
@@ -1440,6 +1440,32 @@ static __device__ __forceinline__ void eig_fused_body(
             }
         }
     }
+    if (it.direct) {
+        // the slab is the whole block (uniform over the workgroup): y goes to the pool, and the
+        // block's y.z partial is formed from the x still in registers -- no scratch, no combine item
+        __syncthreads();                            // the last batch's column sums have been read
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double *yo = const_cast<double *>(pools.p[r]) + it.s_off;
+            double d = 0.0;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const int row = row0 + 2 * T * i;
+                if (row < n) { yo[row] = y[r][2 * i]; d = fma(y[r][2 * i], x[r][2 * i], d); }
+                if (row + 1 < n) { yo[row + 1] = y[r][2 * i + 1]; d = fma(y[r][2 * i + 1], x[r][2 * i + 1], d); }
+            }
+            d = wave_sum(d);
+            if (lane == 0) red[0][w][r] = d;
+        }
+        __syncthreads();
+        if (threadIdx.x < NR) {
+            double d = red[0][0][threadIdx.x];
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) d += red[0][ww][threadIdx.x];
+            dot_partials[(int64_t)threadIdx.x * dot_stride + it.direct - 1] = d;
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         double *so = scratch + r * s_stride + it.s_off;
@@ -1467,7 +1493,8 @@ static __device__ __forceinline__ void eig_fused_body(
 #define EIGW_C 2
 template <int NR>
 static __device__ __forceinline__ void eig_wave_body(const EigItem &it, const PoolPair &pools,
-                                                     double *__restrict__ scratch, int64_t s_stride) {
+                                                     double *__restrict__ scratch, int64_t s_stride,
+                                                     double *__restrict__ dot_partials, int dot_stride) {
     constexpr int H = EIGW_ROWS / 128;             // 16-byte loads per column per lane
     constexpr int C = EIGW_C;
     const int n = it.n, ncols = it.ncols;
@@ -1545,6 +1572,22 @@ static __device__ __forceinline__ void eig_wave_body(const EigItem &it, const Po
             }
         }
     }
+    if (it.direct) {                                // the slab is the whole block: see eig_fused_body
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double *yo = const_cast<double *>(pools.p[r]) + it.s_off;
+            double d = 0.0;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const int row = row0 + 128 * i;
+                if (row < n) { yo[row] = y[r][2 * i]; d = fma(y[r][2 * i], x[r][2 * i], d); }
+                if (row + 1 < n) { yo[row + 1] = y[r][2 * i + 1]; d = fma(y[r][2 * i + 1], x[r][2 * i + 1], d); }
+            }
+            d = wave_sum(d);
+            if (lane == 0) dot_partials[(int64_t)r * dot_stride + it.direct - 1] = d;
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         double *so = scratch + r * s_stride + it.s_off;
@@ -1560,7 +1603,8 @@ static __device__ __forceinline__ void eig_wave_body(const EigItem &it, const Po
 template <int NR>
 __global__ __launch_bounds__(256) void ld_eig_wave_kernel(
     const EigItem *__restrict__ items, int n_items, const PoolPair pools_arg,
-    double *__restrict__ scratch, int64_t s_stride, const int *pred, const PhasePtrs *pp) {
+    double *__restrict__ scratch, int64_t s_stride, double *__restrict__ dot_partials, int dot_stride,
+    const int *pred, const PhasePtrs *pp) {
     PRED_EXIT(pred);
     PoolPair pools = pools_arg;
     if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
@@ -1568,11 +1612,12 @@ __global__ __launch_bounds__(256) void ld_eig_wave_kernel(
     const int idx = blockIdx.x * 4 + w;            // one slab per wave
     if (idx >= n_items) return;
     const EigItem it = items[idx];
-    eig_wave_body<NR>(it, pools, scratch, s_stride);
+    eig_wave_body<NR>(it, pools, scratch, s_stride, dot_partials, dot_stride);
 }
 
 void launch_ld_eig_wave(const EigItem *items, int n_items, const double *pool0, const double *pool1,
-                        double *scratch, int64_t s_stride, hipStream_t s) {
+                        double *scratch, int64_t s_stride, double *dot_partials, int dot_stride,
+                        hipStream_t s) {
     if (n_items <= 0) return;
     PoolPair pp;
     pp.p[0] = pool0;
@@ -1580,10 +1625,10 @@ void launch_ld_eig_wave(const EigItem *items, int n_items, const double *pool0, 
     const dim3 grid((n_items + 3) / 4), block(256);
     if (pool1)
         hipLaunchKernelGGL((ld_eig_wave_kernel<2>), grid, block, 0, s, items, n_items, pp, scratch,
-                           s_stride, g_pred, g_phase);
+                           s_stride, dot_partials, dot_stride, g_pred, g_phase);
     else
         hipLaunchKernelGGL((ld_eig_wave_kernel<1>), grid, block, 0, s, items, n_items, pp, scratch,
-                           s_stride, g_pred, g_phase);
+                           s_stride, dot_partials, dot_stride, g_pred, g_phase);
 }
 
 // One launch per block-height class present (R = rows per thread).  A single kernel switching on
@@ -1593,13 +1638,14 @@ void launch_ld_eig_wave(const EigItem *items, int n_items, const double *pool0, 
 template <int R, int NR>
 __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_kernel(
     const EigItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
-    int64_t s_stride, const int *pred, const PhasePtrs *pp) {
+    int64_t s_stride, double *__restrict__ dot_partials, int dot_stride, const int *pred,
+    const PhasePtrs *pp) {
     __shared__ double red[2][EIG_THREADS / 64][EIG_RED_SLOTS];
     PRED_EXIT(pred);
     PoolPair pools = pools_arg;
     if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const EigItem it = items[blockIdx.x];
-    eig_fused_body<R, NR>(it, pools, scratch, s_stride, red);
+    eig_fused_body<R, NR>(it, pools, scratch, s_stride, dot_partials, dot_stride, red);
 }
 
 // The tall class (3 073 .. 6 144 rows): the same body with 512 threads, 12 rows each, so U is read
@@ -1608,17 +1654,19 @@ __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_kernel(
 template <int NR>
 __global__ __launch_bounds__(EIG_TALL_THREADS) void ld_eig_tall_kernel(
     const EigItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
-    int64_t s_stride, const int *pred, const PhasePtrs *pp) {
+    int64_t s_stride, double *__restrict__ dot_partials, int dot_stride, const int *pred,
+    const PhasePtrs *pp) {
     __shared__ double red[2][EIG_TALL_THREADS / 64][EIG_RED_SLOTS];
     PRED_EXIT(pred);
     PoolPair pools = pools_arg;
     if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const EigItem it = items[blockIdx.x];
-    eig_fused_body<12, NR, EIG_TALL_THREADS>(it, pools, scratch, s_stride, red);
+    eig_fused_body<12, NR, EIG_TALL_THREADS>(it, pools, scratch, s_stride, dot_partials, dot_stride, red);
 }
 
 void launch_ld_eig_tall(const EigItem *items, int n_items, const double *pool0, const double *pool1,
-                        double *scratch, int64_t s_stride, hipStream_t s) {
+                        double *scratch, int64_t s_stride, double *dot_partials, int dot_stride,
+                        hipStream_t s) {
     if (n_items <= 0) return;
     PoolPair pp;
     pp.p[0] = pool0;
@@ -1626,10 +1674,10 @@ void launch_ld_eig_tall(const EigItem *items, int n_items, const double *pool0, 
     const dim3 grid(n_items), block(EIG_TALL_THREADS);
     if (pool1)
         hipLaunchKernelGGL((ld_eig_tall_kernel<2>), grid, block, 0, s, items, pp, scratch, s_stride,
-                           g_pred, g_phase);
+                           dot_partials, dot_stride, g_pred, g_phase);
     else
         hipLaunchKernelGGL((ld_eig_tall_kernel<1>), grid, block, 0, s, items, pp, scratch, s_stride,
-                           g_pred, g_phase);
+                           dot_partials, dot_stride, g_pred, g_phase);
 }
 
 // All classes in one launch: the item says how many rows per thread its block needs.  Every class
@@ -1639,21 +1687,22 @@ void launch_ld_eig_tall(const EigItem *items, int n_items, const double *pool0, 
 template <int NR>
 __global__ __launch_bounds__(EIG_THREADS) void ld_eig_fused_all_kernel(
     const EigItem *__restrict__ items, const PoolPair pools_arg, double *__restrict__ scratch,
-    int64_t s_stride, const int *pred, const PhasePtrs *pp) {
+    int64_t s_stride, double *__restrict__ dot_partials, int dot_stride, const int *pred,
+    const PhasePtrs *pp) {
     __shared__ double red[2][EIG_THREADS / 64][EIG_RED_SLOTS];
     PRED_EXIT(pred);
     PoolPair pools = pools_arg;
     if (pp != nullptr) { pools.p[0] = PHASE(pp)->pool_out; pools.p[1] = NR == 2 ? PHASE(pp)->pool_out2 : PHASE(pp)->pool_out; }
     const EigItem it = items[blockIdx.x];
-    if (it.n <= 2 * EIG_THREADS) eig_fused_body<2, NR>(it, pools, scratch, s_stride, red);
-    else if (it.n <= 4 * EIG_THREADS) eig_fused_body<4, NR>(it, pools, scratch, s_stride, red);
-    else if (it.n <= 8 * EIG_THREADS) eig_fused_body<8, NR>(it, pools, scratch, s_stride, red);
-    else eig_fused_body<12, NR>(it, pools, scratch, s_stride, red);
+    if (it.n <= 2 * EIG_THREADS) eig_fused_body<2, NR>(it, pools, scratch, s_stride, dot_partials, dot_stride, red);
+    else if (it.n <= 4 * EIG_THREADS) eig_fused_body<4, NR>(it, pools, scratch, s_stride, dot_partials, dot_stride, red);
+    else if (it.n <= 8 * EIG_THREADS) eig_fused_body<8, NR>(it, pools, scratch, s_stride, dot_partials, dot_stride, red);
+    else eig_fused_body<12, NR>(it, pools, scratch, s_stride, dot_partials, dot_stride, red);
 }
 
 void launch_ld_eig_fused_all(const EigItem *items, int n_items, const double *pool0,
                              const double *pool1, double *scratch, int64_t s_stride,
-                             hipStream_t s) {
+                             double *dot_partials, int dot_stride, hipStream_t s) {
     if (n_items <= 0) return;
     PoolPair pp;
     pp.p[0] = pool0;
@@ -1661,35 +1710,37 @@ void launch_ld_eig_fused_all(const EigItem *items, int n_items, const double *po
     const dim3 grid(n_items), block(EIG_THREADS);
     if (pool1)
         hipLaunchKernelGGL((ld_eig_fused_all_kernel<2>), grid, block, 0, s, items, pp, scratch,
-                           s_stride, g_pred, g_phase);
+                           s_stride, dot_partials, dot_stride, g_pred, g_phase);
     else
         hipLaunchKernelGGL((ld_eig_fused_all_kernel<1>), grid, block, 0, s, items, pp, scratch,
-                           s_stride, g_pred, g_phase);
+                           s_stride, dot_partials, dot_stride, g_pred, g_phase);
 }
 
 template <int R>
 static void launch_eig_r(const EigItem *items, int n_items, const PoolPair &pp, bool two,
-                         double *scratch, int64_t s_stride, hipStream_t s) {
+                         double *scratch, int64_t s_stride, double *dot_partials, int dot_stride,
+                         hipStream_t s) {
     const dim3 grid(n_items), block(EIG_THREADS);
     if (two)
         hipLaunchKernelGGL((ld_eig_fused_kernel<R, 2>), grid, block, 0, s, items, pp, scratch,
-                           s_stride, g_pred, g_phase);
+                           s_stride, dot_partials, dot_stride, g_pred, g_phase);
     else
         hipLaunchKernelGGL((ld_eig_fused_kernel<R, 1>), grid, block, 0, s, items, pp, scratch,
-                           s_stride, g_pred, g_phase);
+                           s_stride, dot_partials, dot_stride, g_pred, g_phase);
 }
 
 void launch_ld_eig_fused(const EigItem *items, int n_items, int R, const double *pool0,
-                         const double *pool1, double *scratch, int64_t s_stride, hipStream_t s) {
+                         const double *pool1, double *scratch, int64_t s_stride,
+                         double *dot_partials, int dot_stride, hipStream_t s) {
     if (n_items <= 0) return;
     PoolPair pp;
     pp.p[0] = pool0;
     pp.p[1] = pool1 ? pool1 : pool0;
     switch (R) {
-        case 2: launch_eig_r<2>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, s); break;
-        case 4: launch_eig_r<4>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, s); break;
-        case 8: launch_eig_r<8>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, s); break;
-        case 12: launch_eig_r<12>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, s); break;
+        case 2: launch_eig_r<2>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, dot_partials, dot_stride, s); break;
+        case 4: launch_eig_r<4>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, dot_partials, dot_stride, s); break;
+        case 8: launch_eig_r<8>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, dot_partials, dot_stride, s); break;
+        case 12: launch_eig_r<12>(items, n_items, pp, pool1 != nullptr, scratch, s_stride, dot_partials, dot_stride, s); break;
         default: break;
     }
 }
