@@ -28,7 +28,7 @@ def main():
     args = ap.parse_args()
     from test_gpu_edge_cases import _problem, _build
     pool = [1, 2, 5, 31, 64, 127, 128, 129, 200, 255, 256, 257, 300, 513]
-    bad, handed, t0 = 0, 0, time.time()
+    bad, handed, rounding, t0 = 0, 0, 0, time.time()
     for seed in range(args.first, args.first + args.seeds):
         rng = np.random.default_rng(77000 + seed)
         P = int(rng.choice([1, 2, 2, 3, 4, 5]))
@@ -64,6 +64,24 @@ def main():
             ok &= np.array_equal(dev[1], host[1]) and np.array_equal(dev[2], host[2]) and dev[3] == host[3]
             handed += dev[5]
             if not ok:
+                # Mixtures beyond the on-chip stash (M >= 70 here, or more than four cohorts) run LAZY
+                # trials on the device: the state is carried as (stored vi_mu, a, c) -- within a beta
+                # loop (round 5) and, without --learn-scaling and up to four cohorts, from sweep to sweep
+                # -- while the host's line search stores and re-blends rounded arrays.  The same
+                # numbers to rounding: every decision equal (L to the bit, the same trials), values close.
+                near = dev[3] == host[3]
+                for d, h in zip(dev[0], host[0]):
+                    near &= d[1] == h[1] and abs(d[0] - h[0]) <= 1e-10 * abs(h[0])
+                    near &= bool(np.allclose(d[2], h[2], rtol=1e-6, atol=1e-12))
+                    near &= bool(np.allclose(d[3], h[3], rtol=1e-10, atol=0))
+                near &= bool(np.allclose(dev[1], host[1], rtol=1e-8, atol=1e-12))
+                near &= bool(np.allclose(dev[2], host[2], rtol=1e-8, atol=1e-300))
+                if near and (M >= 70 or P > 4):
+                    rounding += 1
+                    ok = True
+                    if seed % 10 == 1:
+                        print('ok (lazy trials: equal to rounding, every decision equal)', label, flush=True)
+            if not ok:
                 bad += 1
                 print('MISMATCH', label, flush=True)
             elif seed % 10 == 0:
@@ -72,8 +90,9 @@ def main():
         except Exception as exc:
             bad += 1
             print('ERROR', label, repr(exc)[:300], flush=True)
-    print('%d problems, %d mismatches or errors, %d stages handed back to the host, %.0f s'
-          % (args.seeds, bad, handed, time.time() - t0))
+    print('%d problems, %d mismatches or errors (%d equal to the bit, %d -- lazy trials -- to rounding), '
+          '%d stages handed back to the host, %.0f s'
+          % (args.seeds, bad, args.seeds - bad - rounding, rounding, handed, time.time() - t0))
     sys.exit(1 if bad else 0)
 
 

@@ -23,9 +23,17 @@ def main():
     ap.add_argument('--seeds', type=int, default=100)
     ap.add_argument('--first', type=int, default=0)
     ap.add_argument('--sweeps', type=int, default=3)
+    ap.add_argument('--shapes', action='store_true',
+                    help='round 5: each problem under a work-item shape of its own -- VILMA_LD_TILE (strip '
+                         'shapes of the tiled dense product, 0 = round 4\'s kernel) and VILMA_EIG_SLAB_ELEMS '
+                         '(many small slabs ... one slab per block = the direct path) drawn from the seed -- '
+                         'and blocks of up to 1 300 SNPs in the pool, so that tiles of several slabs, '
+                         'off-diagonal tiles and multi-slab eigen blocks occur')
     args = ap.parse_args()
     from test_gpu_edge_cases import _problem, _compare
     pool = [1, 2, 5, 31, 64, 127, 128, 129, 200, 255, 256, 257, 300, 513]
+    if args.shapes:
+        pool += [511, 512, 640, 700, 1025, 1300]
     bad, t0 = 0, time.time()
     for seed in range(args.first, args.first + args.seeds):
         rng = np.random.default_rng(5000 + seed)
@@ -36,6 +44,15 @@ def main():
         N = max(sum(s) for s in sizes) + int(rng.integers(0, 9))
         kw = dict(scaled=bool(rng.integers(0, 2)), scale_se=bool(rng.integers(0, 2)))
         label = 'seed %d: P=%d M=%d A=%d N=%d %s' % (seed, P, M, A, N, kw)
+        if args.shapes:         # (read by vilma_create: every problem makes its own context)
+            srng = np.random.default_rng(9000 + seed)
+            tile = str(srng.choice(['auto', '512,4', '512,2', '512,1', '256,2', '256,1', '128,1', '0']))
+            slab = int(srng.choice([1024, 4096, 32768, 393216]))
+            os.environ.pop('VILMA_LD_TILE', None)
+            if tile != 'auto':
+                os.environ['VILMA_LD_TILE'] = tile
+            os.environ['VILMA_EIG_SLAB_ELEMS'] = str(slab)
+            label += ' tile %s slab %d' % (tile, slab)
         try:
             pr = _problem(rng, P, sizes, N=N, M=M, A=A, ldthresh=float(rng.choice([1.0, 0.7])),
                           empty_annot=bool(rng.integers(0, 2)))

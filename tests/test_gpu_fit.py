@@ -94,6 +94,58 @@ def test_inner_loops_on_the_device_equal_host_decided_bit_for_bit(monkeypatch, s
     assert host[4] == 0 and dev[4] >= 15 and dev[5] == 0
 
 
+@pytest.mark.parametrize('two_step', ['1', '0'])
+def test_persistent_lazy_state_against_a_stored_one_and_through_drains(monkeypatch, two_step):
+    """Mixtures beyond the stash, no --learn-scaling: the state lives as (stored vi_mu, a, c) from
+    sweep to sweep -- no sweep writes vi_mu, the sums pass only sums, the evaluation behind the
+    M-step derives its state as the trials do (SweepCtl::mu_base).  Against the same fit with the
+    state written out at the end of every sweep (VILMA_PIPE_PERSIST=0) and against the host-decided
+    fit: every decision the same (L to the bit), values to rounding.  And the state comes back as an
+    array whenever somebody asks: a drain between two queued sweeps (the reported state's c must
+    have survived the trial queued beyond it), a parameter read in mid-fit, the end of the run."""
+    g = golden('traj_p2_mid.npz')
+    monkeypatch.setenv('VILMA_TILE_SUMS', '0')
+    monkeypatch.setenv('VILMA_PIPE_LAZY', '1')
+    monkeypatch.setenv('VILMA_TWO_STEP', two_step)
+    n = len(g['elbo'])
+
+    def run(lookahead, persist, poke=False, n=n):
+        monkeypatch.setenv('VILMA_LOOKAHEAD', '1' if lookahead else '0')
+        monkeypatch.setenv('VILMA_PIPE_PERSIST', '1' if persist else '0')
+        vi, _ = product_vi_from_traj(g)
+        np.random.seed(int(g['seed']))
+        vi._initialize()
+        state, trace, seen = None, [], []
+        for k in range(n):
+            state, stats = vi.sweep(state, lookahead=k + 1 < n)
+            trace.append((state['elbo'], tuple(state['L']), state['running']))
+            if poke and k == 4:
+                vi.engine.drain()                       # the promise of another sweep broken
+            if poke and k in (8, 9):
+                seen.append((k, vi._params()[0].copy()))    # a state read in mid-fit (twice in a row)
+        out = (trace, vi._params()[0].copy(), vi.n_trials, vi.n_stages_ahead, seen)
+        vi.engine.close()
+        return out
+    host = run(False, False)
+    stored = run(True, False)
+    kept = run(True, True)
+    poked = run(True, True, poke=True)
+    for other in (stored, kept, poked):
+        for (e_o, L_o, r_o), (e_h, L_h, r_h) in zip(other[0], host[0]):
+            assert L_o == L_h
+            assert abs(e_o - e_h) <= 1e-12 * abs(e_h) and abs(r_o - r_h) <= 1e-9 * abs(r_h)
+        np.testing.assert_allclose(other[1], host[1], rtol=1e-10, atol=1e-14)
+        assert other[2] == host[2]
+    assert kept[3] >= 15 and poked[3] >= 10
+    # the arrays handed out in mid-fit are states of the trajectory: the next sweeps go on from them
+    # (the uninterrupted runs above end where the interrupted one does), and they differ from sweep
+    # to sweep
+    (k0, m0), (k1, m1) = poked[4]
+    assert np.all(np.isfinite(m0)) and np.all(np.isfinite(m1)) and not np.array_equal(m0, m1)
+    # ... and the array read after sweep 8 is what a host-decided fit of nine sweeps ends with
+    np.testing.assert_allclose(m0, run(False, False, n=9)[1], rtol=1e-10, atol=1e-14)
+
+
 def test_changing_the_stream_between_queued_sweeps(monkeypatch):
     """A fit that moves to another HIP stream while sweeps are queued ahead on the old one: the
     library finishes what it queued there, puts the reported state back and carries on on the new

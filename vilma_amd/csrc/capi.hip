@@ -531,7 +531,7 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     a.diff = (!blend && dsum_dev && dmax_dev) ? 1 : 0;
     // a beta trial also leaves the per-tile responsibility sums of its candidates (vilma_trial_sums)
     const int ns = two ? 2 : 1;
-    a.no_store = (blend && queued && c->lazy_trial) ? 1 : 0;
+    a.no_store = (queued && (blend ? c->lazy_trial : c->lazy_persist)) ? 1 : 0;
     const bool stash = blend && !a.no_store && c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, ns);
     if (stash) a.sum_partials = c->sum_partials;
     if (sums_a_dev && !stash) return fail(c, "this trial cannot deliver the responsibility sums");
@@ -610,7 +610,8 @@ int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev
         c->prof_now = c->prof > 0 && (c->prof_tick % c->prof) == 0;
         prof_begin(c, s, e0);
         launch_delta_sums(a, sums_dev, s);
-        prof_end(c, s, e0, a.mat ? VILMA_PROF_SUMS_MAT : VILMA_PROF_SUMS);
+        // (a persistent lazy state: the pass derives the state and stores nothing)
+        prof_end(c, s, e0, (a.mat && !c->lazy_persist) ? VILMA_PROF_SUMS_MAT : VILMA_PROF_SUMS);
     }
     set_launch_phase(nullptr);
     HIPCHK(c, hipGetLastError());
@@ -619,16 +620,16 @@ int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev
 // The state lazy trials reached, a * mu[mu_from] + Sig cvec[mom] (PhasePtrs), written out into
 // mu[mu_to] by the host's own launch (a device-resident sweep handed back in the middle of a beta
 // loop: the host's line search works on stored vi_mu).  Its responsibility sums go to sums_dev.
-int vilma_detail::materialise_deferred(vilma_ctx *c, hipStream_t s, int mu_from, int mu_to, int mom,
-                                       double a_def, const double *tau, double *sums_dev) {
+int vilma_detail::materialise_deferred(vilma_ctx *c, hipStream_t s, int mu_from, int mu_to, int c_buf,
+                                       int lse_buf, double a_def, const double *tau, double *sums_dev) {
     DeltaArgs a;
     fill_delta_args(c, a, c->delta_partials);
     a.mat = 1;
     a.mu = c->mu[mu_from];
     a.mu_mat = c->mu[mu_to];
-    a.cvec = c->cvec[mom];
+    a.cvec = c->cvec[c_buf];
     a.acoef = a_def;
-    a.lse = c->lse[mom];
+    a.lse = c->lse[lse_buf];
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? tau[p] : 1.0;
     launch_delta_sums(a, sums_dev, s);
     HIPCHK(c, hipGetLastError());

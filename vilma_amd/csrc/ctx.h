@@ -166,6 +166,7 @@ struct vilma_ctx {
                                     // state lazy trials reached (PhasePtrs, kernels.h)
     bool poison = false;            // VILMA_DEBUG_POISON=1: NaN into what a trial is about to write
     bool lazy_trial = false;        // the trials being queued store no vi_mu (set by sweep.hip)
+    bool lazy_persist = false;      // ... and nothing else does: the evaluations being queued derive their state too
     double *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;
     std::vector<int32_t> dot_start;     // first y.z partial slot of each cohort (+ end)
@@ -264,9 +265,10 @@ int queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, double *dsum, 
 // accepted), for mixtures too large for the trial pass's on-chip stash; and the M-step from them
 int queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev);
 int queue_mstep(vilma_ctx *c, hipStream_t s, const double *sums_dev, double *hyper_dev);
-// a * mu[mu_from] + Sig cvec[mom] -> mu[mu_to] (the state lazy trials reached, written out by the host)
-int materialise_deferred(vilma_ctx *c, hipStream_t s, int mu_from, int mu_to, int mom, double a_def,
-                         const double *tau, double *sums_dev);
+// a * mu[mu_from] + Sig cvec[c_buf] -> mu[mu_to] (the state lazy trials reached, written out by the host;
+// lse[lse_buf]: its log-normaliser, for the responsibility sums that come with it)
+int materialise_deferred(vilma_ctx *c, hipStream_t s, int mu_from, int mu_to, int c_buf, int lse_buf,
+                         double a_def, const double *tau, double *sums_dev);
 // HIP-event brackets recorded with vilma_ctx::prof_tag == tag / >= tag are forgotten (launches of
 // a queued phase that did not happen exit at once: their microseconds are not kernel times)
 void prof_drop_tag(vilma_ctx *c, int64_t tag);

@@ -12,7 +12,7 @@ struct SweepDecideArgs {
     int32_t mode, P, A, M;
     int32_t check_convergence;       // veto when dsum[0] == 0
     int32_t have_b, have_sums_b;     // candidate B evaluated / its responsibility sums available
-    int32_t mstep_inside, lazy, scale_se, two_snapshots, max_inner, debug_kill_deferred;
+    int32_t mstep_inside, lazy, persist, scale_se, two_snapshots, max_inner, debug_kill_deferred;
     double chi[VILMA_MAX_P], ranks[VILMA_MAX_P];
     double rel_tol, abs_tol, rate, l_max, em_tol;
     SweepCtl *ctl;
@@ -30,7 +30,7 @@ static inline SweepDecideArgs decide_args(const SweepDecideParams &p) {
     SweepDecideArgs a;
     a.mode = p.mode; a.P = p.P; a.A = p.A; a.M = p.M;
     a.check_convergence = p.check_convergence; a.have_b = p.have_b; a.have_sums_b = p.have_sums_b;
-    a.mstep_inside = p.mstep_inside; a.lazy = p.lazy; a.scale_se = p.scale_se;
+    a.mstep_inside = p.mstep_inside; a.lazy = p.lazy; a.persist = p.persist; a.scale_se = p.scale_se;
     a.two_snapshots = p.two_snapshots;
     a.max_inner = p.max_inner;
     a.debug_kill_deferred = p.debug_kill_deferred;
@@ -54,6 +54,8 @@ struct DecideReport {
     // the block as it stood when the sweep ended (before the same decision's line search moved on)
     double end_L0, end_running, end_tau[VILMA_MAX_P];
     int32_t end_mu_role[3], end_mom_role[3], end_snap_cur;
+    double end_a_def;           // (persistent lazy state: the reported state is end_a_def (stored vi_mu)
+    int32_t end_c_zero;         // + Sig c, c in the buffer of end_mu_role[0])
 };
 
 static __host__ __device__ inline void decide_set_phases(const SweepDecideArgs &a, SweepCtl *ctl) {
@@ -62,8 +64,10 @@ static __host__ __device__ inline void decide_set_phases(const SweepDecideArgs &
     const double s1 = 1.0 / Lt;
     const double Lt2 = Lt * a.rate;
     const double s2 = 1.0 / Lt2;
-    phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_EVAL, 0.0, 0.0, ctl->phase[0]);
-    phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_TRIAL, s1, s2, ctl->phase[1]);
+    phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_EVAL, 0.0, 0.0, ctl->phase[0],
+               a.persist != 0, ctl->mu_base);
+    phase_ptrs(a.bases, ctl->mu_role, ctl->mom_role, VILMA_PHASE_TRIAL, s1, s2, ctl->phase[1],
+               a.persist != 0, ctl->mu_base);
     set_phase_extras(a.bases, ctl->snap_cur, a.two_snapshots != 0, ctl->tau, ctl->a_def, ctl->c_zero, ctl->phase[0]);
     set_phase_extras(a.bases, ctl->snap_cur, a.two_snapshots != 0, ctl->tau, ctl->a_def, ctl->c_zero, ctl->phase[1]);
     // the sums pass works on the state the evaluation starts from (a lazy accept overrides this)
@@ -79,6 +83,7 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
     rep.outcome = VILMA_OUT_NONE; rep.consumed = 0; rep.sweep_end = 0; rep.mstep = 0;
     rep.orig = 0.0; rep.fa = 0.0; rep.fb = 0.0; rep.eval_obj = 0.0; rep.sweep_change = 0.0;
     rep.L_tried = 0.0; rep.end_L0 = 0.0; rep.end_running = 0.0; rep.end_snap_cur = 0;
+    rep.end_a_def = 1.0; rep.end_c_zero = 1;
     for (int p = 0; p < VILMA_MAX_P; ++p) rep.end_tau[p] = 1.0;
     for (int q = 0; q < 3; ++q) { rep.end_mu_role[q] = 0; rep.end_mom_role[q] = 0; }
     if (!ctl->alive) return;
@@ -136,6 +141,7 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                 decide_set_phases(a, ctl);
             }
             rep.end_L0 = ctl->L0; rep.end_running = r; rep.end_snap_cur = ctl->snap_cur;
+            rep.end_a_def = ctl->a_def; rep.end_c_zero = ctl->c_zero;
             for (int p = 0; p < VILMA_MAX_P; ++p) rep.end_tau[p] = ctl->tau[p];
             for (int q = 0; q < 3; ++q) {
                 rep.end_mu_role[q] = ctl->mu_role[q];
@@ -212,7 +218,14 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                 // beside its moments (PhasePtrs).  While the beta loop goes on that is all that moves;
                 // when it ends the sums pass behind this decision writes the state out (role ua).
                 const double a_acc = (a.lazy ? ctl->a_def : 1.0) * (1.0 - step_acc);
-                if (a.lazy && !ends) {
+                if (a.persist) {
+                    // the state stays (stored vi_mu, a, c) whether the loop ends or not; the c buffers
+                    // change roles as stored candidates would (A's is in role 1, B's in role 2)
+                    ctl->a_def = a_acc;
+                    ctl->c_zero = 0;
+                    if (choice == 1) { ctl->mu_role[0] = ua; ctl->mu_role[1] = uc; ctl->mu_role[2] = ub; }
+                    else { ctl->mu_role[0] = ub; ctl->mu_role[1] = ua; ctl->mu_role[2] = uc; }
+                } else if (a.lazy && !ends) {
                     ctl->a_def = a_acc;
                     ctl->c_zero = 0;
                 } else if (choice == 1 || a.lazy) {
@@ -220,7 +233,7 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                 } else {
                     ctl->mu_role[0] = ub; ctl->mu_role[1] = ua; ctl->mu_role[2] = uc;
                 }
-                if (a.lazy && ends) {
+                if (a.lazy && ends && !a.persist) {
                     ctl->a_def = 1.0;
                     ctl->c_zero = 1;
                 }
@@ -258,6 +271,12 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                     sp.c_pend = a.bases.c[lazy_macc];
                     sp.a_pend = lazy_a;
                     sp.lse_ref = a.bases.lse[lazy_macc];
+                    if (a.persist) {
+                        // ... and writes nothing: the pass only forms the sums of the accepted state
+                        sp.mu_in = a.bases.mu[ctl->mu_base];
+                        sp.mu_mat = nullptr;
+                        sp.c_pend = a.bases.c[ctl->mu_role[0]];
+                    }
                 }
             }
         }

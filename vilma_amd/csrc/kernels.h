@@ -181,6 +181,14 @@ struct SweepCtl {
     double hrl[VILMA_MAX_P];    // 0.5 * ld_rank * log(tau) (det_log: the host gets the same bits)
     double a_def;               // lazy trials: the current state is a_def * (vi_mu of role 0) + Sig c, c in
     int32_t c_zero;             // the c buffer beside the current moments; c_zero: it is that vi_mu itself
+    // PERSISTENT lazy state (SweepDecideParams::persist): the state is a_def * (vi_mu of buffer mu_base)
+    // + Sig c for as long as the block lives -- no vi_mu is written by any sweep.  The three c buffers
+    // then take the roles the vi_mu buffers would (mu_role: current / candidate A / candidate B, rotated
+    // by every accept), so the c of the last reported state survives one trial queued beyond it exactly
+    // as a stored vi_mu would; the evaluation behind the M-step derives mu_k from (base, a, c) as the
+    // trials do.  Whoever needs the state as an array (a hand-back to the host, a drain, the end of the
+    // run) writes it out once (sweep.hip: persist_writeback).
+    int32_t mu_base;
     int32_t dbg_deferred;       // (tests) TRIAL decisions that found the state in that form so far
     PhasePtrs phase[3];
 };
@@ -195,7 +203,8 @@ struct BufferBases { double *mu[3], *pool[3], *m[3], *v[3], *lse[3], *c[3], *sna
 // holds: the accepted candidate's moments sit in role ta.)
 static __host__ __device__ inline void phase_ptrs(const BufferBases &b, const int32_t (&mu)[3],
                                                   const int32_t (&mom)[3], int phase, double step,
-                                                  double step2, PhasePtrs &o) {
+                                                  double step2, PhasePtrs &o, bool persist = false,
+                                                  int mu_base = 0) {
     const int cur = phase == VILMA_PHASE_EVAL ? mom[0] : mom[1];      // moments treated as current
     const int ta = phase == VILMA_PHASE_EVAL ? mom[1] : mom[0];       // ... written as candidate A
     const int tb = mom[2];
@@ -204,6 +213,11 @@ static __host__ __device__ inline void phase_ptrs(const BufferBases &b, const in
     o.pool_out = b.pool[ta]; o.m_out = b.m[ta]; o.v_out = b.v[ta]; o.lse_out = b.lse[ta];
     o.pool_out2 = b.pool[tb]; o.m_out2 = b.m[tb]; o.v_out2 = b.v[tb]; o.lse_out2 = b.lse[tb];
     o.c_cur = b.c[cur]; o.c_out = b.c[ta]; o.c_out2 = b.c[tb];
+    if (persist) {
+        // (SweepCtl::mu_base) the stored vi_mu never moves; the c buffers go by the vi_mu roles
+        o.mu_in = b.mu[mu_base]; o.mu_out = nullptr; o.mu_out2 = nullptr;
+        o.c_cur = b.c[mu[0]]; o.c_out = b.c[mu[1]]; o.c_out2 = b.c[mu[2]];
+    }
     o.step = step; o.step2 = step2;
 }
 // (snap_in / snap_out and tau of a PhasePtrs are set by set_phase_extras)
@@ -253,6 +267,9 @@ struct SnpKernelArgs {
     // a LAZY beta trial (no_store != 0; launch_snp_pass without the stash only; queued sweeps only, so
     // its buffers come from PhasePtrs): the candidates' vi_mu are not stored -- see PhasePtrs --
     // and the pass that needs the accepted state derives it (DeltaArgs::mat)
+    // no_store on a plain EVALUATION (a queued sweep with a persistent lazy state, SweepCtl::mu_base):
+    // the state evaluated is a_def (stored vi_mu) + Sig c_cur (PhasePtrs), derived component by
+    // component with the trials' expressions
     int32_t no_store;
     const int *pred;          // filled by the launcher (set_launch_predicate)
     const PhasePtrs *pp;      // filled by the launcher (set_launch_phase)
@@ -444,6 +461,8 @@ struct SweepDecideParams {
                                     // candidate's responsibility sums are in the result vector)
     int lazy;                       // the trials store no vi_mu: the sums pass behind an accepting
                                     // decision materialises the accepted candidate
+    int persist;                    // ... or (lazy, no --learn-scaling, P <= 4) nothing does: the state
+                                    // stays (stored vi_mu, a, c) from sweep to sweep (SweepCtl::mu_base)
     int scale_se;                   // an EVAL decision may update tau
     int two_snapshots;              // evaluations write their means to the other snapshot buffer
     int max_inner;                  // MAX_NUM_ITERS

@@ -1948,6 +1948,15 @@ static __device__ __forceinline__ double spd_inverse(const double (&lam)[P][P], 
 #ifndef KU
 #define KU 2
 #endif
+// batches of a plain evaluation requested ahead of the one being folded in, plus one (2: double
+// buffer, as the trials; 3: two ahead -- 100 VGPRs instead of 88, four waves per SIMD instead of
+// five, 6 KiB in flight per wave instead of 4).  Measured in round 5 and the same to the percent
+// (C3 evaluation 0.1753 against 0.1769 ms, M = 582 1.838 against 1.829 ms; forced back to five waves it
+// spills and takes 0.192 ms: profiles/r05q_eval_pass_prefetch_depth.txt): neither what a wave has in
+// flight nor the number of waves is what holds the evaluation at 3.8 - 4.1 TB/s.
+#ifndef SNP_EVAL_DEPTH
+#define SNP_EVAL_DEPTH 2
+#endif
 // Few components per wave (M = 40: ten): measured and NOT adopted -- batches of 5, so that all of a
 // wave's vi_mu is requested up front.  The loop shrinks (6.0 k -> 4.7 k cycles) but the kernel
 // needs 129 - 166 registers instead of 92 - 128, fewer workgroups are in flight per CU and both
@@ -2011,7 +2020,9 @@ static __device__ __forceinline__ void lds_barrier() {
 template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH, bool NOSTORE = false>
 __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WAVES(P)) void snp_pass_kernel(const SnpKernelArgs a) {
     static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
-    static_assert(!NOSTORE || (BLEND && !STASH), "lazy trials are the no-stash trials");
+    // NOSTORE with BLEND: a lazy trial; without: a plain evaluation of a lazy state (both derive
+    // mu_k = a (stored vi_mu) + Sig_k c component by component and store no vi_mu)
+    static_assert(!NOSTORE || !STASH, "lazy passes have no stash");
     constexpr int NT = 2 * P + 2;
     constexpr int NTP = (NT + 7) / 8 * 8;
     constexpr int NACC = 2 + 2 * P;
@@ -2100,6 +2111,9 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
 #endif
     };
     double bufA[KB][P], bufB[KB][P], lhA[KB], lhB[KB];
+    constexpr bool DEEP = !BLEND && P <= 2 && SNP_EVAL_DEPTH == 3;
+    double bufC[DEEP ? KB : 1][P], lhC[DEEP ? KB : 1];
+    (void)bufC; (void)lhC;
     constexpr bool FETCH_FIRST = !BLEND;
     if (FETCH_FIRST) fetch_mu(bufA, kbeg);
     const double s0 = q.lse_ref != nullptr ? q.lse_ref[ii] : 0.0;
@@ -2161,7 +2175,7 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
     // Sig (s g + (1 - s) Lam mu) written in the two numbers that describe it.  The candidates' cc go
     // beside their moments (one wave per tile writes them).
     double ac[NS], cc[NS][P];
-    if (NOSTORE) {
+    if (NOSTORE && BLEND) {
         const double a0 = q.c_zero ? 1.0 : q.a_def;
 #pragma unroll
         for (int c = 0; c < NS; ++c) ac[c] = a0 * (1.0 - step[c]);
@@ -2174,6 +2188,11 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
                 if ((SNP_SPLIT != 4 || w == 0) && live) (c == 0 ? q.c_out : q.c_out2)[p * N64 + i] = cc[c][p];
             }
         }
+    } else if (NOSTORE) {
+        // a plain evaluation of the lazy state itself: (a, c) as they stand
+        ac[0] = q.c_zero ? 1.0 : q.a_def;
+#pragma unroll
+        for (int p = 0; p < P; ++p) cc[0][p] = q.c_zero ? 0.0 : q.c_cur[p * N64 + ii];
     }
 
     const const_tab prec_tab = as_table(a.prec);
@@ -2245,14 +2264,14 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
                 double nat[P], mun[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    nat[p] = !BLEND ? told[p]
-                             : NOSTORE ? (ac[c] * told[p] + cc[c][p])      // Lam (ac mu + Sig cc)
-                                       : (step[c] * g[p] + (1.0 - step[c]) * told[p]);
+                    nat[p] = NOSTORE ? (ac[c] * told[p] + cc[c][p])        // Lam (ac mu + Sig cc)
+                             : !BLEND ? told[p]
+                                      : (step[c] * g[p] + (1.0 - step[c]) * told[p]);
                 double quad = 0.0;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     double t = mul[kk][p];
-                    if (BLEND) {
+                    if (BLEND || NOSTORE) {
                         t = NOSTORE ? ac[c] * mul[kk][p] : 0.0;
 #pragma unroll
                         for (int q = 0; q < P; ++q) t += sig[p][q] * (NOSTORE ? cc[c][q] : nat[q]);
@@ -2332,12 +2351,29 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
         }
         if (!FETCH_FIRST || attempt > 0) fetch(bufA, lhA, kbeg);
         SNP_STAMP(1);
+        if constexpr (DEEP) {
+            // a plain evaluation only reads: TWO batches requested ahead of the one being folded in
+            // (three buffers in rotation).  With one ahead a wave has 2 - 4 KiB in flight, 20 waves a
+            // CU 40 - 80 KiB: short of what 8 TB/s times the loaded latency asks of a CU.
+            fetch(bufB, lhB, kbeg + KB);
+            for (int k0 = kbeg; k0 < kend; k0 += 3 * KB) {
+                fetch(bufC, lhC, k0 + 2 * KB);
+                fold(bufA, lhA, k0, all_sums);
+                if (k0 + KB >= kend) break;        // wave-uniform
+                fetch(bufA, lhA, k0 + 3 * KB);
+                fold(bufB, lhB, k0 + KB, all_sums);
+                if (k0 + 2 * KB >= kend) break;
+                fetch(bufB, lhB, k0 + 4 * KB);
+                fold(bufC, lhC, k0 + 2 * KB, all_sums);
+            }
+        } else {
         for (int k0 = kbeg; k0 < kend; k0 += 2 * KB) {
             fetch(bufB, lhB, k0 + KB);         // past the end the clamped loads re-read component M-1
             fold(bufA, lhA, k0, all_sums);
             if (k0 + KB >= kend) break;        // wave-uniform
             fetch(bufA, lhA, k0 + 2 * KB);
             fold(bufB, lhB, k0 + KB, all_sums);
+        }
         }
         SNP_STAMP(2);
         // every wave publishes its part of the normaliser; every wave adds the four parts in wave
@@ -2576,8 +2612,8 @@ static void launch_snp_pass_s(const SnpKernelArgs &a, bool stash, hipStream_t s)
             return;
         }
     }
-    if constexpr (BLEND) {
-        if (a.no_store) {       // lazy trial: g instead of the candidates' vi_mu
+    if constexpr (BLEND || P <= 4) {
+        if (a.no_store) {       // lazy trial: no candidate vi_mu stored; lazy evaluation: the state derived
             hipLaunchKernelGGL((snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, false, true>), grid, block, lds, s, a);
             return;
         }
@@ -2764,13 +2800,17 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
 #pragma unroll
                     for (int q = 0; q < P; ++q) t += sig[p][q] * cv[q];
                     mu[u][p] = t;
-                    if constexpr (!PAIR_BATCH && !PAIR_COMP) MU_STORE(&mu_mat[mu_base + MU_ROW(k * P + p, N64)], t);
+                    if constexpr (!PAIR_BATCH && !PAIR_COMP) {
+                        if (mu_mat != nullptr) MU_STORE(&mu_mat[mu_base + MU_ROW(k * P + p, N64)], t);
+                    }
                 }
 #if MU_PAIRED
                 if constexpr (PAIR_COMP) {
+                    if (mu_mat != nullptr) {
 #pragma unroll
-                    for (int t = 0; t < P / 2; ++t)
-                        MU_STORE2(&mu_mat[mu_base + MU_PAIR(((k * P) >> 1) + t)], mu[u][2 * t], mu[u][2 * t + 1]);
+                        for (int t = 0; t < P / 2; ++t)
+                            MU_STORE2(&mu_mat[mu_base + MU_PAIR(((k * P) >> 1) + t)], mu[u][2 * t], mu[u][2 * t + 1]);
+                    }
                 }
 #endif
             } else {
@@ -2787,7 +2827,9 @@ __global__ __launch_bounds__(SNP_THREADS) void delta_kernel(const DeltaArgs a) {
             delta[u] = fmax(wdet * pass_exp(0.5 * quad + lhk - lse, expk), 1e-100);
         }
 #if MU_PAIRED
-        if constexpr (MAT && PAIR_BATCH) {
+        // (mu_mat == nullptr, uniform over the launch: a persistent lazy state -- the pass derives the
+        // state for its sums and stores nothing)
+        if constexpr (MAT && PAIR_BATCH) if (mu_mat != nullptr) {
             // the batch's new rows, pair by pair (a pair whose first row lies beyond the mixture was
             // computed from a clamped load: not stored; one that ends in the padding row stores zero there)
             const int j0 = (k0 * P) >> 1, MP = M * P;

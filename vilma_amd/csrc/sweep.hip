@@ -150,7 +150,8 @@ struct SweepState {
     SweepCtl *ctl_host = nullptr;           // pinned staging of the control block
     // the state at the end of the last sweep reported from the device (what a caller who breaks
     // the LOOKAHEAD promise gets back): roles, tau, snapshot buffer
-    struct Reported { int32_t mu_role[3], mom_role[3], snap_cur; double tau[VILMA_MAX_P]; bool valid = false; } rep_end;
+    struct Reported { int32_t mu_role[3], mom_role[3], snap_cur; double tau[VILMA_MAX_P]; bool valid = false;
+                      double a_def = 1.0; int32_t c_zero = 1; } rep_end;     // (a_def, c_zero: persistent lazy state)
     // statistics of decisions looked at in one call that belong to the next sweep
     int carry_trials = 0, carry_evals = 0, carry_products = 0;
     // the host's line search resumes a sweep the device began (see Resume)
@@ -534,6 +535,27 @@ bool lazy_trials(const vilma_ctx *c, const SweepState *s) {
     if (e && e[0] == '0') return false;
     return !stash_sums(c, s);
 }
+// ... and then nothing needs vi_mu as an array while the sweeps stay on the device: the state lives
+// on as (stored vi_mu, a, c) from sweep to sweep (SweepCtl::mu_base), the sums pass stops storing
+// (at M = 582 it wrote 9.8 GB per sweep) and the evaluation behind the M-step derives its state like
+// the trials.  Not with --learn-scaling (a tau update changes Sig_k under a state that must stay
+// put) nor beyond four cohorts (the lazy evaluation is built for P <= 4).
+bool lazy_persist(const vilma_ctx *c, const SweepState *s) {
+    const char *e = std::getenv("VILMA_PIPE_PERSIST");      // =0: write vi_mu out at the end of every sweep (A/B)
+    if (e && e[0] == '0') return false;
+    return lazy_trials(c, s) && !s->scale_se && c->P <= 4;
+}
+// A persistent lazy state (k.c_zero == 0: a_def (vi_mu of buffer mu_base) + Sig c, c in buffer c_buf)
+// written out for whoever needs vi_mu as an array; the host-side vi_mu roles then name the buffer
+// it went to as current.  lse_buf: the state's log-normaliser (for the sums that come with the pass).
+int persist_writeback(vilma_ctx *c, SweepState *s, hipStream_t st, int mu_base, int c_buf, int lse_buf,
+                      double a_def, const double *tau) {
+    const int to = (mu_base + 1) % 3;
+    if (materialise_deferred(c, st, mu_base, to, c_buf, lse_buf, a_def, tau, s->results + s->o_sa)) return 1;
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->mu_cur = to; c->mu_ta = mu_base; c->mu_tb = (mu_base + 2) % 3;
+    return 0;
+}
 
 int pipeline_buffers(vilma_ctx *c, SweepState *s) {
     if (c->ctl) return 0;
@@ -567,6 +589,7 @@ SweepDecideParams decide_params(vilma_ctx *c, SweepState *s, int mode, bool veto
     p.have_sums_b = (two && stash) ? 1 : 0;
     p.mstep_inside = stash ? 1 : 0;
     p.lazy = lazy_trials(c, s) ? 1 : 0;
+    p.persist = lazy_persist(c, s) ? 1 : 0;
     p.scale_se = (s->scale_se && allow_tau) ? 1 : 0;
     p.two_snapshots = 1;
     p.max_inner = MAX_NUM_ITERS;
@@ -618,6 +641,7 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     int rc = 0;
     c->prof_tag = 4 * tag;
     c->lazy_trial = lazy_trials(c, s);
+    c->lazy_persist = lazy_persist(c, s);
     set_launch_predicate(&c->ctl->alive);
     if (c->poison) launch_poison(s->results + s->o_ta, s->o_sb + s->am - s->o_ta, 0, st);
     rc = queue_trial_phase(c, st, two, s->results + s->o_ta, s->results + s->o_tb,
@@ -664,6 +688,7 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     }
     c->prof_tag = 0;
     c->lazy_trial = false;
+    c->lazy_persist = false;
     if (!rc) s->groups_out += 1;
     s->pipe_stream = st;
     return rc;
@@ -697,6 +722,7 @@ int pipeline_arm(vilma_ctx *c, SweepState *s, hipStream_t st, const double *L, d
     k.mom_role[0] = c->mom_ta; k.mom_role[1] = c->mom_cur; k.mom_role[2] = c->mom_tb;
     k.a_def = 1.0;          // the host's current vi_mu is stored as it is
     k.c_zero = 1;
+    k.mu_base = c->mu_cur;  // (persistent lazy state: and stays there)
     k.L0 = L[0];
     k.L_try = std::max(1.0, L[0] / 1.25);
     k.cur_obj = s->objective;
@@ -718,6 +744,7 @@ int pipeline_arm(vilma_ctx *c, SweepState *s, hipStream_t st, const double *L, d
     for (int q = 0; q < 3; ++q) { s->rep_end.mu_role[q] = k.mu_role[q]; s->rep_end.mom_role[q] = k.mom_role[q]; }
     s->rep_end.snap_cur = k.snap_cur;
     for (int p = 0; p < VILMA_MAX_P; ++p) s->rep_end.tau[p] = k.tau[p];
+    s->rep_end.a_def = 1.0; s->rep_end.c_zero = 1;
     return 0;
 }
 
@@ -780,11 +807,17 @@ int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const DecideR
     s->cur_sums = -1;
     s->armed = false;
     s->resume = SweepState::Resume();
-    if (!k.c_zero) {
+    if (!k.c_zero && q.args.persist) {
+        // a persistent lazy state: (vi_mu of buffer mu_base, a, c of the current role) -- write it out
+        // for the host's kernels
+        if (persist_writeback(c, s, st, k.mu_base, k.mu_role[0], k.mom_role[1], k.a_def, k.tau)) return 1;
+        s->mirror.a_def = 1.0;
+        s->mirror.c_zero = 1;
+    } else if (!k.c_zero) {
         // handed back in the middle of a beta loop of lazy trials: the current state exists as
         // (stored vi_mu, a, c) only -- write it out for the host's kernels
-        if (materialise_deferred(c, st, k.mu_role[0], k.mu_role[1], k.mom_role[1], k.a_def, k.tau,
-                                 s->results + s->o_sa)) return 1;
+        if (materialise_deferred(c, st, k.mu_role[0], k.mu_role[1], k.mom_role[1], k.mom_role[1], k.a_def,
+                                 k.tau, s->results + s->o_sa)) return 1;
         HIPCHK(c, hipStreamSynchronize(st));
         c->mu_cur = k.mu_role[1]; c->mu_ta = k.mu_role[0];
         s->mirror.a_def = 1.0;
@@ -876,6 +909,13 @@ int pipeline_rollback(vilma_ctx *c, SweepState *s, hipStream_t st) {
     if (!s->rep_end.valid) return fail(c, "internal: nothing to roll back to");
     const int cur = s->rep_end.mu_role[0];
     c->mu_cur = cur; c->mu_ta = (cur + 1) % 3; c->mu_tb = (cur + 2) % 3;
+    if (!s->rep_end.c_zero) {
+        // the reported state is a persistent lazy one: its c is still in its buffer (role 0 of the
+        // reported roles -- one trial beyond writes the other two), its vi_mu is written out now
+        // (the log-normaliser handed over only shifts the sums that come with the pass: not used)
+        if (persist_writeback(c, s, st, s->mirror.mu_base, cur, s->rep_end.mom_role[1], s->rep_end.a_def,
+                              s->rep_end.tau)) return 1;
+    }
     c->mom_cur = 0; c->mom_ta = 1; c->mom_tb = 2;
     c->snap_cur = s->rep_end.snap_cur;
     for (int p = 0; p < c->P; ++p) c->tau[p] = s->rep_end.tau[p];
@@ -961,6 +1001,7 @@ int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, doubl
             for (int t = 0; t < 3; ++t) { s->rep_end.mu_role[t] = rep.end_mu_role[t]; s->rep_end.mom_role[t] = rep.end_mom_role[t]; }
             s->rep_end.snap_cur = rep.end_snap_cur;
             for (int p = 0; p < VILMA_MAX_P; ++p) s->rep_end.tau[p] = rep.end_tau[p];
+            s->rep_end.a_def = rep.end_a_def; s->rep_end.c_zero = rep.end_c_zero;
             s->rep_end.valid = true;
         }
         if (q.args.mode == VILMA_DECIDE_TRIAL && rep.L_tried != 0.0) {
@@ -1013,6 +1054,13 @@ int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, doubl
         // device's (the sweep's last evaluation is accepted unconditionally)
         const SweepCtl &k = s->mirror;
         c->mu_cur = k.mu_role[0]; c->mu_ta = k.mu_role[1]; c->mu_tb = k.mu_role[2];
+        if (!k.c_zero) {
+            // (a persistent lazy state: the run ends here, its vi_mu is written out)
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (persist_writeback(c, s, st, k.mu_base, k.mu_role[0], k.mom_role[1], k.a_def, k.tau)) return 1;
+            s->mirror.a_def = 1.0;
+            s->mirror.c_zero = 1;
+        }
         c->mom_cur = k.mom_role[1]; c->mom_ta = k.mom_role[0]; c->mom_tb = k.mom_role[2];
         c->snap_cur = k.snap_cur;
         for (int p = 0; p < c->P; ++p) c->tau[p] = k.tau[p];
