@@ -12,8 +12,8 @@ With N>1 (launched by torch.distributed.run, one rank per GPU) the same global p
 sharded by LD blocks (strong scaling); the 3P+2 sums are all-reduced over RCCL per evaluation.
 
 Prints ONE JSON line (rank 0) with the sweep throughput, the roofline object of the dominant
-kernel (ld_sym_kernel for dense LD, ld_eig_fused_kernel for eigen-form LD; timed with HIP events on
-its launch stream inside the library) and, at N=1, the CPU baseline: the oracle (a port following
+kernel (ld_tile_kernel for dense LD -- ld_sym_kernel with VILMA_LD_TILE=0 --, ld_eig_fused_kernel
+for eigen-form LD; timed with HIP events on its launch stream inside the library) and, at N=1, the CPU baseline: the oracle (a port following
 the reference's operation schedule) timed on this host on a bounded sample of the same workload.
 
 roofline.achieved is priced on the ALGORITHMIC bytes of the product as this build defines it:
@@ -440,7 +440,10 @@ def main(argv=None, engine_factory=None):
              ('snp_pass_trial2', 'snp_pass_trial2', 3 * mp_bytes),
              ('snp_pass_trial_lazy', 'snp_pass_trial_lazy', mp_bytes),
              ('snp_pass_trial2_lazy', 'snp_pass_trial2_lazy', mp_bytes),
-             ('delta_kernel (sums pass)', 'sums_pass', mp_bytes),
+             # (with --learn-scaling the pass also WRITES the state in the sweep after a tau update --
+             # the library cannot tell when it queues it: bytes and fraction are then a lower bound)
+             ('delta_kernel (sums pass%s)' % ('; storing the state too in sweeps behind a tau update'
+                                              if args.learn_scaling else ''), 'sums_pass', mp_bytes),
              ('delta_kernel<MAT> (re-derive + store + sums)', 'sums_pass_store', 2 * mp_bytes)]
     kernel_rows = []
     for name, key, nbytes in kinds:

@@ -251,3 +251,44 @@ def test_device_resident_sweeps_equal_host_decided_sweeps(shape, monkeypatch):
     # sweeps did run from the control block -- p2_m130 too: a mixture beyond the on-chip stash gets
     # its responsibility sums from a pass behind the decision, not from the host
     assert dev[4] >= 15 and dev[5] == 0
+
+
+@pytest.mark.parametrize('two_step', ['1', '0'])
+def test_learn_scaling_under_a_persistent_lazy_state(monkeypatch, two_step):
+    """--learn-scaling with a mixture beyond the stash (M = 70, two cohorts): the state lives as
+    (stored vi_mu, a, c) across sweeps, and a tau update changes Sig_k = (Prec_k + D / tau)^-1 under
+    it -- the EVAL decision that takes the update has the state written out with the OLD tau (a pass
+    queued beside the re-evaluation) and goes on from that array (decide.h).  30 sweeps in which tau
+    moves again and again: the sweeps decided on the device against the host-decided fit (every
+    decision equal, tau and ELBO to rounding) and, for the first sweeps, against the oracle."""
+    rng = np.random.default_rng(77)
+    pr = _problem(rng, 2, [[300, 129, 200], [257, 64, 513]], N=900, M=70, A=2)
+    monkeypatch.setenv('VILMA_TWO_STEP', two_step)
+    _compare(pr, sweeps=4, scale_se=True)
+
+    def run(lookahead, persist):
+        monkeypatch.setenv('VILMA_LOOKAHEAD', '1' if lookahead else '0')
+        monkeypatch.setenv('VILMA_PIPE_PERSIST', '1' if persist else '0')
+        vi = _build(pr, 'product', scale_se=True)
+        np.random.seed(3)
+        vi._initialize()
+        state, trace = None, []
+        for k in range(30):
+            state, stats = vi.sweep(state, lookahead=k + 1 < 30)
+            trace.append((state['elbo'], tuple(state['L']), tuple(vi.error_scaling)))
+            if k == 20:
+                vi.engine.drain()           # (a drain behind tau updates: the stored array has moved)
+        out = (trace, vi._params()[0].copy(), vi.n_trials, vi.n_stages_ahead)
+        vi.engine.close()
+        return out
+    host, stored, kept = run(False, False), run(True, False), run(True, True)
+    moved = [k for k in range(1, 30) if host[0][k][2] != host[0][k - 1][2]]
+    assert len(moved) >= 5, moved                       # tau did move, in many sweeps
+    for other in (stored, kept):
+        for (e_o, L_o, t_o), (e_h, L_h, t_h) in zip(other[0], host[0]):
+            assert L_o == L_h
+            assert abs(e_o - e_h) <= 1e-11 * abs(e_h)
+            np.testing.assert_allclose(t_o, t_h, rtol=1e-11)
+        np.testing.assert_allclose(other[1], host[1], rtol=1e-9, atol=1e-13)
+        assert other[2] == host[2] and other[3] >= 20
+

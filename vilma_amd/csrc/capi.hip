@@ -599,7 +599,9 @@ int vilma_detail::queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, 
                                    double *dmax) {
     return evaluate(c, s, false, 0.0, totals, dsum, dmax, 0.0, nullptr, VILMA_PHASE_EVAL);
 }
-int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev) {
+// writes_state: the pass is queued to WRITE the state out (a tau update under a persistent lazy state,
+// sweep.hip), whatever it does with the sums
+int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev, bool writes_state) {
     DeltaArgs a;
     fill_delta_args(c, a, c->delta_partials);
     a.mat = c->lazy_trial ? 1 : 0;       // behind a lazy trial the pass also stores the candidate
@@ -611,7 +613,7 @@ int vilma_detail::queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev
         prof_begin(c, s, e0);
         launch_delta_sums(a, sums_dev, s);
         // (a persistent lazy state: the pass derives the state and stores nothing)
-        prof_end(c, s, e0, (a.mat && !c->lazy_persist) ? VILMA_PROF_SUMS_MAT : VILMA_PROF_SUMS);
+        prof_end(c, s, e0, (a.mat && (!c->lazy_persist || writes_state)) ? VILMA_PROF_SUMS_MAT : VILMA_PROF_SUMS);
     }
     set_launch_phase(nullptr);
     HIPCHK(c, hipGetLastError());

@@ -263,7 +263,7 @@ int queue_trial_phase(vilma_ctx *c, hipStream_t s, bool two, double *totals_a, d
 int queue_eval_phase(vilma_ctx *c, hipStream_t s, double *totals, double *dsum, double *dmax);
 // responsibility sums of the state the queued EVAL phase starts from (the candidate the decision
 // accepted), for mixtures too large for the trial pass's on-chip stash; and the M-step from them
-int queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev);
+int queue_sums_phase(vilma_ctx *c, hipStream_t s, double *sums_dev, bool writes_state = false);
 int queue_mstep(vilma_ctx *c, hipStream_t s, const double *sums_dev, double *hyper_dev);
 // a * mu[mu_from] + Sig cvec[c_buf] -> mu[mu_to] (the state lazy trials reached, written out by the host;
 // lse[lse_buf]: its log-normaliser, for the responsibility sums that come with it)

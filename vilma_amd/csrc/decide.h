@@ -54,8 +54,9 @@ struct DecideReport {
     // the block as it stood when the sweep ended (before the same decision's line search moved on)
     double end_L0, end_running, end_tau[VILMA_MAX_P];
     int32_t end_mu_role[3], end_mom_role[3], end_snap_cur;
-    double end_a_def;           // (persistent lazy state: the reported state is end_a_def (stored vi_mu)
-    int32_t end_c_zero;         // + Sig c, c in the buffer of end_mu_role[0])
+    double end_a_def;           // (persistent lazy state: the reported state is end_a_def (vi_mu of buffer
+    int32_t end_c_zero;         // end_mu_base) + Sig c, c in the buffer of end_mu_role[0])
+    int32_t end_mu_base;
 };
 
 static __host__ __device__ inline void decide_set_phases(const SweepDecideArgs &a, SweepCtl *ctl) {
@@ -83,7 +84,7 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
     rep.outcome = VILMA_OUT_NONE; rep.consumed = 0; rep.sweep_end = 0; rep.mstep = 0;
     rep.orig = 0.0; rep.fa = 0.0; rep.fb = 0.0; rep.eval_obj = 0.0; rep.sweep_change = 0.0;
     rep.L_tried = 0.0; rep.end_L0 = 0.0; rep.end_running = 0.0; rep.end_snap_cur = 0;
-    rep.end_a_def = 1.0; rep.end_c_zero = 1;
+    rep.end_a_def = 1.0; rep.end_c_zero = 1; rep.end_mu_base = 0;
     for (int p = 0; p < VILMA_MAX_P; ++p) rep.end_tau[p] = 1.0;
     for (int q = 0; q < 3; ++q) { rep.end_mu_role[q] = 0; rep.end_mom_role[q] = 0; }
     if (!ctl->alive) return;
@@ -109,6 +110,15 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
             if (!ok) {
                 dead = true;            // the host reports the error
             } else {
+                // A persistent lazy state a (stored vi_mu) + Sig_k c must stay put while Sig_k =
+                // (Prec_k + D / tau)^-1 changes under it: the pass queued behind this decision (it runs
+                // with the re-evaluation) writes it out with the OLD tau into the vi_mu buffer next to
+                // the stored one, and that array is the stored state from here on
+                const int32_t mat_from = ctl->mu_base, mat_to = (ctl->mu_base + 1) % 3;
+                const int32_t mat_c = ctl->mu_role[0], mat_lse = ctl->mom_role[1];
+                const double mat_a = ctl->a_def;
+                double tau_old[VILMA_MAX_P];
+                for (int p = 0; p < VILMA_MAX_P; ++p) tau_old[p] = ctl->tau[p];
                 for (int p = 0; p < P; ++p) {
                     ctl->tau[p] = tau[p];
                     ctl->hrl[p] = det_hrl(a.ranks[p], tau[p]);
@@ -118,7 +128,24 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                 const int32_t m0 = ctl->mom_role[0];
                 ctl->mom_role[0] = ctl->mom_role[1];
                 ctl->mom_role[1] = m0;
+                const bool write_out = a.persist && !ctl->c_zero;
+                if (write_out) {
+                    ctl->mu_base = mat_to;
+                    ctl->a_def = 1.0;
+                    ctl->c_zero = 1;
+                }
+                ctl->run_mat = write_out ? 1 : 0;
+                ctl->tau_hot = 1;
                 decide_set_phases(a, ctl);
+                if (write_out) {
+                    PhasePtrs &sp = ctl->phase[VILMA_PHASE_SUMS];
+                    sp.mu_in = a.bases.mu[mat_from];
+                    sp.mu_mat = a.bases.mu[mat_to];
+                    sp.c_pend = a.bases.c[mat_c];
+                    sp.a_pend = mat_a;
+                    sp.lse_ref = a.bases.lse[mat_lse];
+                    for (int p = 0; p < VILMA_MAX_P; ++p) sp.tau[p] = tau_old[p];
+                }
                 ctl->run_eval2 = 1;
                 ctl->eval_pending = 2;
                 rep.outcome = VILMA_OUT_TAU_UPDATED;
@@ -141,7 +168,7 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                 decide_set_phases(a, ctl);
             }
             rep.end_L0 = ctl->L0; rep.end_running = r; rep.end_snap_cur = ctl->snap_cur;
-            rep.end_a_def = ctl->a_def; rep.end_c_zero = ctl->c_zero;
+            rep.end_a_def = ctl->a_def; rep.end_c_zero = ctl->c_zero; rep.end_mu_base = ctl->mu_base;
             for (int p = 0; p < VILMA_MAX_P; ++p) rep.end_tau[p] = ctl->tau[p];
             for (int q = 0; q < 3; ++q) {
                 rep.end_mu_role[q] = ctl->mu_role[q];
@@ -152,7 +179,11 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
             if (a.check_convergence && results[a.o_dsum] == 0.0) dead = true;
         }
     }
-    if (a.mode == VILMA_DECIDE_EVAL && rep.outcome != VILMA_OUT_TAU_UPDATED) ctl->run_eval2 = 0;
+    if (a.mode == VILMA_DECIDE_EVAL && rep.outcome != VILMA_OUT_TAU_UPDATED) {
+        ctl->run_eval2 = 0;
+        ctl->run_mat = 0;
+        if (rep.consumed == 1) ctl->tau_hot = 0;        // this sweep's evaluation left tau alone
+    }
     if (a.mode == VILMA_DECIDE_TRIAL && !dead && a.debug_kill_deferred > 0 && !ctl->c_zero) {
         ctl->dbg_deferred += 1;
         if (ctl->dbg_deferred == a.debug_kill_deferred) dead = true;
@@ -160,8 +191,10 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
     // ---- (2) the line search on the trial's candidates
     if (a.mode == VILMA_DECIDE_TRIAL && !dead) {
         ctl->run_eval2 = 0;
+        ctl->run_mat = 0;
         ctl->run_sums = 0;
         int32_t lazy_uc = 0, lazy_ua = 0, lazy_macc = 0;
+        int32_t store_to = -1, store_from = 0;          // (persistent lazy state, tau_hot: see below)
         double lazy_a = 1.0;
         bool lazy_materialise = false;
         rep.orig = ctl->cur_obj;
@@ -225,6 +258,16 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                     ctl->c_zero = 0;
                     if (choice == 1) { ctl->mu_role[0] = ua; ctl->mu_role[1] = uc; ctl->mu_role[2] = ub; }
                     else { ctl->mu_role[0] = ub; ctl->mu_role[1] = ua; ctl->mu_role[2] = uc; }
+                    if (ends && a.scale_se && ctl->tau_hot) {
+                        // tau moved in the last sweep and will probably move in this one: the sums pass
+                        // behind this decision writes the state out (into the vi_mu buffer next to the
+                        // stored one), so that the update finds an array
+                        store_from = ctl->mu_base;
+                        store_to = (ctl->mu_base + 1) % 3;
+                        ctl->mu_base = store_to;
+                        ctl->a_def = 1.0;
+                        ctl->c_zero = 1;
+                    }
                 } else if (a.lazy && !ends) {
                     ctl->a_def = a_acc;
                     ctl->c_zero = 0;
@@ -273,8 +316,9 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                     sp.lse_ref = a.bases.lse[lazy_macc];
                     if (a.persist) {
                         // ... and writes nothing: the pass only forms the sums of the accepted state
-                        sp.mu_in = a.bases.mu[ctl->mu_base];
-                        sp.mu_mat = nullptr;
+                        // (unless tau is on the move, see above)
+                        sp.mu_in = a.bases.mu[store_to >= 0 ? store_from : ctl->mu_base];
+                        sp.mu_mat = store_to >= 0 ? a.bases.mu[store_to] : nullptr;
                         sp.c_pend = a.bases.c[ctl->mu_role[0]];
                     }
                 }
@@ -287,6 +331,7 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
         ctl->alive = 0;
         ctl->run_eval = 0;
         ctl->run_eval2 = 0;
+        ctl->run_mat = 0;
         ctl->run_sums = 0;
         rep.outcome = VILMA_OUT_DEAD;
         rep.mstep = 0;
@@ -316,4 +361,6 @@ static __host__ __device__ inline void decide_snapshot_scalars(const SweepDecide
     }
     for (int p = 0; p < VILMA_MAX_P; ++p) { x[SNAP_TAU + p] = ctl->tau[p]; x[SNAP_HRL + p] = ctl->hrl[p]; }
     x[SNAP_A_DEF] = ctl->a_def; x[SNAP_C_ZERO] = (double)ctl->c_zero;
+    x[SNAP_MU_BASE] = (double)ctl->mu_base; x[SNAP_TAU_HOT] = (double)ctl->tau_hot;
+    x[SNAP_RUN_MAT] = (double)ctl->run_mat;
 }

@@ -189,6 +189,12 @@ struct SweepCtl {
     // trials do.  Whoever needs the state as an array (a hand-back to the host, a drain, the end of the
     // run) writes it out once (sweep.hip: persist_writeback).
     int32_t mu_base;
+    // --learn-scaling under a persistent lazy state: a tau update needs the state as an array (written
+    // with the old tau).  tau_hot: the last sweep's EVAL decision moved tau -- the next sweep then ends
+    // with the storing form of the sums pass (as without persistence: a tau that moves usually moves
+    // again, and the state is in memory when it does); run_mat: the write-out pass queued behind the
+    // last EVAL decision runs (tau moved under a state still in (a, c) form)
+    int32_t tau_hot, run_mat;
     int32_t dbg_deferred;       // (tests) TRIAL decisions that found the state in that form so far
     PhasePtrs phase[3];
 };
@@ -441,6 +447,7 @@ enum {
     SNAP_FA, SNAP_FB, SNAP_EVAL_OBJ, SNAP_CONSUMED, SNAP_SWEEP_END, SNAP_SWEEP_CHANGE,
     SNAP_L_TRIED, SNAP_SNAP_CUR, SNAP_RUN_EVAL, SNAP_RUN_EVAL2, SNAP_EVAL_PENDING, SNAP_RUN_SUMS,
     SNAP_MU_ROLE = 26, SNAP_MOM_ROLE = 29, SNAP_TAU = 32, SNAP_HRL = 40, SNAP_A_DEF = 48, SNAP_C_ZERO = 49,
+    SNAP_MU_BASE = 50, SNAP_TAU_HOT = 51, SNAP_RUN_MAT = 52,
     SNAP_SERIAL = VILMA_SNAP_EXTRA - 1
 };
 #define VILMA_DECIDE_TRIAL 0    // behind a beta trial (and the evaluation in front of it, if one ran)

@@ -151,7 +151,7 @@ struct SweepState {
     // the state at the end of the last sweep reported from the device (what a caller who breaks
     // the LOOKAHEAD promise gets back): roles, tau, snapshot buffer
     struct Reported { int32_t mu_role[3], mom_role[3], snap_cur; double tau[VILMA_MAX_P]; bool valid = false;
-                      double a_def = 1.0; int32_t c_zero = 1; } rep_end;     // (a_def, c_zero: persistent lazy state)
+                      double a_def = 1.0; int32_t c_zero = 1, mu_base = 0; } rep_end;   // (a_def, c_zero, mu_base: persistent lazy state)
     // statistics of decisions looked at in one call that belong to the next sweep
     int carry_trials = 0, carry_evals = 0, carry_products = 0;
     // the host's line search resumes a sweep the device began (see Resume)
@@ -538,12 +538,14 @@ bool lazy_trials(const vilma_ctx *c, const SweepState *s) {
 // ... and then nothing needs vi_mu as an array while the sweeps stay on the device: the state lives
 // on as (stored vi_mu, a, c) from sweep to sweep (SweepCtl::mu_base), the sums pass stops storing
 // (at M = 582 it wrote 9.8 GB per sweep) and the evaluation behind the M-step derives its state like
-// the trials.  Not with --learn-scaling (a tau update changes Sig_k under a state that must stay
-// put) nor beyond four cohorts (the lazy evaluation is built for P <= 4).
+// the trials.  With --learn-scaling a tau update changes Sig_k under a state that must stay put: the
+// EVAL decision that takes it has the state written out with the old tau (a pass queued behind it,
+// beside the re-evaluation) and goes on from that array.  Not beyond four cohorts (the lazy
+// evaluation is built for P <= 4).
 bool lazy_persist(const vilma_ctx *c, const SweepState *s) {
     const char *e = std::getenv("VILMA_PIPE_PERSIST");      // =0: write vi_mu out at the end of every sweep (A/B)
     if (e && e[0] == '0') return false;
-    return lazy_trials(c, s) && !s->scale_se && c->P <= 4;
+    return lazy_trials(c, s) && c->P <= 4;
 }
 // A persistent lazy state (k.c_zero == 0: a_def (vi_mu of buffer mu_base) + Sig c, c in buffer c_buf)
 // written out for whoever needs vi_mu as an array; the host-side vi_mu roles then name the buffer
@@ -679,6 +681,13 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
         if (s->comm_kind) rc = comm_allreduce(c, s, st, s->results + s->o_dsum, s->o_tot + s->nt - s->o_dsum, 0);
         if (!rc) rc = queue_decision(c, s, st, VILMA_DECIDE_EVAL, false, false, tag);
         c->prof_tag = 4 * tag + 2;
+        if (!rc && c->lazy_persist) {
+            // a tau update under a persistent lazy state: the state written out with the old tau (the
+            // sums that come with the pass land in candidate B's slot, which lazy trials leave unused)
+            set_launch_predicate(&c->ctl->run_mat);
+            rc = queue_sums_phase(c, st, s->results + s->o_sb, /*writes_state=*/true);
+            set_launch_predicate(nullptr);
+        }
         if (!rc) {
             set_launch_predicate(&c->ctl->run_eval2);
             rc = queue_eval_phase(c, st, s->results + s->o_tot, s->pipe_diff ? s->results + s->o_dsum : nullptr,
@@ -744,7 +753,7 @@ int pipeline_arm(vilma_ctx *c, SweepState *s, hipStream_t st, const double *L, d
     for (int q = 0; q < 3; ++q) { s->rep_end.mu_role[q] = k.mu_role[q]; s->rep_end.mom_role[q] = k.mom_role[q]; }
     s->rep_end.snap_cur = k.snap_cur;
     for (int p = 0; p < VILMA_MAX_P; ++p) s->rep_end.tau[p] = k.tau[p];
-    s->rep_end.a_def = 1.0; s->rep_end.c_zero = 1;
+    s->rep_end.a_def = 1.0; s->rep_end.c_zero = 1; s->rep_end.mu_base = k.mu_base;
     return 0;
 }
 
@@ -797,6 +806,9 @@ int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const DecideR
     s->groups_out = 0;
     const SweepCtl &k = s->mirror;
     c->mu_cur = k.mu_role[0]; c->mu_ta = k.mu_role[1]; c->mu_tb = k.mu_role[2];
+    if (q.args.persist) {       // (the vi_mu roles name c buffers; the stored array is in mu_base)
+        c->mu_cur = k.mu_base; c->mu_ta = (k.mu_base + 1) % 3; c->mu_tb = (k.mu_base + 2) % 3;
+    }
     c->mom_cur = k.mom_role[1]; c->mom_ta = k.mom_role[0]; c->mom_tb = k.mom_role[2];
     c->snap_cur = k.snap_cur;
     for (int p = 0; p < c->P; ++p) c->tau[p] = k.tau[p];
@@ -907,14 +919,16 @@ int pipeline_rollback(vilma_ctx *c, SweepState *s, hipStream_t st) {
     s->resume = SweepState::Resume();
     s->carry_trials = s->carry_evals = s->carry_products = 0;
     if (!s->rep_end.valid) return fail(c, "internal: nothing to roll back to");
-    const int cur = s->rep_end.mu_role[0];
+    // (a persistent lazy state: the vi_mu roles name c buffers, the stored array is in mu_base)
+    const bool persisted = lazy_persist(c, s);
+    const int cur = persisted ? s->rep_end.mu_base : s->rep_end.mu_role[0];
     c->mu_cur = cur; c->mu_ta = (cur + 1) % 3; c->mu_tb = (cur + 2) % 3;
     if (!s->rep_end.c_zero) {
         // the reported state is a persistent lazy one: its c is still in its buffer (role 0 of the
         // reported roles -- one trial beyond writes the other two), its vi_mu is written out now
         // (the log-normaliser handed over only shifts the sums that come with the pass: not used)
-        if (persist_writeback(c, s, st, s->mirror.mu_base, cur, s->rep_end.mom_role[1], s->rep_end.a_def,
-                              s->rep_end.tau)) return 1;
+        if (persist_writeback(c, s, st, s->rep_end.mu_base, s->rep_end.mu_role[0], s->rep_end.mom_role[1],
+                              s->rep_end.a_def, s->rep_end.tau)) return 1;
     }
     c->mom_cur = 0; c->mom_ta = 1; c->mom_tb = 2;
     c->snap_cur = s->rep_end.snap_cur;
@@ -1001,7 +1015,7 @@ int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, doubl
             for (int t = 0; t < 3; ++t) { s->rep_end.mu_role[t] = rep.end_mu_role[t]; s->rep_end.mom_role[t] = rep.end_mom_role[t]; }
             s->rep_end.snap_cur = rep.end_snap_cur;
             for (int p = 0; p < VILMA_MAX_P; ++p) s->rep_end.tau[p] = rep.end_tau[p];
-            s->rep_end.a_def = rep.end_a_def; s->rep_end.c_zero = rep.end_c_zero;
+            s->rep_end.a_def = rep.end_a_def; s->rep_end.c_zero = rep.end_c_zero; s->rep_end.mu_base = rep.end_mu_base;
             s->rep_end.valid = true;
         }
         if (q.args.mode == VILMA_DECIDE_TRIAL && rep.L_tried != 0.0) {
@@ -1054,6 +1068,9 @@ int pipeline_sweep(vilma_ctx *c, SweepState *s, hipStream_t st, double *L, doubl
         // device's (the sweep's last evaluation is accepted unconditionally)
         const SweepCtl &k = s->mirror;
         c->mu_cur = k.mu_role[0]; c->mu_ta = k.mu_role[1]; c->mu_tb = k.mu_role[2];
+        if (lazy_persist(c, s)) {
+            c->mu_cur = k.mu_base; c->mu_ta = (k.mu_base + 1) % 3; c->mu_tb = (k.mu_base + 2) % 3;
+        }
         if (!k.c_zero) {
             // (a persistent lazy state: the run ends here, its vi_mu is written out)
             HIPCHK(c, hipStreamSynchronize(st));
