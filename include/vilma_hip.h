@@ -397,11 +397,12 @@ int vilma_sweep_drain(vilma_ctx *ctx);
  * with HIP events on their stream (a pair costs a few microseconds of stream time, so small
  * shards sample).  vilma_prof_read synchronises the device and returns, per kernel kind, the accumulated kernel
  * milliseconds and number of bracketed launches since the last reset (arrays of VILMA_PROF_KINDS). */
-#define VILMA_PROF_LD_SYM 0      /* ld_sym_kernel: symmetric dense blocks, lower triangle read once */
+#define VILMA_PROF_LD_SYM 0      /* the symmetric dense product's kernel (ld_tile_kernel; ld_sym_kernel with
+                                  * VILMA_LD_TILE=0): dense blocks, lower triangle read once */
 #define VILMA_PROF_LD_EIG 1      /* ld_eig_fused_kernel: one product of the eigen-form blocks (the fused
                                   * launches incl. the 512-thread one for 3 073 .. 6 144 SNPs, the
                                   * two-pass kernels of taller blocks, combine) */
-#define VILMA_PROF_LD_SYM2 2     /* ld_sym_kernel with two right-hand sides (vilma_trial_beta2): one pass
+#define VILMA_PROF_LD_SYM2 2     /* the same kernel with two right-hand sides (vilma_trial_beta2): one pass
                                   * over the store, two products */
 #define VILMA_PROF_SNP_EVAL 3    /* snp_pass_kernel of a plain evaluation */
 #define VILMA_PROF_SNP_TRIAL 4   /* ... of a one-step beta trial */
