@@ -1,10 +1,14 @@
 // Hand-written gfx950 (CDNA4, wave64) kernels for the `vilma fit` hot path.
 //
-//   ld_sym_kernel      block-diagonal LD product on dense symmetric blocks: streams only the
+//   ld_tile_kernel     block-diagonal LD product on dense symmetric blocks: streams only the
 //                      lower triangle (128-column slab panels), forming column sums and row sums
-//                      of each panel in one pass; ld_sym_combine_kernel adds the partials in a
-//                      fixed order -- replaces BlockDiagonalMatrix.dot (reference
+//                      in one pass; one workgroup takes the rows of up to four neighbouring slabs,
+//                      merges their partial sums in LDS and stores once (a block that fits one
+//                      item writes y itself); ld_tile_combine_kernel adds the partials of larger
+//                      blocks in a fixed order -- replaces BlockDiagonalMatrix.dot (reference
 //                      matrix_structures.py:389-408).  HBM-streaming, 16-byte coalesced loads.
+//                      ld_sym_kernel + ld_sym_combine_kernel: rounds 1 - 4's form of the same
+//                      product, one workgroup per slab chunk (VILMA_LD_TILE=0: the A/B baseline).
 //   ld_eig_fused_kernel  eigen-form blocks, y = U (s * (U^T x)) with U read once: a slab of columns
 //                      of the column-major U stays in registers between its two uses --
 //                      LowRankMatrix.dot (matrix_structures.py:148-152); ld_eig_wave_kernel
@@ -18,8 +22,9 @@
 //                      numerics.py:11-146, 179-213 and variational_inference.py:762-823, 873-885
 //                      for one or two candidate points.
 //   delta_kernel       responsibilities of a state reduced per annotation (numerics.py:118-129)
-//                      or written out; with MAT the accepted candidate of a lazy trial re-derived
-//                      and stored on the way.  mstep_kernel: the M-step table from those sums.
+//                      or written out; with MAT the state lazy trials reached, a (stored vi_mu) +
+//                      Sig c, derived on the way (and stored, when somebody needs the array).
+//                      mstep_kernel: the M-step table from those sums.
 //   sweep_decide_kernel  the decisions of the sweep loop on the device (decide.h).
 //   finalize / reduce / mean_diff   deterministic fixed-order reductions of per-workgroup
 //                      partials and the convergence statistics.  No atomics anywhere.
