@@ -64,10 +64,10 @@ def main():
             ok &= np.array_equal(dev[1], host[1]) and np.array_equal(dev[2], host[2]) and dev[3] == host[3]
             handed += dev[5]
             if not ok:
-                # Mixtures beyond the on-chip stash (M >= 70 here, or more than four cohorts) run LAZY
-                # trials on the device: the state is carried as (stored vi_mu, a, c) -- within a beta
-                # loop (round 5) and, without --learn-scaling and up to four cohorts, from sweep to sweep
-                # -- while the host's line search stores and re-blends rounded arrays.  The same
+                # Mixtures beyond the on-chip stash (M >= 70 here, or more than four cohorts) and, late in
+                # round 5, every fit without --learn-scaling run LAZY trials on the device: the state is
+                # carried as (stored vi_mu, a, c) -- within a beta loop and, up to four cohorts, from sweep
+                # to sweep -- while the host's line search stores and re-blends rounded arrays.  The same
                 # numbers to rounding: every decision equal (L to the bit, the same trials), values close.
                 near = dev[3] == host[3]
                 for d, h in zip(dev[0], host[0]):
@@ -76,7 +76,7 @@ def main():
                     near &= bool(np.allclose(d[3], h[3], rtol=1e-10, atol=0))
                 near &= bool(np.allclose(dev[1], host[1], rtol=1e-8, atol=1e-12))
                 near &= bool(np.allclose(dev[2], host[2], rtol=1e-8, atol=1e-300))
-                if near and (M >= 70 or P > 4):
+                if near and (M >= 70 or P > 4 or not scale_se):
                     rounding += 1
                     ok = True
                     if seed % 10 == 1:

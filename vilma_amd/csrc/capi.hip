@@ -532,7 +532,9 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     // a beta trial also leaves the per-tile responsibility sums of its candidates (vilma_trial_sums)
     const int ns = two ? 2 : 1;
     a.no_store = (queued && (blend ? c->lazy_trial : c->lazy_persist)) ? 1 : 0;
-    const bool stash = blend && !a.no_store && c->sum_partials != nullptr && snp_pass_can_stash(c->M, c->P, ns);
+    // (lazy trials beyond the stash have none; lazy trials of a mixture that fits keep it: lazy_stash)
+    const bool stash = blend && (!a.no_store || c->lazy_stash) && c->sum_partials != nullptr &&
+                       snp_pass_can_stash(c->M, c->P, ns);
     if (stash) a.sum_partials = c->sum_partials;
     if (sums_a_dev && !stash) return fail(c, "this trial cannot deliver the responsibility sums");
     if (!queued) c->tile_sums_ns = stash ? ns : 0;

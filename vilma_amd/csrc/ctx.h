@@ -167,6 +167,7 @@ struct vilma_ctx {
     bool poison = false;            // VILMA_DEBUG_POISON=1: NaN into what a trial is about to write
     bool lazy_trial = false;        // the trials being queued store no vi_mu (set by sweep.hip)
     bool lazy_persist = false;      // ... and nothing else does: the evaluations being queued derive their state too
+    bool lazy_stash = false;        // ... and the lazy trials being queued keep the on-chip stash (the mixture fits it)
     double *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;
     std::vector<int32_t> dot_start;     // first y.z partial slot of each cohort (+ end)

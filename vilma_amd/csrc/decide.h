@@ -258,7 +258,7 @@ static __host__ __device__ inline void decide_core(const SweepDecideArgs &a, Swe
                     ctl->c_zero = 0;
                     if (choice == 1) { ctl->mu_role[0] = ua; ctl->mu_role[1] = uc; ctl->mu_role[2] = ub; }
                     else { ctl->mu_role[0] = ub; ctl->mu_role[1] = ua; ctl->mu_role[2] = uc; }
-                    if (ends && a.scale_se && ctl->tau_hot) {
+                    if (ends && a.scale_se && ctl->tau_hot && !a.mstep_inside) {
                         // tau moved in the last sweep and will probably move in this one: the sums pass
                         // behind this decision writes the state out (into the vi_mu buffer next to the
                         // stored one), so that the update finds an array

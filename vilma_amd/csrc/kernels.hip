@@ -2026,8 +2026,10 @@ template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH, bool NOSTORE = 
 __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WAVES(P)) void snp_pass_kernel(const SnpKernelArgs a) {
     static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
     // NOSTORE with BLEND: a lazy trial; without: a plain evaluation of a lazy state (both derive
-    // mu_k = a (stored vi_mu) + Sig_k c component by component and store no vi_mu)
-    static_assert(!NOSTORE || !STASH, "lazy passes have no stash");
+    // mu_k = a (stored vi_mu) + Sig_k c component by component and store no vi_mu).  A lazy trial
+    // may keep the stash (mixtures that fit it): its candidates' responsibility sums then come out
+    // of this pass as a storing trial's do.
+    static_assert(!NOSTORE || !STASH || BLEND, "only trials stash");
     constexpr int NT = 2 * P + 2;
     constexpr int NTP = (NT + 7) / 8 * 8;
     constexpr int NACC = 2 + 2 * P;
@@ -2606,14 +2608,22 @@ static void launch_snp_pass_s(const SnpKernelArgs &a, bool stash, hipStream_t s)
     const size_t lds = snp_pass_lds_bytes(a.M, P, NS, stash);
     if constexpr (P <= 4) {
         if (stash) {
-            auto kern = snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true>;
-            static bool raised = false;         // more than 64 KB of dynamic LDS needs the attribute
-            if (!raised) {
-                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          96 * 1024);
-                raised = true;
+            auto launch = [&](auto kern, bool &raised) {
+                if (!raised) {                  // more than 64 KB of dynamic LDS needs the attribute
+                    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              96 * 1024);
+                    raised = true;
+                }
+                hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+            };
+            static bool raised = false, raised_lazy = false;
+            if constexpr (BLEND) {
+                if (a.no_store) {       // a lazy trial that keeps the stash
+                    launch(snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true, true>, raised_lazy);
+                    return;
+                }
             }
-            hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+            launch(snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true>, raised);
             return;
         }
     }
@@ -2660,7 +2670,7 @@ void launch_snp_pass(const SnpKernelArgs &args, bool blend, int ns, hipStream_t 
     SnpKernelArgs a = args;
     a.pred = g_pred;
     a.pp = g_phase;
-    const bool stash = !a.no_store && a.sum_partials != nullptr && snp_pass_can_stash(a.M, a.P, ns);
+    const bool stash = a.sum_partials != nullptr && snp_pass_can_stash(a.M, a.P, ns);
     switch (a.P) {
         case 1: launch_snp_pass_p<1>(a, blend, ns, stash, s); break;
         case 2: launch_snp_pass_p<2>(a, blend, ns, stash, s); break;

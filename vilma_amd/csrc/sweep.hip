@@ -530,10 +530,22 @@ bool stash_sums(const vilma_ctx *c, const SweepState *s) {
 // Without the stash the candidates' responsibility sums need a pass over the accepted candidate
 // anyway; the trials then need not store their candidates' vi_mu at all ("lazy": that pass
 // re-derives the accepted one and stores it) -- at M = 582 a trial writes 19.6 GB less.
+// Round 5, late: mixtures that FIT the stash run lazy trials too when the lazy state persists (below) --
+// the trial keeps its stash (the TRIAL decision still does the M-step itself) and stores two [P][N]
+// vectors instead of two vi_mu arrays (C3: 1.35 GB per trial; the trial pass 0.37 -> 0.22 ms).  Not
+// with --learn-scaling: a tau update then needs the write-out pass every time (there is no sums pass
+// to store the state while tau keeps moving), which costs more than the trials save.
+bool lazy_with_stash(const vilma_ctx *c, const SweepState *s) {
+    const char *e = std::getenv("VILMA_STASH_LAZY");        // =0: trials of a mixture that fits the stash store (A/B)
+    if (e && e[0] == '0') return false;
+    const char *pe = std::getenv("VILMA_PIPE_PERSIST");
+    if (pe && pe[0] == '0') return false;
+    return stash_sums(c, s) && !s->scale_se && c->P <= 4;
+}
 bool lazy_trials(const vilma_ctx *c, const SweepState *s) {
     const char *e = std::getenv("VILMA_PIPE_LAZY");         // =0: the trials store both candidates (A/B)
     if (e && e[0] == '0') return false;
-    return !stash_sums(c, s);
+    return !stash_sums(c, s) || lazy_with_stash(c, s);
 }
 // ... and then nothing needs vi_mu as an array while the sweeps stay on the device: the state lives
 // on as (stored vi_mu, a, c) from sweep to sweep (SweepCtl::mu_base), the sums pass stops storing
@@ -644,6 +656,7 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     c->prof_tag = 4 * tag;
     c->lazy_trial = lazy_trials(c, s);
     c->lazy_persist = lazy_persist(c, s);
+    c->lazy_stash = c->lazy_trial && stash;
     set_launch_predicate(&c->ctl->alive);
     if (c->poison) launch_poison(s->results + s->o_ta, s->o_sb + s->am - s->o_ta, 0, st);
     rc = queue_trial_phase(c, st, two, s->results + s->o_ta, s->results + s->o_tb,
@@ -698,6 +711,7 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     c->prof_tag = 0;
     c->lazy_trial = false;
     c->lazy_persist = false;
+    c->lazy_stash = false;
     if (!rc) s->groups_out += 1;
     s->pipe_stream = st;
     return rc;
