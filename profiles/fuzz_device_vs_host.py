@@ -65,7 +65,7 @@ def main():
             handed += dev[5]
             if not ok:
                 # Mixtures beyond the on-chip stash (M >= 70 here, or more than four cohorts) and, late in
-                # round 5, every fit without --learn-scaling run LAZY trials on the device: the state is
+                # round 5, every other fit too unless VILMA_STASH_LAZY=0 run LAZY trials on the device: the state is
                 # carried as (stored vi_mu, a, c) -- within a beta loop and, up to four cohorts, from sweep
                 # to sweep -- while the host's line search stores and re-blends rounded arrays.  The same
                 # numbers to rounding: every decision equal (L to the bit, the same trials), values close.
@@ -76,7 +76,7 @@ def main():
                     near &= bool(np.allclose(d[3], h[3], rtol=1e-10, atol=0))
                 near &= bool(np.allclose(dev[1], host[1], rtol=1e-8, atol=1e-12))
                 near &= bool(np.allclose(dev[2], host[2], rtol=1e-8, atol=1e-300))
-                if near and (M >= 70 or P > 4 or not scale_se):
+                if near and (M >= 70 or P > 4 or os.environ.get('VILMA_STASH_LAZY') != '0'):
                     rounding += 1
                     ok = True
                     if seed % 10 == 1:

@@ -203,12 +203,10 @@ def test_device_resident_sweeps_equal_host_decided_sweeps(shape, stored, monkeyp
           'p3_scale_se': lambda: _problem(rng, 3, [[50, 40], [45, 45], [30, 30, 30]], N=100, M=6)}[shape]()
     scale_se = shape.endswith('scale_se')
     # stored: trials of mixtures that fit the stash store their candidates (VILMA_STASH_LAZY=0: the form
-    # of rounds 3 - 4, and what fits with --learn-scaling take by default) -- device-decided and
+    # of rounds 3 - 4) -- device-decided and
     # host-decided sweeps are then equal to the BIT; by default they run lazy trials that keep the stash
     # (late round 5) and are equal to rounding, every decision the same
     monkeypatch.setenv('VILMA_STASH_LAZY', '0' if stored else '1')
-    if not stored and scale_se:
-        pytest.skip('fits with --learn-scaling store their candidates either way')
 
     def run(lookahead):
         monkeypatch.setenv('VILMA_LOOKAHEAD', '1' if lookahead else '0')
@@ -228,7 +226,7 @@ def test_device_resident_sweeps_equal_host_decided_sweeps(shape, stored, monkeyp
     dev = run(True)
     if scale_se:
         assert any(t[3] != (1.0,) * pr['P'] for t in host[0])      # tau did get updated
-    lazy = shape in ('p2_m130', 'p5', 'p1_scale_se') or (not stored and not scale_se)
+    lazy = shape in ('p2_m130', 'p5', 'p1_scale_se') or not stored
     if lazy:
         # Mixtures beyond the stash: the queued sweeps' trials store no vi_mu and carry the beta loop's
         # state as mu_k = a mu_k^stored + Sig_k c (round 5), written out once when the loop ends; the

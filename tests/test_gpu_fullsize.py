@@ -99,16 +99,19 @@ def test_c3_fit_invariants():
     eng.close()
 
 
-def test_c3_learn_scaling_acts_at_full_size_device_decided_equals_host_decided():
+def test_c3_learn_scaling_acts_at_full_size_device_decided_equals_host_decided(monkeypatch):
     """--learn-scaling at the headline size, run until it ACTS: from the standard start the full
     C3 problem first gains less than EM_TOL in a sweep after ~158 sweeps (profiles/
     r05c_learn_scaling_where_it_acts.txt); from then on the EVAL decision updates tau
     (_update_error_scaling, reference variational_inference.py:472-486) and re-evaluates.  200
-    sweeps decided on the device against 200 decided by the host: ELBO, L and tau equal to the
-    bit in every sweep; tau moves; every sweep passes the reference's acceptance bound; the cached
-    objective equals a fresh evaluation at the final tau."""
+    sweeps decided on the device against 200 decided by the host: with trials that store their
+    candidates (VILMA_STASH_LAZY=0) ELBO, L and tau equal to the bit in every sweep; with the default
+    lazy trials (the state carried as (stored vi_mu, a, c), written out with the old tau whenever tau
+    moves) every L equal, tau and ELBO to rounding; tau moves; every sweep passes the reference's
+    acceptance bound; the cached objective equals a fresh evaluation at the final tau."""
     runs = []
-    for ahead in (True, False):
+    for ahead, stored in ((True, True), (False, True), (True, False)):
+        monkeypatch.setenv('VILMA_STASH_LAZY', '0' if stored else '1')
         sh, eng, drv = _setup('C3', scale_se=True)
         drv.initialize_from(sh.fake_mu)
         state, elbo_prev, rows = None, drv._objective, []
@@ -128,6 +131,10 @@ def test_c3_learn_scaling_acts_at_full_size_device_decided_equals_host_decided()
         runs.append(rows)
         eng.close()
     assert runs[0] == runs[1]
+    for (e, L, tau), (e0, L0, tau0) in zip(runs[2], runs[1]):
+        assert L == L0
+        assert abs(e - e0) <= 1e-11 * abs(e0)
+        np.testing.assert_allclose(tau, tau0, rtol=1e-10)
 
 
 def test_c3k12_default_mixture_fit_invariants():

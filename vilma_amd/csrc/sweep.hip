@@ -530,17 +530,18 @@ bool stash_sums(const vilma_ctx *c, const SweepState *s) {
 // Without the stash the candidates' responsibility sums need a pass over the accepted candidate
 // anyway; the trials then need not store their candidates' vi_mu at all ("lazy": that pass
 // re-derives the accepted one and stores it) -- at M = 582 a trial writes 19.6 GB less.
-// Round 5, late: mixtures that FIT the stash run lazy trials too when the lazy state persists (below) --
+// Round 5, late: mixtures that FIT the stash run lazy trials too (the lazy state persists: below) --
 // the trial keeps its stash (the TRIAL decision still does the M-step itself) and stores two [P][N]
-// vectors instead of two vi_mu arrays (C3: 1.35 GB per trial; the trial pass 0.37 -> 0.22 ms).  Not
-// with --learn-scaling: a tau update then needs the write-out pass every time (there is no sums pass
-// to store the state while tau keeps moving), which costs more than the trials save.
+// vectors instead of two vi_mu arrays (C3: 1.35 GB per trial; the trial pass 0.37 -> 0.285 ms).  With
+// --learn-scaling every tau update then needs the write-out pass (there is no sums pass that could
+// store the state while tau keeps moving: decide.h, tau_hot) -- 0.29 ms at C3, which the sweeps in
+// which tau moves earn back with their second trial (they run 3 - 16).
 bool lazy_with_stash(const vilma_ctx *c, const SweepState *s) {
     const char *e = std::getenv("VILMA_STASH_LAZY");        // =0: trials of a mixture that fits the stash store (A/B)
     if (e && e[0] == '0') return false;
     const char *pe = std::getenv("VILMA_PIPE_PERSIST");
     if (pe && pe[0] == '0') return false;
-    return stash_sums(c, s) && !s->scale_se && c->P <= 4;
+    return stash_sums(c, s) && c->P <= 4;
 }
 bool lazy_trials(const vilma_ctx *c, const SweepState *s) {
     const char *e = std::getenv("VILMA_PIPE_LAZY");         // =0: the trials store both candidates (A/B)
