@@ -349,8 +349,15 @@ typedef struct {
                                      re-evaluation -- is then decided by a kernel from a control
                                      block on the device, for every mixture size, and work beyond
                                      the state this call reports (at most ONE beta trial) may
-                                     already be on `stream` when it returns.  Results are the bits
-                                     of the same call without the flag.  The host replays every
+                                     already be on `stream` when it returns.  Every decision is
+                                     the one the same call without the flag takes (L to the bit,
+                                     the same trials); values are its bits when the trials store
+                                     their candidates (VILMA_STASH_LAZY=0 / VILMA_PIPE_LAZY=0) and
+                                     equal to rounding otherwise -- up to four cohorts the queued
+                                     sweeps keep the state as (stored vi_mu, a, c), mu_k = a mu_k
+                                     + Sig_k c, store no vi_mu array and write the state out when
+                                     somebody reads it (vilma_sweep_drain, any state read, the
+                                     last sweep of a run).  The host replays every
                                      decision with the same source and returns an error if the
                                      two differ.  Ignored with VILMA_SWEEP_VERBOSE (per-update
                                      events need the host in the loop) and with VILMA_LOOKAHEAD=0
