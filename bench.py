@@ -432,6 +432,13 @@ def main(argv=None, engine_factory=None):
     # bracketed on the same sampling tick, so launches_k / sampled products = launches of kind k
     # per LD product, and the sweep's algorithmic bytes follow from the exact product count.
     mp_bytes = 8.0 * shard.N * M * P
+    # the form the queued sweeps held the state in (vilma_prof_state_form): 2 = mu_k = Sig_k c, what a fit
+    # started by _initialize is and stays -- the lazy passes then read NO vi_mu array (their loads hit
+    # one L2-resident tile): they are priced on the [P][N] vectors they do move and are ALU-bound
+    state_form = engine.state_form() if hasattr(engine, 'state_form') else 0
+    vec = 8.0 * shard.N * P
+    lazy_bytes = {'snp_pass_eval': 11 * vec, 'snp_pass_trial_lazy': 12 * vec, 'snp_pass_trial2_lazy': 17 * vec,
+                  'sums_pass': 2 * vec} if state_form == 2 else {}
     kinds = [(sym_name + '<1>', 'ld_sym_kernel', alg_dense),
              (sym_name + '<2>', 'ld_sym_kernel_two_rhs', alg_dense),
              ('ld_eig_fused_kernel', 'ld_eig_fused_kernel', alg_eig),
@@ -450,9 +457,14 @@ def main(argv=None, engine_factory=None):
         ms_k, n_k = prof.get(key, (0.0, 0))
         if not n_k:
             continue
+        base_free = key in lazy_bytes
+        if base_free:
+            nbytes = lazy_bytes[key]
         gbps = nbytes / (ms_k / n_k * 1e-3) / 1e9
         kernel_rows.append({'name': name, 'algorithmic_bytes': nbytes, 'avg_ms': ms_k / n_k,
                             'launches': int(n_k), 'GBps': gbps, 'frac': gbps / HBM_PEAK_GBS})
+        if base_free:
+            kernel_rows[-1]['bound'] = 'alu (the state is mu_k = Sig_k c: no vi_mu array is read; bytes = the [P][N] vectors moved)'
     sampled_products = sum(prof[k][1] for k in ('ld_sym_kernel', 'ld_sym_kernel_two_rhs')) or \
         prof['ld_eig_fused_kernel'][1]
     per_product = (sum(r['algorithmic_bytes'] * r['launches'] for r in kernel_rows) / sampled_products
@@ -499,6 +511,7 @@ def main(argv=None, engine_factory=None):
                                              '8 n^2 as full matrices; the symmetric kernel needs the lower triangle, half of it' if shard.kind == 'ar1' else '8 n r, U counted once',
                                              'WITH --learn-scaling (error_scaling updated by EM)' if args.learn_scaling else 'no --learn-scaling'),
             'sharding': 'LD blocks over %d GPU(s), contiguous runs balanced by bytes' % world,
+            'state_form': {0: 'stored vi_mu', 1: '(stored vi_mu, a, c)', 2: 'mu_k = Sig_k c (a = 0: no vi_mu array read by the sweeps)'}[state_form],
             'ld_work_items': ('%d per launch: tiles of %d rows x %d slabs of 128 columns (ld_tile_kernel)'
                               % (tile_items, tile_rows, tile_slabs)) if tile_rows > 0 else
                              ('%d per launch: one slab chunk each (ld_sym_kernel)' % tile_items),

@@ -397,6 +397,13 @@ int vilma_update_error_scaling(vilma_ctx *ctx, void *stream, double *orig_obj, d
 /* Forget work queued ahead by VILMA_SWEEP_LOOKAHEAD (the caller breaks its promise): waits for
  * it, restores the state after the last sweep reported.  A no-op otherwise. */
 int vilma_sweep_drain(vilma_ctx *ctx);
+/* The form in which the sweeps queued ahead held the state behind the last decision the host has
+ * looked at: 0 = a stored vi_mu array; 1 = (stored vi_mu, a, c), mu_k = a mu_k + Sig_k c; 2 = the same
+ * with a == 0 -- what a fit started by vilma_initialize is (the reference's _initialize builds
+ * vi_mu_k = vi_sigma_k temp_nat_mu, variational_inference.py:683-690) and stays: no per-SNP pass
+ * of such sweeps reads a vi_mu array, their memory traffic is [P][N] vectors (bench.py prices them
+ * accordingly). */
+int vilma_prof_state_form(vilma_ctx *ctx, int *form);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 

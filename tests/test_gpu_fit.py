@@ -111,9 +111,12 @@ def test_persistent_lazy_state_against_a_stored_one_and_through_drains(monkeypat
     monkeypatch.setenv('VILMA_TWO_STEP', two_step)
     n = len(g['elbo'])
 
-    def run(lookahead, persist, poke=False, n=n):
+    def run(lookahead, persist, poke=False, n=n, pure=True):
         monkeypatch.setenv('VILMA_LOOKAHEAD', '1' if lookahead else '0')
         monkeypatch.setenv('VILMA_PIPE_PERSIST', '1' if persist else '0')
+        # (the state _initialize builds is mu_k = Sig_k c: by default the persistent form starts with
+        # a = 0 and no pass reads a vi_mu array; VILMA_PURE_START=0 starts from the stored array)
+        monkeypatch.setenv('VILMA_PURE_START', '1' if pure else '0')
         vi, _ = product_vi_from_traj(g)
         np.random.seed(int(g['seed']))
         vi._initialize()
@@ -125,14 +128,20 @@ def test_persistent_lazy_state_against_a_stored_one_and_through_drains(monkeypat
                 vi.engine.drain()                       # the promise of another sweep broken
             if poke and k in (8, 9):
                 seen.append((k, vi._params()[0].copy()))    # a state read in mid-fit (twice in a row)
-        out = (trace, vi._params()[0].copy(), vi.n_trials, vi.n_stages_ahead, seen)
+        form = vi.engine.state_form()
+        out = (trace, vi._params()[0].copy(), vi.n_trials, vi.n_stages_ahead, seen, form)
         vi.engine.close()
         return out
     host = run(False, False)
     stored = run(True, False)
     kept = run(True, True)
     poked = run(True, True, poke=True)
-    for other in (stored, kept, poked):
+    based = run(True, True, pure=False)
+    # the form the queued sweeps held the state in: base-free by default (through the drain and the
+    # state reads too: a write-out re-establishes it), (stored vi_mu, a, c) without the pure start,
+    # a stored array when every sweep writes it out
+    assert kept[5] == 2 and poked[5] == 2 and based[5] == 1 and stored[5] == 0 and host[5] == 0
+    for other in (stored, kept, poked, based):
         for (e_o, L_o, r_o), (e_h, L_h, r_h) in zip(other[0], host[0]):
             assert L_o == L_h
             assert abs(e_o - e_h) <= 1e-12 * abs(e_h) and abs(r_o - r_h) <= 1e-9 * abs(r_h)

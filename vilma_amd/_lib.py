@@ -124,6 +124,7 @@ def load():
         'vilma_posterior': (C.c_int, [vp, vp, vp]),
         'vilma_sweep': (C.c_int, [vp, vp, vp, vp, vp, C.c_double, C.c_int, vp]),
         'vilma_sweep_drain': (C.c_int, [vp]),
+        'vilma_prof_state_form': (C.c_int, [vp, vp]),
         'vilma_update_beta': (C.c_int, [vp, vp, vp, C.c_double, vp, vp]),
         'vilma_update_hyper_delta': (C.c_int, [vp, vp, vp, vp]),
         'vilma_update_error_scaling': (C.c_int, [vp, vp, vp, vp]),

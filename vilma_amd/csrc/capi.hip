@@ -1141,6 +1141,7 @@ static int mu_convert(vilma_ctx *c, double *buf, double *host, bool to_device) {
 }
 
 int vilma_set_mu(vilma_ctx *c, const double *vi_mu) {
+    if (c) c->pure_c = -1;
     if (!c) return 1;
     if (vilma_sweep_drain(c)) return 1;      // nothing may be queued ahead of the state in use
     HIPCHK(c, hipDeviceSynchronize());
@@ -1288,11 +1289,14 @@ int vilma_init_state(vilma_ctx *c, void *stream, const double *fake_mu, double *
     a.fake_mu = stage; a.sld = c->sld; a.annot = c->annot;
     a.prec = c->prec; a.log_det = c->log_det;
     a.mu_out = c->mu[c->mu_cur];
+    a.c_out = c->cvec[c->mu_cur];
     a.partials = c->delta_partials;
     for (int p = 0; p < VILMA_MAX_P; ++p) a.tau.v[p] = p < c->P ? c->tau[p] : 1.0;
     launch_init_state(a, sums_dev, s);
     HIPCHK(c, hipGetLastError());
     c->have_moments = false;
+    c->pure_c = c->mu_cur;
+    for (int p = 0; p < VILMA_MAX_P; ++p) c->pure_tau[p] = a.tau.v[p];
     return 0;
 }
 
@@ -1329,6 +1333,7 @@ int vilma_accept(vilma_ctx *c, int take_mu) {
         std::swap(c->mom_cur, c->mom_ta);
         if (take_mu) std::swap(c->mu_cur, c->mu_ta);
     }
+    if (take_mu) c->pure_c = -1;
     c->have_b = false;
     c->have_moments = true;
     return 0;

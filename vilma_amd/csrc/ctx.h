@@ -165,6 +165,10 @@ struct vilma_ctx {
     double *cvec[3] = {nullptr, nullptr, nullptr};  // [P][N] beside each set of moments: the vector c of a
                                     // state lazy trials reached (PhasePtrs, kernels.h)
     bool poison = false;            // VILMA_DEBUG_POISON=1: NaN into what a trial is about to write
+    // vi_mu of role `current` equals Sig_k cvec[pure_c] for every component (what vilma_init_state leaves,
+    // at the tau of pure_tau): a queued sweep may start from the lazy form a = 0; -1: not known to
+    int pure_c = -1;
+    double pure_tau[VILMA_MAX_P] = {};
     bool lazy_trial = false;        // the trials being queued store no vi_mu (set by sweep.hip)
     bool lazy_persist = false;      // ... and nothing else does: the evaluations being queued derive their state too
     bool lazy_stash = false;        // ... and the lazy trials being queued keep the on-chip stash (the mixture fits it)

@@ -412,6 +412,9 @@ struct InitArgs {
     const int32_t *annot;
     const double *prec, *log_det;
     double *mu_out;           // [M][P][N]
+    double *c_out;            // [P][N] or nullptr: the vector c with mu_out_k = Sig_k c (the reference's
+                              // temp_nat_mu, variational_inference.py:683-690): the state _initialize
+                              // builds IS of the lazy form a = 0 (PhasePtrs)
     double *partials;         // [init_partial_rows(N)][A*M]
     TauArg tau;
 };

@@ -152,6 +152,8 @@ struct SweepState {
     // the LOOKAHEAD promise gets back): roles, tau, snapshot buffer
     struct Reported { int32_t mu_role[3], mom_role[3], snap_cur; double tau[VILMA_MAX_P]; bool valid = false;
                       double a_def = 1.0; int32_t c_zero = 1, mu_base = 0; } rep_end;   // (a_def, c_zero, mu_base: persistent lazy state)
+    int last_form = 0;      // form of the state behind the last decision looked at: 0 a stored vi_mu, 1 (stored vi_mu, a, c),
+                            // 2 the same with a == 0 (no pass reads vi_mu) -- vilma_prof_state_form
     // statistics of decisions looked at in one call that belong to the next sweep
     int carry_trials = 0, carry_evals = 0, carry_products = 0;
     // the host's line search resumes a sweep the device began (see Resume)
@@ -567,6 +569,16 @@ int persist_writeback(vilma_ctx *c, SweepState *s, hipStream_t st, int mu_base, 
                       double a_def, const double *tau) {
     const int to = (mu_base + 1) % 3;
     if (materialise_deferred(c, st, mu_base, to, c_buf, lse_buf, a_def, tau, s->results + s->o_sa)) return 1;
+    c->pure_c = -1;
+    if (a_def == 0.0) {
+        // the array just written IS Sig_k c (the pass forms 0 * stored + Sig_k c with the passes' own
+        // expressions): with c beside it the next arming starts from the base-free form again
+        if (c_buf != to)
+            HIPCHK(c, hipMemcpyAsync(c->cvec[to], c->cvec[c_buf], (size_t)c->P * c->N * sizeof(double),
+                                     hipMemcpyDeviceToDevice, st));
+        c->pure_c = to;
+        for (int p = 0; p < VILMA_MAX_P; ++p) c->pure_tau[p] = p < c->P ? tau[p] : 1.0;
+    }
     HIPCHK(c, hipStreamSynchronize(st));
     c->mu_cur = to; c->mu_ta = mu_base; c->mu_tb = (mu_base + 2) % 3;
     return 0;
@@ -747,6 +759,21 @@ int pipeline_arm(vilma_ctx *c, SweepState *s, hipStream_t st, const double *L, d
     k.a_def = 1.0;          // the host's current vi_mu is stored as it is
     k.c_zero = 1;
     k.mu_base = c->mu_cur;  // (persistent lazy state: and stays there)
+    {
+        // ... unless it is known to be Sig_k c for a vector c at hand (what vilma_init_state leaves:
+        // the reference's _initialize builds vi_mu = einsum(vi_sigma, temp_nat_mu)): the persistent
+        // lazy state then starts with a = 0 and no pass of the sweeps reads a vi_mu array at all
+        const char *e = std::getenv("VILMA_PURE_START");    // =0: start from the stored array (A/B)
+        bool pure = !(e && e[0] == '0') && lazy_persist(c, s) && c->pure_c == c->mu_cur;
+        for (int p = 0; p < c->P && pure; ++p) pure = c->pure_tau[p] == c->tau[p];
+        if (pure) {
+            k.a_def = 0.0;
+            k.c_zero = 0;
+        }
+        // (from here on the c buffers change roles on the device: what the host knows about them is
+        // void until a write-out re-establishes it, persist_writeback)
+        c->pure_c = -1;
+    }
     k.L0 = L[0];
     k.L_try = std::max(1.0, L[0] / 1.25);
     k.cur_obj = s->objective;
@@ -795,6 +822,7 @@ int consume_decision(vilma_ctx *c, SweepState *s, DecideReport *rep, const doubl
     if (q.first_of_group) s->groups_out -= 1;
     const double *snap = s->land[q.land];
     decide_core(q.args, &s->mirror, snap, *rep);
+    s->last_form = s->mirror.c_zero ? 0 : (s->mirror.a_def == 0.0 ? 2 : 1);
     double want[VILMA_SNAP_EXTRA];
     decide_snapshot_scalars(q.args, &s->mirror, *rep, want);
     const double *got = snap + s->size;
@@ -847,6 +875,7 @@ int pipeline_takeover(vilma_ctx *c, SweepState *s, hipStream_t st, const DecideR
                                  k.tau, s->results + s->o_sa)) return 1;
         HIPCHK(c, hipStreamSynchronize(st));
         c->mu_cur = k.mu_role[1]; c->mu_ta = k.mu_role[0];
+        c->pure_c = -1;
         s->mirror.a_def = 1.0;
         s->mirror.c_zero = 1;
     }
@@ -1322,6 +1351,13 @@ int vilma_debug_result_slot(vilma_ctx *c, int which, double *out, int n) {
     if (vilma_sweep_drain(c)) return 1;
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(out, s->results + (which ? s->o_tb : s->o_ta), (size_t)n * sizeof(double), hipMemcpyDefault));
+    return 0;
+}
+
+int vilma_prof_state_form(vilma_ctx *c, int *form) {
+    if (!c || !form) return 1;
+    SweepState *s = c->sw;
+    *form = s ? s->last_form : 0;
     return 0;
 }
 

@@ -492,6 +492,13 @@ class HipEngine:
     def drain(self):
         self._check(self.lib.vilma_sweep_drain(self.ctx))
 
+    def state_form(self):
+        """0: the queued sweeps held the state as a stored vi_mu; 1: as (stored vi_mu, a, c); 2: the same
+        with a == 0 (no per-SNP pass reads vi_mu)."""
+        f = C.c_int()
+        self._check(self.lib.vilma_prof_state_form(self.ctx, C.byref(f)))
+        return f.value
+
     def update_beta(self, L0, line_search_rate):
         """_update_beta from the current state; returns (L0 after backtracking, orig, new)."""
         L, o, n = C.c_double(float(L0)), C.c_double(), C.c_double()
