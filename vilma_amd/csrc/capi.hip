@@ -531,7 +531,7 @@ int evaluate(vilma_ctx *c, hipStream_t s, bool blend, double step, double *total
     a.diff = (!blend && dsum_dev && dmax_dev) ? 1 : 0;
     // a beta trial also leaves the per-tile responsibility sums of its candidates (vilma_trial_sums)
     const int ns = two ? 2 : 1;
-    a.no_store = (queued && (blend ? c->lazy_trial : c->lazy_persist)) ? 1 : 0;
+    a.no_store = (queued && (blend ? c->lazy_trial : c->lazy_persist)) ? (c->lazy_nobase ? 2 : 1) : 0;
     // (lazy trials beyond the stash have none; lazy trials of a mixture that fits keep it: lazy_stash)
     const bool stash = blend && (!a.no_store || c->lazy_stash) && c->sum_partials != nullptr &&
                        snp_pass_can_stash(c->M, c->P, ns);

@@ -172,6 +172,7 @@ struct vilma_ctx {
     bool lazy_trial = false;        // the trials being queued store no vi_mu (set by sweep.hip)
     bool lazy_persist = false;      // ... and nothing else does: the evaluations being queued derive their state too
     bool lazy_stash = false;        // ... and the lazy trials being queued keep the on-chip stash (the mixture fits it)
+    bool lazy_nobase = false;       // ... and their state has a == 0 for as long as they can run (armed base-free, no --learn-scaling)
     double *snp_partials = nullptr, *dot_partials = nullptr;
     double *delta_partials = nullptr, *diff_partials = nullptr;
     std::vector<int32_t> dot_start;     // first y.z partial slot of each cohort (+ end)

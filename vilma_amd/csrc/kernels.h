@@ -276,6 +276,8 @@ struct SnpKernelArgs {
     // no_store on a plain EVALUATION (a queued sweep with a persistent lazy state, SweepCtl::mu_base):
     // the state evaluated is a_def (stored vi_mu) + Sig c_cur (PhasePtrs), derived component by
     // component with the trials' expressions
+    // (2: ... and the host knows the state has a == 0 for as long as the pass can run: the variant
+    // without any vi_mu load, up to two cohorts)
     int32_t no_store;
     const int *pred;          // filled by the launcher (set_launch_predicate)
     const PhasePtrs *pp;      // filled by the launcher (set_launch_phase)

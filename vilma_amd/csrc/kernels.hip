@@ -2022,7 +2022,7 @@ static __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH, bool NOSTORE = false>
+template <int P, bool BLEND, bool ONE_ANNOT, int NS, bool STASH, bool NOSTORE = false, bool NOBASE = false>
 __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WAVES(P)) void snp_pass_kernel(const SnpKernelArgs a) {
     static_assert(NS == 1 || BLEND, "two candidates only make sense for a beta trial");
     // NOSTORE with BLEND: a lazy trial; without: a plain evaluation of a lazy state (both derive
@@ -2030,6 +2030,11 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
     // may keep the stash (mixtures that fit it): its candidates' responsibility sums then come out
     // of this pass as a storing trial's do.
     static_assert(!NOSTORE || !STASH || BLEND, "only trials stash");
+    // NOBASE: a lazy pass that is KNOWN (by the host, when it queues it: SnpKernelArgs::no_store == 2) to
+    // work on a state with a == 0 -- no vi_mu load is compiled in, nor the arithmetic on what it would
+    // have returned (the passes are bound by the vector ALU there).  The other lazy passes find
+    // a == 0 out at run time and point their loads at one L2-resident tile (below).
+    static_assert(!NOBASE || NOSTORE, "base-free passes are lazy passes");
     constexpr int NT = 2 * P + 2;
     constexpr int NTP = (NT + 7) / 8 * 8;
     constexpr int NACC = 2 + 2 * P;
@@ -2094,7 +2099,7 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
     // it stays (a' = (1 - s) a) -- needs no stored vi_mu at all.  Its loads are not compiled out but
     // pointed at tile 0 of the buffer (40 KB that stay in L2; 0 * finite = 0): no vi_mu byte comes
     // from HBM.
-    const bool nobase = NOSTORE && !q.c_zero && q.a_def == 0.0;          // uniform over the launch
+    const bool nobase = NOBASE || (NOSTORE && !q.c_zero && q.a_def == 0.0);   // uniform over the launch
     const int64_t mu_base = MU_BASE(nobase ? (ii & (MU_TILE - 1)) : ii, M, P, N64);
 
     // vi_mu is read in batches of KB components (KB*P independent 512-B wave loads), double
@@ -2103,6 +2108,14 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
     // (C3: 0.207 -> 0.198 ms).  A trial does not: the same move costs it 0.02 ms
     // (gpurun_out/ab23.txt of round 3; it is bound by its stores, not by latency).
     auto fetch_mu = [&](double (&dst)[KB][P], int k0) {
+        if constexpr (NOBASE) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                for (int p = 0; p < P; ++p) dst[kk][p] = 0.0;
+            (void)k0;
+            return;
+        }
 #if MU_PAIRED
         // the batch's KB P rows are KB P / 2 row pairs: 16 bytes per lane and load (k0 P is even)
         static_assert(KB % 2 == 0, "row pairs of an odd number of cohorts span two components");
@@ -2206,6 +2219,15 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
 #pragma unroll
         for (int p = 0; p < P; ++p) cc[0][p] = q.c_zero ? 0.0 : q.c_cur[p * N64 + ii];
     }
+    if (NOBASE && (q.c_zero || q.a_def != 0.0)) {
+        // queued for a state it does not find (the host's bookkeeping and the device's disagree):
+        // nothing of this pass may look like a result -- every sum it leaves is NaN, the decision
+        // behind it gives the sweep back to the host, which reports the failure
+#pragma unroll
+        for (int c = 0; c < NS; ++c)
+#pragma unroll
+            for (int p = 0; p < P; ++p) cc[c][p] = __builtin_nan("");
+    }
 
     const const_tab prec_tab = as_table(a.prec);
     const const_tab lh_tab = as_table(a.lh);          // one annotation: the row is wave-uniform
@@ -2267,8 +2289,10 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
 #pragma unroll
             for (int p = 0; p < P; ++p) {              // Lam_k mu_k: the old natural parameter
                 double t = 0.0;
+                if constexpr (!NOBASE) {
 #pragma unroll
-                for (int q = 0; q < P; ++q) t += lam[p][q] * mul[kk][q];
+                    for (int q = 0; q < P; ++q) t += lam[p][q] * mul[kk][q];
+                }
                 told[p] = t;
             }
 #pragma unroll
@@ -2276,7 +2300,8 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
                 double nat[P], mun[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    nat[p] = NOSTORE ? (ac[c] * told[p] + cc[c][p])        // Lam (ac mu + Sig cc)
+                    nat[p] = NOBASE ? cc[c][p]                              // (a == 0: Lam Sig cc)
+                             : NOSTORE ? (ac[c] * told[p] + cc[c][p])      // Lam (ac mu + Sig cc)
                              : !BLEND ? told[p]
                                       : (step[c] * g[p] + (1.0 - step[c]) * told[p]);
                 double quad = 0.0;
@@ -2284,7 +2309,7 @@ __global__ __launch_bounds__(SNP_THREADS, BLEND ? SNP_MIN_WAVES(P) : SNP_EVAL_WA
                 for (int p = 0; p < P; ++p) {
                     double t = mul[kk][p];
                     if (BLEND || NOSTORE) {
-                        t = NOSTORE ? ac[c] * mul[kk][p] : 0.0;
+                        t = (NOSTORE && !NOBASE) ? ac[c] * mul[kk][p] : 0.0;
 #pragma unroll
                         for (int q = 0; q < P; ++q) t += sig[p][q] * (NOSTORE ? cc[c][q] : nat[q]);
 #if !MU_PAIRED
@@ -2621,14 +2646,26 @@ static void launch_snp_pass_s(const SnpKernelArgs &a, bool stash, hipStream_t s)
                 }
                 hipLaunchKernelGGL(kern, grid, block, lds, s, a);
             };
-            static bool raised = false, raised_lazy = false;
+            static bool raised = false, raised_lazy = false, raised_nobase = false;
             if constexpr (BLEND) {
+                if constexpr (P <= 2) {
+                    if (a.no_store == 2) {      // ... of a state known to have a == 0
+                        launch(snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true, true, true>, raised_nobase);
+                        return;
+                    }
+                }
                 if (a.no_store) {       // a lazy trial that keeps the stash
                     launch(snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true, true>, raised_lazy);
                     return;
                 }
             }
             launch(snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, true>, raised);
+            return;
+        }
+    }
+    if constexpr (P <= 2) {
+        if (a.no_store == 2) {  // a lazy pass of a state known to have a == 0: no vi_mu load compiled in
+            hipLaunchKernelGGL((snp_pass_kernel<P, BLEND, ONE_ANNOT, NS, false, true, true>), grid, block, lds, s, a);
             return;
         }
     }

@@ -152,6 +152,7 @@ struct SweepState {
     // the LOOKAHEAD promise gets back): roles, tau, snapshot buffer
     struct Reported { int32_t mu_role[3], mom_role[3], snap_cur; double tau[VILMA_MAX_P]; bool valid = false;
                       double a_def = 1.0; int32_t c_zero = 1, mu_base = 0; } rep_end;   // (a_def, c_zero, mu_base: persistent lazy state)
+    bool armed_pure = false; // the block was armed with a == 0 (pipeline_arm): without --learn-scaling a stays 0 until it is disarmed
     int last_form = 0;      // form of the state behind the last decision looked at: 0 a stored vi_mu, 1 (stored vi_mu, a, c),
                             // 2 the same with a == 0 (no pass reads vi_mu) -- vilma_prof_state_form
     // statistics of decisions looked at in one call that belong to the next sweep
@@ -670,6 +671,11 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     c->lazy_trial = lazy_trials(c, s);
     c->lazy_persist = lazy_persist(c, s);
     c->lazy_stash = c->lazy_trial && stash;
+    // (a tau update is the one thing that sets a back to 1 on the device behind the host's back)
+    c->lazy_nobase = c->lazy_persist && s->armed_pure && !s->scale_se && c->P <= 2;
+    if (const char *e = std::getenv("VILMA_NOBASE_KERNELS")) {    // =0: the run-time form everywhere (A/B)
+        if (e[0] == '0') c->lazy_nobase = false;
+    }
     set_launch_predicate(&c->ctl->alive);
     if (c->poison) launch_poison(s->results + s->o_ta, s->o_sb + s->am - s->o_ta, 0, st);
     rc = queue_trial_phase(c, st, two, s->results + s->o_ta, s->results + s->o_tb,
@@ -725,6 +731,7 @@ int queue_group(vilma_ctx *c, SweepState *s, hipStream_t st, bool veto, bool fre
     c->lazy_trial = false;
     c->lazy_persist = false;
     c->lazy_stash = false;
+    c->lazy_nobase = false;
     if (!rc) s->groups_out += 1;
     s->pipe_stream = st;
     return rc;
@@ -770,6 +777,7 @@ int pipeline_arm(vilma_ctx *c, SweepState *s, hipStream_t st, const double *L, d
             k.a_def = 0.0;
             k.c_zero = 0;
         }
+        s->armed_pure = pure;
         // (from here on the c buffers change roles on the device: what the host knows about them is
         // void until a write-out re-establishes it, persist_writeback)
         c->pure_c = -1;
